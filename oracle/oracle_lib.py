@@ -134,3 +134,29 @@ def nlp_hess(cfg, x, p, lam_f, lam_g):
                             lam_g.ctypes.data, row.ctypes.data, col.ctypes.data, val.ctypes.data)
     assert n == nnzh, (n, nnzh)
     return row, col, val
+
+
+def ipm_opts(max_iter=60, tol=1e-9, mu_init=0.1, mu_min=1e-10, exact_hessian=1, verbose=0):
+    o = IpmOpts()
+    o.max_iter, o.tol, o.mu_init, o.mu_min, o.exact_hessian, o.verbose = max_iter, tol, mu_init, mu_min, exact_hessian, verbose
+    return o
+
+
+def ref_solve_batch(cfg, P, X0, opts=None, f32=False, nthreads=1):
+    """Structured reference solver (ipm_ref.c).  P[B,np], X0[B,nx] -> X[B,nx], info[B,6]
+    (iterations, kkt error, final mu, #GN fallbacks, primal infeasibility, status)."""
+    opts = opts or ipm_opts()
+    dt = np.float32 if f32 else np.float64
+    P = np.ascontiguousarray(P, dt)
+    X0 = np.ascontiguousarray(X0, dt)
+    B = P.shape[0]
+    nx, npar = dims(cfg)[:2]
+    assert P.shape == (B, npar) and X0.shape == (B, nx)
+    X = np.zeros((B, nx), dt)
+    info = np.zeros((B, 6))
+    fn = lib().cmpc_ref_solve_batch_f32 if f32 else lib().cmpc_ref_solve_batch
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    fn(C.addressof(cfg), C.addressof(opts), B, P.ctypes.data, X0.ctypes.data, X.ctypes.data,
+       info.ctypes.data, nthreads)
+    return X, info

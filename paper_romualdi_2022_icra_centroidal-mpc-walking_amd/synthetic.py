@@ -1,0 +1,141 @@
+"""Synthetic problem batches for the five BASELINE.json configurations.
+
+Every generator returns (cfg, P[B,n_p], X0[B,n_x]) in float64, in the reference's x/p layout
+(layout.py).  Distributions, seeds and the robot mass constant are the ones SURVEY 8d states; the
+URDF is not in the reference tree, so the mass used to normalise pushes is an explicit constant.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import config as _cfg
+from .contacts import PlannedContact, sample_schedule
+from .layout import Layout, cold_start, pack_parameters
+
+ROBOT_MASS = 56.0  # kg, stated constant
+FOOT_Y = 0.08
+
+
+def _tile(d, B):
+    return {k: np.broadcast_to(v, (B,) + v.shape).copy() for k, v in d.items()}
+
+
+def _standing_lists(cfg, horizon_end):
+    return {cfg.contacts[0].contact_name: [PlannedContact(-1.0, horizon_end + 1.0, (0.0, FOOT_Y, 0.0))],
+            cfg.contacts[1].contact_name: [PlannedContact(-1.0, horizon_end + 1.0, (0.0, -FOOT_Y, 0.0))]}
+
+
+def _perturbed_state(rng, B, com_nominal):
+    com0 = np.asarray(com_nominal)[None, :] + rng.uniform(-0.02, 0.02, (B, 3))
+    dcom0 = rng.uniform(-0.1, 0.1, (B, 3))
+    h0 = rng.uniform(-0.05, 0.05, (B, 3))
+    return com0, dcom0, h0
+
+
+def _finish(cfg, sched, com0, dcom0, h0, com_ref, h_ref, f_ext=None):
+    P = pack_parameters(cfg.N, sched["R"], sched["upper"], sched["lower"], sched["enabled"],
+                        sched["nominal"], sched["current"], com0, dcom0, h0, com_ref, h_ref, f_ext)
+    return cfg, P, cold_start(cfg.N, P)
+
+
+def config1_plumbing():
+    """Single iCub3 standing MPC, horizon=10, 2 contacts (CPU-runnable plumbing case)."""
+    cfg = _cfg.icub_gazebo_v3(10, 0.1)
+    B, N = 1, cfg.N
+    sched = _tile(sample_schedule(cfg, _standing_lists(cfg, N * cfg.sampling_time)), B)
+    com0 = np.array([[0.0, 0.0, 0.53]])
+    ref = np.broadcast_to(np.array([0.0, 0.0, 0.53]), (B, N + 1, 3)).copy()
+    return _finish(cfg, sched, com0, np.zeros((B, 3)), np.zeros((B, 3)), ref, np.zeros((B, N + 1, 3)))
+
+
+def config2_perturbed_com(B=256, N=20, seed=0):
+    """Batch of perturbed-CoM standing problems, ergoCubGazeboV1 parameters (the bench workload)."""
+    cfg = _cfg.ergocub_gazebo_v1(N, 0.06)
+    rng = np.random.default_rng(seed)
+    sched = _tile(sample_schedule(cfg, _standing_lists(cfg, N * cfg.sampling_time)), B)
+    com0, dcom0, h0 = _perturbed_state(rng, B, (0.0, 0.0, 0.7))
+    ref = np.broadcast_to(np.array([0.0, 0.0, 0.7]), (B, N + 1, 3)).copy()
+    return _finish(cfg, sched, com0, dcom0, h0, ref, np.zeros((B, N + 1, 3)))
+
+
+def _walking_lists(cfg, swing_start, swing_len, step=0.1):
+    dt = cfg.sampling_time
+    t_end = cfg.N * dt
+    left = [PlannedContact(-1.0, swing_start * dt, (0.0, FOOT_Y, 0.0)),
+            PlannedContact((swing_start + swing_len) * dt, t_end + 1.0, (step, FOOT_Y, 0.0))]
+    right = [PlannedContact(-1.0, t_end + 1.0, (0.0, -FOOT_Y, 0.0))]
+    return {cfg.contacts[0].contact_name: left, cfg.contacts[1].contact_name: right}
+
+
+def config3_external_push(B=4096, N=20, seed=1):
+    """Walking schedule with a swing phase inside the horizon (left Gamma = 1x6, 0x8, 1x6) so the
+    step adjustment is active, plus an external push U(-50,50) N in x,y over the first 0.2 s."""
+    cfg = _cfg.ergocub_gazebo_v1(N, 0.06)
+    rng = np.random.default_rng(seed)
+    sched = _tile(sample_schedule(cfg, _walking_lists(cfg, 6, 8)), B)
+    com0, dcom0, h0 = _perturbed_state(rng, B, (0.0, 0.0, 0.7))
+    ref = np.broadcast_to(np.array([0.0, 0.0, 0.7]), (B, N + 1, 3)).copy()
+    f_ext = np.zeros((B, N, 3))
+    nk = int(np.ceil(0.2 / cfg.sampling_time))
+    push = rng.uniform(-50.0, 50.0, (B, 2)) / ROBOT_MASS
+    f_ext[:, :nk, :2] = push[:, None, :]
+    return _finish(cfg, sched, com0, dcom0, h0, ref, np.zeros((B, N + 1, 3)), f_ext)
+
+
+def config4_monte_carlo(B=65536, N=20, seed=2):
+    """Config-3 generator with seed 2 (sharded 8 x 8192 by bench.py --gpus 8)."""
+    return config3_external_push(B, N, seed)
+
+
+def config5_footstep_candidates(B=8192, N=30, seed=3):
+    """ergoCubGazeboV1, horizon 30.  The reference's MANN generator cannot run here (no onnxruntime,
+    model blob missing), so candidate schedules are synthetic: step length U(0,0.15) m, width
+    0.16+-0.02 m, yaw U(-0.2,0.2) rad, step duration 0.6-0.9 s, double support 0.12-0.24 s."""
+    cfg = _cfg.ergocub_gazebo_v1(N, 0.06)
+    rng = np.random.default_rng(seed)
+    dt, t_end = cfg.sampling_time, N * cfg.sampling_time
+    parts = []
+    for _ in range(B):
+        step_T = rng.uniform(0.6, 0.9)
+        ds = rng.uniform(0.12, 0.24)
+        swing_left = bool(rng.integers(2))
+        feet = {True: [PlannedContact(-1.0, 0.0, (0.0, FOOT_Y, 0.0))],
+                False: [PlannedContact(-1.0, 0.0, (0.0, -FOOT_Y, 0.0))]}
+        t = ds
+        while t < t_end + step_T:
+            stance = feet[not swing_left][-1]
+            land_t = t + (step_T - ds)
+            width = rng.uniform(0.14, 0.18)
+            yaw = rng.uniform(-0.2, 0.2)
+            x = stance.position[0] + rng.uniform(0.0, 0.15)
+            y = stance.position[1] + (width if swing_left else -width)
+            feet[swing_left][-1].deactivation_time = t
+            feet[swing_left].append(PlannedContact(land_t, land_t, (x, y, 0.0), yaw))
+            t = land_t + ds
+            swing_left = not swing_left
+        for lst in feet.values():
+            lst[-1].deactivation_time = t_end + 10.0
+            for a, b in zip(lst[:-1], lst[1:]):
+                if a.deactivation_time <= a.activation_time:
+                    a.deactivation_time = b.activation_time - (step_T - ds)
+        parts.append(sample_schedule(cfg, {cfg.contacts[0].contact_name: feet[True],
+                                           cfg.contacts[1].contact_name: feet[False]}))
+    sched = {k: np.stack([p[k] for p in parts]) for k in parts[0]}
+    com0, dcom0, h0 = _perturbed_state(rng, B, (0.0, 0.0, 0.7))
+    # CoM reference: constant-velocity drift towards the mean of the last nominal foot positions
+    goal = 0.5 * (sched["nominal"][:, 0, -1] + sched["nominal"][:, 1, -1])
+    s = np.linspace(0.0, 1.0, N + 1)[None, :, None]
+    ref = np.zeros((B, N + 1, 3))
+    ref[:, :, :2] = s * goal[:, None, :2]
+    ref[:, :, 2] = 0.7
+    return _finish(cfg, sched, com0, dcom0, h0, ref, np.zeros((B, N + 1, 3)))
+
+
+def standing_known_answer(N=12, dt=0.1, which="tmp"):
+    """The standing problem of SURVEY 8c (iii): tmp.c weight set, N=12, dt=0.1 -> f* = 8.16487469."""
+    cfg = _cfg.generated_code_weights(which, N, dt)
+    sched = _tile(sample_schedule(cfg, _standing_lists(cfg, N * dt)), 1)
+    com0 = np.array([[0.01, -0.005, 0.69]])
+    dcom0 = np.array([[0.02, 0.0, 0.0]])
+    ref = np.broadcast_to(np.array([0.0, 0.0, 0.7]), (1, N + 1, 3)).copy()
+    return _finish(cfg, sched, com0, dcom0, np.zeros((1, 3)), ref, np.zeros((1, N + 1, 3)))
