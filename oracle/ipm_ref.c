@@ -28,7 +28,10 @@
 #include <string.h>
 
 #ifndef REAL
-#define REAL double
+#define REAL double   /* vectors: iterate, residuals, right-hand sides, steps */
+#define MREAL double  /* matrices: linearisation, stage Hessians, Riccati factors */
+#define PREAL double  /* problem I/O: p, x0, x */
+#define CREAL double  /* stage Hessian Quu and its Cholesky (barrier terms z/t span 1e-6..1e9) */
 #define FN(n) n
 #endif
 
@@ -77,11 +80,11 @@ typedef struct {
     const cmpc_nlp_cfg* cfg;
     lay L;
     int N;
-    const REAL* p;            /* parameter vector (reference layout) */
+    const PREAL* p;           /* parameter vector (reference layout) */
     REAL wz2[NMAX + 1];       /* 2 w_z(k)^2 */
     REAL D[3];                /* 2 w_rate */
     /* per-stage constants */
-    REAL arow[NMAX][96];      /* friction rows, world frame: a = R (sx, sy, -mu)^T */
+    MREAL arow[NMAX][96];      /* friction rows, world frame: a = R (sx, sy, -mu)^T */
     REAL qlo[NMAX][6], qhi[NMAX][6];
     int qfree[NMAX][6];
     /* iterate */
@@ -89,10 +92,14 @@ typedef struct {
     /* step */
     REAL dS[NMAX + 1][NS], dU[NMAX][NU], LAMn[NMAX + 1][NS], dT[NMAX][NI], dZ[NMAX][NI];
     /* linearisation + factors */
-    REAL A[NMAX][NS * NS], B[NMAX][NS * NU], d[NMAX][NS];
-    REAL Lc[NMAX][NU * NU], W[NMAX][NU * NXA], lq[NMAX][NU];
+    MREAL A[NMAX][NS * NS], B[NMAX][NS * NU];
+    REAL d[NMAX][NS];
+    MREAL Lc[NMAX][NU * NU], W[NMAX][NU * NXA];
+    REAL lq[NMAX][NU];
     REAL gs[NMAX + 1][NS];    /* tracking gradient */
-    REAL Sx[NMAX][9];         /* exact-Hessian skew block dt*[lam_h]x of the stage (0 if GN) */
+    MREAL Sx[NMAX][9];        /* exact-Hessian skew block dt*[lam_h]x of the stage (0 if GN) */
+    REAL CMU[NMAX][NI];       /* per-row complementarity target (0: affine step; mu - dt_a dz_a: corrector) */
+    REAL DG[NMAX][NI];        /* change of the row coefficient between predictor and corrector */
 } ws;
 
 static const REAL SXr[4] = {1, -1, -1, 1};
@@ -109,7 +116,7 @@ static inline void crossr(const REAL* a, const REAL* b, REAL* o)
 static inline REAL gam_of(const ws* w, int c, int k) { return w->p[w->L.p_gam[c] + k]; }
 
 /* ---------------- problem set-up ---------------- */
-static void setup(ws* w, const cmpc_nlp_cfg* cfg, const REAL* p)
+static void setup(ws* w, const cmpc_nlp_cfg* cfg, const PREAL* p)
 {
     const int N = cfg->N;
     int k, c, j, i, a;
@@ -122,13 +129,13 @@ static void setup(ws* w, const cmpc_nlp_cfg* cfg, const REAL* p)
     for (i = 0; i < 3; ++i) w->D[i] = (REAL)(2.0 * cfg->w_rate[i]);
     for (k = 0; k < N; ++k)
         for (c = 0; c < 2; ++c) {
-            const REAL* R = p + w->L.p_R[c] + 9 * k;
+            const PREAL* R = p + w->L.p_R[c] + 9 * k;
             const REAL gam = gam_of(w, c, k);
             for (j = 0; j < 4; ++j)
                 for (i = 0; i < 4; ++i)
                     for (a = 0; a < 3; ++a)
                         w->arow[k][3 * (16 * c + 4 * j + i) + a] =
-                            SXr[i] * RM(R, a, 0) + SYr[i] * RM(R, a, 1) - (REAL)cfg->mu * RM(R, a, 2);
+                            (MREAL)(SXr[i] * (REAL)RM(R, a, 0) + SYr[i] * (REAL)RM(R, a, 1) - (REAL)cfg->mu * (REAL)RM(R, a, 2));
             for (i = 0; i < 3; ++i) {
                 REAL lo = p[w->L.p_lo[c] + 3 * k + i], hi = p[w->L.p_up[c] + 3 * k + i];
                 w->qlo[k][3 * c + i] = lo; w->qhi[k][3 * c + i] = hi;
@@ -139,19 +146,19 @@ static void setup(ws* w, const cmpc_nlp_cfg* cfg, const REAL* p)
 
 /* ---------------- stage functions ---------------- */
 /* dynamics s+ = phi_k(s,u); optionally the Jacobians A (15x15), B (15x30), row-major */
-static void dyn(const ws* w, int k, const REAL* s, const REAL* u, REAL* sn, REAL* A, REAL* B)
+static void dyn(const ws* w, int k, const REAL* s, const REAL* u, REAL* sn, MREAL* A, MREAL* B)
 {
     const cmpc_nlp_cfg* cfg = w->cfg;
     const lay* L = &w->L;
     const REAL dt = (REAL)cfg->dt;
-    const REAL* p = w->p;
+    const PREAL* p = w->p;
     REAL acc[3], tor[3], Fsum[3] = {0, 0, 0};
     int c, j, i, a;
-    if (A) { memset(A, 0, sizeof(REAL) * NS * NS); memset(B, 0, sizeof(REAL) * NS * NU); }
+    if (A) { memset(A, 0, sizeof(MREAL) * NS * NS); memset(B, 0, sizeof(MREAL) * NS * NU); }
     for (i = 0; i < 3; ++i) { acc[i] = p[L->p_fext + 3 * k + i]; tor[i] = p[L->p_text + 3 * k + i]; }
     acc[2] -= (REAL)cfg->gravity;
     for (c = 0; c < 2; ++c) {
-        const REAL* R = p + L->p_R[c] + 9 * k;
+        const PREAL* R = p + L->p_R[c] + 9 * k;
         const REAL gam = gam_of(w, c, k);
         const REAL* pos = s + 9 + 3 * c;
         REAL Fc[3] = {0, 0, 0};
@@ -210,7 +217,7 @@ static void grad_track(const ws* w, int k, const REAL* s, REAL* gs)
 {
     const cmpc_nlp_cfg* cfg = w->cfg;
     const lay* L = &w->L;
-    const REAL* p = w->p;
+    const PREAL* p = w->p;
     int i, c;
     gs[0] = 2 * (REAL)cfg->w_com[0] * (s[0] - p[L->p_comref + 3 * k + 0]);
     gs[1] = 2 * (REAL)cfg->w_com[1] * (s[1] - p[L->p_comref + 3 * k + 1]);
@@ -257,7 +264,7 @@ static inline int row_active(const ws* w, int k, int i) { return i < 32 ? 1 : w-
 static inline REAL row_val(const ws* w, int k, int i, const REAL* u)
 {
     if (i < 32) {
-        const REAL* a = w->arow[k] + 3 * i;
+        const MREAL* a = w->arow[k] + 3 * i;
         const REAL* f = u + 3 * (i / 4);
         return a[0] * f[0] + a[1] * f[1] + a[2] * f[2];
     }
@@ -268,7 +275,7 @@ static inline REAL row_val(const ws* w, int k, int i, const REAL* u)
 static inline REAL row_dot(const ws* w, int k, int i, const REAL* du)
 {
     if (i < 32) {
-        const REAL* a = w->arow[k] + 3 * i;
+        const MREAL* a = w->arow[k] + 3 * i;
         const REAL* f = du + 3 * (i / 4);
         return a[0] * f[0] + a[1] * f[1] + a[2] * f[2];
     }
@@ -280,24 +287,24 @@ static inline REAL row_dot(const ws* w, int k, int i, const REAL* du)
 static inline void row_axpy(const ws* w, int k, int i, REAL coef, REAL* g)
 {
     if (i < 32) {
-        const REAL* a = w->arow[k] + 3 * i;
+        const MREAL* a = w->arow[k] + 3 * i;
         REAL* f = g + 3 * (i / 4);
         f[0] += a[0] * coef; f[1] += a[1] * coef; f[2] += a[2] * coef;
     } else if (i < 38) g[24 + i - 32] += coef;
     else g[24 + i - 38] -= coef;
 }
 
-static int chol(REAL* A, int n)
+static int chol(CREAL* A, int n)
 {
     int i, j, k;
     for (j = 0; j < n; ++j) {
-        REAL d = A[j * n + j];
+        CREAL d = A[j * n + j];
         for (k = 0; k < j; ++k) d -= A[j * n + k] * A[j * n + k];
         if (!(d > 0)) return 1;
-        d = (REAL)sqrt((double)d);
+        d = (CREAL)sqrt((double)d);
         A[j * n + j] = d;
         for (i = j + 1; i < n; ++i) {
-            REAL v = A[i * n + j];
+            CREAL v = A[i * n + j];
             for (k = 0; k < j; ++k) v -= A[i * n + k] * A[j * n + k];
             A[i * n + j] = v / d;
         }
@@ -367,25 +374,26 @@ static void kkt_error(const ws* w, REAL mu, REAL* stat, REAL* prim, REAL* comp, 
 
 /* ---------------- Riccati backward sweep ---------------- */
 /* builds and factorises the stage QPs; returns 0 ok / 1 non-positive pivot at some stage */
-static int riccati_backward(ws* w, REAL mu, int use_exact)
+static int riccati_backward(ws* w, int use_exact)
 {
     const cmpc_nlp_cfg* cfg = w->cfg;
     const int N = w->N;
     const REAL dt = (REAL)cfg->dt;
-    REAL Pm[NXA * NXA], pv[NXA];
-    REAL Quu[NU * NU], Qux[NU * NXA], qu[NU], Qss[NS * NS], qs[NS], PA[NS * NS], PB[NS * NU], Pd[NS];
+    MREAL Pm[NXA * NXA], Qux[NU * NXA], Qss[NS * NS], PA[NS * NS], PB[NS * NU];
+    CREAL Quu[NU * NU];
+    REAL pv[NXA], qu[NU], qs[NS], Pd[NS];
     int k, i, j, a, b, c, havep = 0;
 
     memset(Pm, 0, sizeof(Pm)); memset(pv, 0, sizeof(pv));
     for (i = 0; i < NS; ++i) { Pm[i * NXA + i] = qdiag(w, N, i); pv[i] = w->gs[N][i]; }
 
     for (k = N - 1; k >= 0; --k) {
-        const REAL* A = w->A[k];
-        const REAL* B = w->B[k];
+        const MREAL* A = w->A[k];
+        const MREAL* B = w->B[k];
         const REAL* d = w->d[k];
         const REAL* u = w->U[k];
-        REAL* Lc = w->Lc[k];
-        REAL* W = w->W[k];
+        MREAL* Lc = w->Lc[k];
+        MREAL* W = w->W[k];
         REAL* lq = w->lq[k];
         REAL gu[NU];
         const int pk = (k > 0);
@@ -406,12 +414,12 @@ static int riccati_backward(ws* w, REAL mu, int use_exact)
             if (!row_active(w, k, i)) continue;
             t = w->T[k][i]; z = w->Z[k][i]; sig = z / t;
             r = row_val(w, k, i, u) + t;
-            row_axpy(w, k, i, mu / t + sig * r, gu);
+            row_axpy(w, k, i, w->CMU[k][i] / t + sig * r, gu);
             if (i < 32) {
-                const REAL* ar = w->arow[k] + 3 * i;
+                const MREAL* ar = w->arow[k] + 3 * i;
                 const int o = 3 * (i / 4);
                 for (a = 0; a < 3; ++a)
-                    for (b = 0; b < 3; ++b) Quu[(o + a) * NU + o + b] += sig * ar[a] * ar[b];
+                    for (b = 0; b < 3; ++b) Quu[(o + a) * NU + o + b] += (CREAL)sig * (CREAL)ar[a] * (CREAL)ar[b];
             } else {
                 const int o = 24 + (i - 32) % 6;
                 Quu[o * NU + o] += sig;
@@ -477,11 +485,11 @@ static int riccati_backward(ws* w, REAL mu, int use_exact)
                 }
             }
         }
-        memset(w->Sx[k], 0, sizeof(REAL) * 9);
+        memset(w->Sx[k], 0, sizeof(MREAL) * 9);
         if (use_exact) {
             /* S[f_cj, pos_c] = dt gam [lam_h]x ; S[f_cj, com] = -dt gam [lam_h]x (lam multiplies phi - s+) */
             const REAL* lh = w->LAM[k + 1] + 6;
-            REAL* Sx = w->Sx[k];
+            MREAL* Sx = w->Sx[k];
             Sx[1] = -dt * lh[2]; Sx[2] = dt * lh[1];
             Sx[3] = dt * lh[2];  Sx[5] = -dt * lh[0];
             Sx[6] = -dt * lh[1]; Sx[7] = dt * lh[0];
@@ -508,9 +516,9 @@ static int riccati_backward(ws* w, REAL mu, int use_exact)
             Qss[i * NS + i] += qdiag(w, k, i);
         }
         /* ---- factorise ---- */
-        memcpy(Lc, Quu, sizeof(Quu));
-        if (chol(Lc, NU)) return 1;
-        memset(W, 0, sizeof(REAL) * NU * NXA);
+        if (chol(Quu, NU)) return 1;
+        for (i = 0; i < NU * NU; ++i) Lc[i] = (MREAL)Quu[i];
+        memset(W, 0, sizeof(MREAL) * NU * NXA);
         for (j = 0; j < ncol; ++j)
             for (i = 0; i < NU; ++i) {
                 REAL v = Qux[i * NXA + j];
@@ -544,15 +552,63 @@ static int riccati_backward(ws* w, REAL mu, int use_exact)
     return 0;
 }
 
+/* vector-only backward sweep for a changed right-hand side: the row coefficients change by DG
+ * (corrector of the predictor-corrector step); updates lq in place using the stored factors */
+static void riccati_delta(ws* w)
+{
+    const int N = w->N;
+    REAL dp[NXA], dq[NU], dl[NU];
+    int k, i, a, havep = 0;
+    memset(dp, 0, sizeof(dp));
+    for (k = N - 1; k >= 0; --k) {
+        const MREAL* A = w->A[k];
+        const MREAL* B = w->B[k];
+        const MREAL* Lc = w->Lc[k];
+        const MREAL* W = w->W[k];
+        const int pk = (k > 0);
+        memset(dq, 0, sizeof(dq));
+        for (i = 0; i < NI; ++i)
+            if (row_active(w, k, i)) row_axpy(w, k, i, w->DG[k][i], dq);
+        for (i = 0; i < NU; ++i) {
+            REAL v = dq[i];
+            for (a = 0; a < NS; ++a) v += B[a * NU + i] * dp[a];
+            if (havep && i < NF) v += dp[NS + i];
+            dq[i] = v;
+        }
+        for (i = 0; i < NU; ++i) {
+            REAL v = dq[i];
+            for (a = 0; a < i; ++a) v -= Lc[i * NU + a] * dl[a];
+            dl[i] = v / Lc[i * NU + i];
+            w->lq[k][i] += dl[i];
+        }
+        {
+            REAL np_[NXA];
+            for (i = 0; i < NS; ++i) {
+                REAL v = 0;
+                for (a = 0; a < NS; ++a) v += A[a * NS + i] * dp[a];
+                for (a = 0; a < NU; ++a) v -= W[a * NXA + i] * dl[a];
+                np_[i] = v;
+            }
+            for (i = NS; i < NXA; ++i) {
+                REAL v = 0;
+                if (pk) for (a = 0; a < NU; ++a) v -= W[a * NXA + i] * dl[a];
+                np_[i] = v;
+            }
+            memcpy(dp, np_, sizeof(dp));
+        }
+        havep = pk;
+    }
+}
+
 /* forward sweep: dS, dU; then new costates LAMn backward; then dT, dZ */
-static void riccati_forward(ws* w, REAL mu)
+static void riccati_forward(ws* w)
 {
     const int N = w->N;
     int k, i, a;
     memset(w->dS[0], 0, sizeof(REAL) * NS);
     for (k = 0; k < N; ++k) {
-        const REAL* W = w->W[k];
-        const REAL* Lc = w->Lc[k];
+        const MREAL* W = w->W[k];
+        const MREAL* Lc = w->Lc[k];
         REAL y[NU];
         for (i = 0; i < NU; ++i) {
             REAL v = w->lq[k][i];
@@ -590,7 +646,7 @@ static void riccati_forward(ws* w, REAL mu)
         }
         /* S^T du: S[f, pos_c] = gam Sx, S[f, com] = -gam Sx  ->  (S^T du)[pos_c] = Sx^T Fc, [com] = -Sx^T Fsum */
         for (i = 0; i < 3; ++i) {
-            const REAL* Sx = w->Sx[k];
+            const MREAL* Sx = w->Sx[k];
             w->LAMn[k][i] -= Sx[0 * 3 + i] * Fsum[0] + Sx[1 * 3 + i] * Fsum[1] + Sx[2 * 3 + i] * Fsum[2];
             for (c = 0; c < 2; ++c)
                 w->LAMn[k][9 + 3 * c + i] += Sx[0 * 3 + i] * Fc[c][0] + Sx[1 * 3 + i] * Fc[c][1] + Sx[2 * 3 + i] * Fc[c][2];
@@ -605,16 +661,16 @@ static void riccati_forward(ws* w, REAL mu)
             r = row_val(w, k, i, w->U[k]) + t;
             dt_ = -r - row_dot(w, k, i, w->dU[k]);
             w->dT[k][i] = dt_;
-            w->dZ[k][i] = (mu - z * t) / t - (z / t) * dt_;
+            w->dZ[k][i] = (w->CMU[k][i] - z * t) / t - (z / t) * dt_;
         }
 }
 
 /* ---------------- initialisation from x0 (reference layout) ---------------- */
-static void init_iterate(ws* w, const REAL* x0, REAL mu0)
+static void init_iterate(ws* w, const PREAL* x0, REAL mu0)
 {
     const lay* L = &w->L;
     const int N = w->N;
-    const REAL* p = w->p;
+    const PREAL* p = w->p;
     int k, c, j, i, a;
     for (k = 0; k <= N; ++k)
         for (i = 0; i < 3; ++i) {
@@ -629,7 +685,7 @@ static void init_iterate(ws* w, const REAL* x0, REAL mu0)
     }
     for (k = 0; k < N; ++k) {
         for (c = 0; c < 2; ++c) {
-            const REAL* R = p + L->p_R[c] + 9 * k;
+            const PREAL* R = p + L->p_R[c] + 9 * k;
             for (j = 0; j < 4; ++j)
                 for (i = 0; i < 3; ++i) w->U[k][12 * c + 3 * j + i] = x0[L->o_f[c][j] + 3 * k + i];
             for (i = 0; i < 3; ++i) {
@@ -659,7 +715,7 @@ static void init_iterate(ws* w, const REAL* x0, REAL mu0)
     memset(w->LAM, 0, sizeof(w->LAM));
 }
 
-static void export_x(const ws* w, REAL* x)
+static void export_x(const ws* w, PREAL* x)
 {
     const lay* L = &w->L;
     const int N = w->N;
@@ -676,58 +732,97 @@ static void export_x(const ws* w, REAL* x)
         for (c = 0; c < 2; ++c) {
             const REAL gam = gam_of(w, c, k);
             for (i = 0; i < 3; ++i)
-                x[L->o_vel[c] + 3 * k + i] = gam < (REAL)0.5 ? (w->S[k + 1][9 + 3 * c + i] - w->S[k][9 + 3 * c + i]) / dt : 0;
+                x[L->o_vel[c] + 3 * k + i] = (PREAL)(gam < (REAL)0.5 ? (w->S[k + 1][9 + 3 * c + i] - w->S[k][9 + 3 * c + i]) / dt : 0);
             for (j = 0; j < 4; ++j)
                 for (i = 0; i < 3; ++i) x[L->o_f[c][j] + 3 * k + i] = w->U[k][12 * c + 3 * j + i];
         }
 }
 
 /* ---------------- driver ---------------- */
+static void step_lengths(const ws* w, REAL tau, REAL* ap_out, REAL* ad_out)
+{
+    const int N = w->N;
+    REAL ap = 1, ad = 1;
+    int k, i;
+    for (k = 0; k < N; ++k)
+        for (i = 0; i < NI; ++i) {
+            if (!row_active(w, k, i)) continue;
+            if (w->dT[k][i] < 0) { REAL a = -tau * w->T[k][i] / w->dT[k][i]; if (a < ap) ap = a; }
+            if (w->dZ[k][i] < 0) { REAL a = -tau * w->Z[k][i] / w->dZ[k][i]; if (a < ad) ad = a; }
+        }
+    *ap_out = ap; *ad_out = ad;
+}
+
 /* info: [0]=iterations [1]=kkt error [2]=final mu [3]=#GN fallbacks [4]=primal inf [5]=status */
-int FN(cmpc_ref_solve_one)(const cmpc_nlp_cfg* cfg, const cmpc_ipm_opts* opt, const REAL* p, const REAL* x0,
-                           REAL* x, double* info)
+int FN(cmpc_ref_solve_one)(const cmpc_nlp_cfg* cfg, const cmpc_ipm_opts* opt, const PREAL* p, const PREAL* x0,
+                           PREAL* x, double* info)
 {
     ws* w = (ws*)malloc(sizeof(ws));
     const int N = cfg->N;
-    REAL mu = (REAL)opt->mu_init;
-    const REAL tau_min = (REAL)0.99;
-    int it, k, i, gn = 0, status = 1;
-    REAL err = 0, es = 0, ep = 0, ec = 0, zavg = 0;
+    int it, k, i, gn = 0, status = 1, nrow = 0;
+    REAL err = 0, es = 0, ep = 0, ec = 0, zavg = 0, mu_cur = 0;
     if (!w || N > NMAX) { free(w); return -1; }
     setup(w, cfg, p);
-    init_iterate(w, x0, mu);
+    init_iterate(w, x0, (REAL)opt->mu_init);
+    for (k = 0; k < N; ++k) for (i = 0; i < NI; ++i) nrow += row_active(w, k, i);
     for (it = 0; it < opt->max_iter; ++it) {
-        REAL sd, ap = 1, ad = 1, tau;
+        REAL ap, ad, tau, lmax = 1, mu_aff = 0, sigma, mu_t;
         int fail;
         linearise(w);
         kkt_error(w, 0, &es, &ep, &ec, &zavg);
-        sd = zavg > 100 ? zavg / 100 : 1;
-        err = es / sd; if (ep > err) err = ep; if (ec / sd > err) err = ec / sd;
+        for (k = 1; k <= N; ++k)
+            for (i = 0; i < NS; ++i) { REAL a = (REAL)fabs((double)w->LAM[k][i]); if (a > lmax) lmax = a; }
+        mu_cur = 0;
+        for (k = 0; k < N; ++k) for (i = 0; i < NI; ++i) if (row_active(w, k, i)) mu_cur += w->T[k][i] * w->Z[k][i];
+        mu_cur /= (REAL)nrow;
+        /* scaled like IPOPT's E_0 with s_d = s_max = 100: stationarity is judged at 100*tol */
+        (void)lmax;
+        err = es * (REAL)0.01; if (ep > err) err = ep; if (ec > err) err = ec;
         if (opt->verbose)
-            printf("it %3d mu %.1e stat %.2e prim %.2e comp %.2e\n", it, (double)mu, (double)es, (double)ep, (double)ec);
-        if (err <= (REAL)opt->tol) { status = 0; break; }
-        /* monotone barrier update (IPOPT eq. 7): shrink mu while the barrier problem is solved */
-        for (;;) {
-            REAL emu;
-            kkt_error(w, mu, &es, &ep, &ec, &zavg);
-            emu = es / sd; if (ep > emu) emu = ep; if (ec / sd > emu) emu = ec / sd;
-            if (mu > (REAL)opt->mu_min && emu <= 10 * mu) {
-                REAL m1 = (REAL)0.2 * mu, m2 = (REAL)pow((double)mu, 1.5);
-                mu = m1 < m2 ? m1 : m2;
-                if (mu < (REAL)opt->mu_min) mu = (REAL)opt->mu_min;
-            } else break;
+            printf("it %3d mu %.2e stat %.2e (rel %.2e) prim %.2e comp %.2e\n", it, (double)mu_cur, (double)es, (double)(es / lmax), (double)ep, (double)ec);
+        if (err <= (REAL)opt->tol) {
+            /* converged on the central path at mu ~ mu_min: one last affine-scaling (mu -> 0) step
+             * extrapolates the path to its end point x(0) = x* without going through the
+             * ill-conditioned small-mu systems (first-order path following, error O(mu^2)) */
+            status = 0;
+            if (opt->verbose >= 0) {
+                memset(w->CMU, 0, sizeof(w->CMU));
+                fail = riccati_backward(w, opt->exact_hessian);
+                if (fail) fail = riccati_backward(w, 0);
+                if (!fail) {
+                    riccati_forward(w);
+                    step_lengths(w, (REAL)0.999, &ap, &ad);
+                    for (k = 0; k <= N; ++k) for (i = 0; i < NS; ++i) w->S[k][i] += ap * w->dS[k][i];
+                    for (k = 0; k < N; ++k) for (i = 0; i < NU; ++i) w->U[k][i] += ap * w->dU[k][i];
+                }
+            }
+            break;
         }
-        fail = riccati_backward(w, mu, opt->exact_hessian);
-        if (fail) { ++gn; fail = riccati_backward(w, mu, 0); }
+        /* predictor (affine scaling) */
+        memset(w->CMU, 0, sizeof(w->CMU));
+        fail = riccati_backward(w, opt->exact_hessian);
+        if (fail) { ++gn; fail = riccati_backward(w, 0); }
         if (fail) { status = 2; break; }
-        riccati_forward(w, mu);
-        tau = 1 - mu; if (tau < tau_min) tau = tau_min;
+        riccati_forward(w);
+        step_lengths(w, 1, &ap, &ad);
+        for (k = 0; k < N; ++k)
+            for (i = 0; i < NI; ++i)
+                if (row_active(w, k, i)) mu_aff += (w->T[k][i] + ap * w->dT[k][i]) * (w->Z[k][i] + ad * w->dZ[k][i]);
+        mu_aff /= (REAL)nrow;
+        sigma = mu_aff / mu_cur; sigma = sigma * sigma * sigma;
+        mu_t = sigma * mu_cur;
+        if (mu_t < (REAL)opt->mu_min) mu_t = (REAL)opt->mu_min;
+        /* corrector */
         for (k = 0; k < N; ++k)
             for (i = 0; i < NI; ++i) {
                 if (!row_active(w, k, i)) continue;
-                if (w->dT[k][i] < 0) { REAL a = -tau * w->T[k][i] / w->dT[k][i]; if (a < ap) ap = a; }
-                if (w->dZ[k][i] < 0) { REAL a = -tau * w->Z[k][i] / w->dZ[k][i]; if (a < ad) ad = a; }
+                w->CMU[k][i] = mu_t - w->dT[k][i] * w->dZ[k][i];
+                w->DG[k][i] = w->CMU[k][i] / w->T[k][i];
             }
+        riccati_delta(w);
+        riccati_forward(w);
+        tau = 1 - mu_t; if (tau < (REAL)0.99) tau = (REAL)0.99;
+        step_lengths(w, tau, &ap, &ad);
         for (k = 0; k <= N; ++k)
             for (i = 0; i < NS; ++i) {
                 w->S[k][i] += ap * w->dS[k][i];
@@ -737,17 +832,17 @@ int FN(cmpc_ref_solve_one)(const cmpc_nlp_cfg* cfg, const cmpc_ipm_opts* opt, co
             for (i = 0; i < NU; ++i) w->U[k][i] += ap * w->dU[k][i];
             for (i = 0; i < NI; ++i) { w->T[k][i] += ap * w->dT[k][i]; w->Z[k][i] += ad * w->dZ[k][i]; }
         }
-        if (opt->verbose) printf("        ap %.3f ad %.3f\n", (double)ap, (double)ad);
+        if (opt->verbose) printf("        sigma %.2e mu_t %.2e ap %.3f ad %.3f\n", (double)sigma, (double)mu_t, (double)ap, (double)ad);
     }
     export_x(w, x);
-    if (info) { info[0] = it; info[1] = (double)err; info[2] = (double)mu; info[3] = gn; info[4] = (double)ep; info[5] = status; }
+    if (info) { info[0] = it; info[1] = (double)err; info[2] = (double)mu_cur; info[3] = gn; info[4] = (double)ep; info[5] = status; }
     free(w);
     return status;
 }
 
 /* batch driver, OpenMP over problems: P[B][np], X0[B][nx] -> X[B][nx], info[B][6] */
-int FN(cmpc_ref_solve_batch)(const cmpc_nlp_cfg* cfg, const cmpc_ipm_opts* opt, int B, const REAL* P, const REAL* X0,
-                             REAL* X, double* info, int nthreads)
+int FN(cmpc_ref_solve_batch)(const cmpc_nlp_cfg* cfg, const cmpc_ipm_opts* opt, int B, const PREAL* P, const PREAL* X0,
+                             PREAL* X, double* info, int nthreads)
 {
     lay L;
     int b, bad = 0;

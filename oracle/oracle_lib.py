@@ -39,7 +39,7 @@ class IpmOpts(C.Structure):
 
 
 def build(force=False):
-    srcs = [os.path.join(_HERE, s) for s in ("nlp_ref.c", "ipm_ref.c", "cmpc_oracle.h")]
+    srcs = [os.path.join(_HERE, s) for s in ("nlp_ref.c", "ipm_ref.c", "ipm_ref_f32.c", "ipm_ref_mix.c", "cmpc_oracle.h")]
     if (not force and os.path.exists(_LIB)
             and all(os.path.getmtime(_LIB) >= os.path.getmtime(s) for s in srcs)):
         return _LIB
@@ -142,11 +142,11 @@ def ipm_opts(max_iter=60, tol=1e-9, mu_init=0.1, mu_min=1e-10, exact_hessian=1, 
     return o
 
 
-def ref_solve_batch(cfg, P, X0, opts=None, f32=False, nthreads=1):
+def ref_solve_batch(cfg, P, X0, opts=None, f32=False, nthreads=1, mix=False):
     """Structured reference solver (ipm_ref.c).  P[B,np], X0[B,nx] -> X[B,nx], info[B,6]
     (iterations, kkt error, final mu, #GN fallbacks, primal infeasibility, status)."""
     opts = opts or ipm_opts()
-    dt = np.float32 if f32 else np.float64
+    dt = np.float32 if (f32 or mix) else np.float64
     P = np.ascontiguousarray(P, dt)
     X0 = np.ascontiguousarray(X0, dt)
     B = P.shape[0]
@@ -154,7 +154,7 @@ def ref_solve_batch(cfg, P, X0, opts=None, f32=False, nthreads=1):
     assert P.shape == (B, npar) and X0.shape == (B, nx)
     X = np.zeros((B, nx), dt)
     info = np.zeros((B, 6))
-    fn = lib().cmpc_ref_solve_batch_f32 if f32 else lib().cmpc_ref_solve_batch
+    fn = lib().cmpc_ref_solve_batch_mix if mix else (lib().cmpc_ref_solve_batch_f32 if f32 else lib().cmpc_ref_solve_batch)
     fn.restype = C.c_int
     fn.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
     fn(C.addressof(cfg), C.addressof(opts), B, P.ctypes.data, X0.ctypes.data, X.ctypes.data,

@@ -1,0 +1,53 @@
+"""Parity metrics shared by the oracle and GPU tests.
+
+north_star tolerance: <= 1e-4 relative error on the CoM trajectory and the contact forces, against
+the converged float64 solve of the same NLP (SURVEY 7 hard part 5 / 8d).
+
+Contact forces are compared modulo the one direction the NLP does not determine: when both feet
+are in stance over the whole horizon, a constant internal force along the line joining the two
+feet (left corners +e, right corners -e, every knot) changes neither the dynamics (zero net force,
+zero net moment) nor the cost (the symmetry cost sees differences between corners of one foot, the
+rate cost differences in time), so the optimal set is a segment, not a point, and two exact solvers
+(or two IPOPT linear solvers) land on different points of it.
+"""
+import numpy as np
+
+import cmpc_amd as cm
+
+
+def _internal_force_direction(L, p):
+    N = L.N
+    gam = np.concatenate([p[L.p_gam[c]:L.p_gam[c] + N] for c in range(2)])
+    if not (gam > 0.5).all():
+        return None
+    e = p[L.p_cur[0]:L.p_cur[0] + 3] - p[L.p_cur[1]:L.p_cur[1] + 3]
+    e = e / np.linalg.norm(e)
+    n = np.zeros(L.nx)
+    for c, sgn in ((0, 1.0), (1, -1.0)):
+        for j in range(4):
+            n[L.f[c][j]:L.f[c][j] + 3 * N] = np.tile(sgn * e, N)
+    return n / np.linalg.norm(n)
+
+
+def errors(N, p, x, x_ref):
+    """-> dict(com, force0, forces, pos, dcom, h): relative (max-norm) errors; pos absolute [m]."""
+    L = cm.Layout(N)
+    x = np.asarray(x, np.float64)
+    x_ref = np.asarray(x_ref, np.float64)
+    d = x - x_ref
+    n = _internal_force_direction(L, np.asarray(p, np.float64))
+    if n is not None:
+        d = d - n * (n @ d)
+
+    def rel(a, b):
+        return float(np.abs(a).max() / max(np.abs(b).max(), 1e-12))
+
+    fall = np.concatenate([np.arange(L.f[c][j], L.f[c][j] + 3 * N) for c in range(2) for j in range(4)])
+    return dict(
+        com=rel(L.x_com(d), L.x_com(x_ref)),
+        dcom=rel(L.x_dcom(d), np.maximum(np.abs(L.x_dcom(x_ref)), 1e-2)),
+        h=float(np.abs(L.x_h(d)).max()),
+        pos=float(max(np.abs(L.x_pos(d, c)).max() for c in range(2))),
+        force0=rel(L.first_forces(d), L.first_forces(x_ref)),
+        forces=rel(d[fall], x_ref[fall]),
+    )

@@ -1,0 +1,107 @@
+"""Pins the solvers under oracle/ (test infrastructure): the generic IPOPT-style solver that makes
+the argmin goldens, and the stage-structured reference solver (ipm_ref.c) the HIP kernels restate.
+
+What the reference itself pins: nothing at the argmin level (it has no tests) -> the
+goldens are pinned by KKT residuals evaluated with the reference's own generated functions
+(oracle/_ref, N=12) and with nlp_ref.c (pinned to those at 1e-12 in test_oracle_nlp.py).
+"""
+import os
+
+import numpy as np
+import pytest
+
+import cmpc_amd as cm
+from oracle import ipm_generic, oracle_lib as ol, problem_nlp
+from tests import parity
+
+CASES = {"known_answer_n12": lambda: cm.synthetic.standing_known_answer(),
+         "cfg1": lambda: cm.synthetic.config1_plumbing(),
+         "cfg2": lambda: cm.synthetic.config2_perturbed_com(8),
+         "cfg3": lambda: cm.synthetic.config3_external_push(8),
+         "cfg5": lambda: cm.synthetic.config5_footstep_candidates(4)}
+
+
+def _load(name, golden_dir):
+    d = np.load(os.path.join(golden_dir, f"argmin_{name}.npz"))
+    cfg = CASES[name]()[0]
+    assert cfg.N == int(d["N"])
+    return cfg, d
+
+
+def test_known_answer_standing_problem():
+    """tmp.c weights, N=12, dt=0.1 -> f* = 8.16487469, sum f_z(0) = 10.2207,
+    com_x 0.0100 ... 0.1329 (measured by the survey with an independent solver)."""
+    cfg, P, X0 = cm.synthetic.standing_known_answer()
+    oc = problem_nlp.oracle_cfg(cfg)
+    L = cm.Layout(cfg.N)
+    lb, ub = problem_nlp.bounds(cfg, P[0])
+    r = ipm_generic.solve(oc, P[0], lb, ub, X0[0])
+    X, info = ol.ref_solve_batch(oc, P, X0)
+    for x in (r["x"], X[0]):
+        f, _ = ol.nlp_fg(oc, x, P[0])
+        assert abs(f - 8.16487469) < 5e-8
+        assert abs(L.first_forces(x)[..., 2].sum() - 10.2207) < 1e-4
+        cx = L.x_com(x)[:, 0]
+        assert abs(cx[0] - 0.0100) < 1e-4 and abs(cx[-1] - 0.1329) < 1e-4
+    assert info[0, 5] == 0
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_golden_satisfies_kkt(name, golden_dir):
+    cfg, d = _load(name, golden_dir)
+    oc = problem_nlp.oracle_cfg(cfg)
+    nx, _, ng, _, _ = ol.dims(oc)
+    refs = []
+    if name == "known_answer_n12":
+        try:
+            from oracle import ref_nlp
+            refs.append(ref_nlp.RefNLP("tmp"))
+        except (ImportError, FileNotFoundError):
+            pass
+    for b in range(d["P"].shape[0]):
+        p = d["P"][b].astype(np.float64)
+        x, lam = d["x_star"][b], d["lam_g"][b]
+        lb, ub = problem_nlp.bounds(cfg, p)
+        f, g = ol.nlp_fg(oc, x, p)
+        assert abs(f - d["f_star"][b]) < 1e-9 * max(1, abs(f))
+        gf = ol.nlp_grad_f(oc, x, p)
+        r, c, v = ol.nlp_jac(oc, x, p)
+        J = np.zeros((ng, nx)); np.add.at(J, (r, c), v)
+        scale = max(1.0, np.abs(lam).max())
+        assert np.abs(gf + J.T @ lam).max() <= 1e-7 * scale
+        assert (g >= lb - 1e-8).all() and (g <= ub + 1e-8).all()
+        ineq = ub - lb > 1e-12
+        # complementarity: multiplier sign matches the active side
+        assert (np.abs(lam[ineq] * np.minimum(g[ineq] - lb[ineq], ub[ineq] - g[ineq])) <= 1e-6 * scale).all()
+        for ref in refs:  # the reference's own generated code says the same
+            f0, gf0, g0, J0 = ref.jac_fg(x, p)
+            assert abs(f0 - f) < 1e-10
+            assert np.abs(gf0 + J0.T @ lam).max() <= 1e-7 * scale
+            assert (g0 >= lb - 1e-8).all() and (g0 <= ub + 1e-8).all()
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_structured_reference_solver_matches_golden(name, golden_dir):
+    cfg, d = _load(name, golden_dir)
+    oc = problem_nlp.oracle_cfg(cfg)
+    P, X0 = d["P"].astype(np.float64), d["X0"].astype(np.float64)
+    X, info = ol.ref_solve_batch(oc, P, X0, ol.ipm_opts(tol=1e-9, mu_min=1e-10))
+    assert (info[:, 5] == 0).all()
+    for b in range(P.shape[0]):
+        e = parity.errors(cfg.N, P[b], X[b], d["x_star"][b])
+        assert e["com"] < 1e-7 and e["forces"] < 2e-5 and e["pos"] < 2e-6, e
+        f, _ = ol.nlp_fg(oc, X[b], P[b])
+        assert abs(f - d["f_star"][b]) <= 1e-7 * max(1.0, abs(f))
+
+
+@pytest.mark.parametrize("name", ["cfg2", "cfg3", "cfg5"])
+def test_hip_arithmetic_model_meets_tolerance(name, golden_dir):
+    """ipm_ref.c built with the HIP kernels' arithmetic (float32 I/O and matrices, float64 vectors
+    and stage Cholesky), default GPU options: inside the 1e-4 north_star tolerance with margin."""
+    cfg, d = _load(name, golden_dir)
+    oc = problem_nlp.oracle_cfg(cfg)
+    X, info = ol.ref_solve_batch(oc, d["P"], d["X0"], ol.ipm_opts(tol=1e-6, mu_min=1e-7, max_iter=40), mix=True)
+    assert (info[:, 5] == 0).all()
+    for b in range(d["P"].shape[0]):
+        e = parity.errors(cfg.N, d["P"][b], X[b], d["x_star"][b])
+        assert e["com"] < 5e-5 and e["force0"] < 5e-5 and e["pos"] < 5e-5, e
