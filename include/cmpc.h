@@ -1,0 +1,127 @@
+/* cmpc.h -- C ABI of the MI355X batched centroidal-MPC solver (libcmpc_hip.so).
+ *
+ * Drop-in boundary for ONE path of GiulioRomualdi/paper_romualdi_2022_icra_centroidal-mpc-walking:
+ * the solve inside BipedalLocomotion::ReducedModelControllers::CentroidalMPC, as the reference
+ * drives it from src/centroidal-mpc-walking/src/CentroidalMPCBlock.cpp:
+ *     initialize              :144   -> cmpc_create            (keys of config/robots/<robot>/centroidal_mpc.ini)
+ *     setState                :407   -> cmpc_set_state
+ *     setReferenceTrajectory  :579   -> cmpc_set_reference
+ *     setContactPhaseList     :609   -> cmpc_set_contacts
+ *     advance                 :615   -> cmpc_solve / cmpc_solve_device   (replaces CasADi Opti -> IPOPT)
+ *     getOutput               :622   -> cmpc_get_solution / cmpc_get_output
+ * and the NLP callbacks IPOPT would call (generated code config/robots/ergoCubGazeboV1/tmp.c:
+ * nlp_fg :12430, nlp_jac_fg :71962, nlp_hess_l :58926) -> cmpc_eval_nlp_device.
+ *
+ * Conventions: plain C, no exceptions; every function returns 0 on success or a negative
+ * cmpc_status; cmpc_last_error() gives the text.  The caller owns every buffer it passes; the
+ * handle owns its device buffers; one handle = one device + one HIP stream, single caller
+ * (the reference calls the class from one thread, Main.cpp:98-110).
+ *
+ * Data layout: decision vector x[n_x] and parameter vector p[n_p] of every problem are laid out
+ * exactly as in the reference's generated NLP (tmp.c:62-67): n_x = 45N+15, n_p = 50N+27,
+ *   x = com[3(N+1)] dcom[3(N+1)] h[3(N+1)] then per contact (left_foot, right_foot):
+ *       pos[3(N+1)] vel[3N] f_corner0..3[3N each]           (3 x knots, column-major)
+ *   p = per contact: R[9N] (vec of 3x3 col-major per knot) upper[3N] lower[3N] enabled[N]
+ *       nominalPos[3(N+1)] currentPos[3]; then com0 dcom0 h0 comRef[3(N+1)] hRef[3(N+1)]
+ *       fExt[3N] tauExt[3N]
+ * Batches are row-major: P[B][n_p], X[B][n_x], float32.
+ */
+#ifndef CMPC_H
+#define CMPC_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct cmpc_handle_s* cmpc_handle;
+
+typedef enum {
+    CMPC_OK = 0,
+    CMPC_ERR_ARG = -1,       /* bad argument / unsupported configuration */
+    CMPC_ERR_HIP = -2,       /* HIP runtime error (no device, allocation, launch) */
+    CMPC_ERR_NOT_CONVERGED = -3 /* at least one problem of the batch did not converge (see info) */
+} cmpc_status;
+
+/* keys of centroidal_mpc.ini (ergoCubGazeboV1/centroidal_mpc.ini:3-42) + solver options */
+typedef struct {
+    int horizon;              /* N = time_horizon / sampling_time (or controller_horizon)        */
+    double sampling_time;     /* dt                                                               */
+    double friction_coefficient; /* static_friction_coefficient (number_of_slices must be 1)      */
+    double gravity;           /* 9.80665                                                          */
+    double com_weight[3];
+    double angular_momentum_weight;
+    double contact_position_weight;
+    double force_rate_of_change_weight[3];
+    double contact_force_symmetry_weight;
+    double corners[2][4][3];  /* [CONTACT_i] corner_j, contacts in alphabetical name order        */
+    /* solver options (ipopt_tolerance / ipopt_max_iteration take the place of IPOPT's) */
+    int max_iterations;       /* Newton iteration budget per solve (default 40)                   */
+    double tolerance;         /* on primal residuals, complementarity and 0.1 x Newton step (default 1e-6) */
+    double mu_init;           /* initial barrier parameter (default 0.1)                          */
+    double mu_min;            /* final barrier parameter (default 1e-7)                           */
+    int exact_hessian;        /* 1 (default): Lagrangian Hessian; 0: Gauss-Newton                 */
+    int final_extrapolation;  /* 1: finish with one extra affine-scaling step towards mu = 0 (default 0) */
+} cmpc_config;
+
+/* number of floats per solve in the info array */
+#define CMPC_INFO 8
+/* info[b] = { iterations, kkt_error, mu, gauss_newton_fallbacks, primal_inf, status(0 ok,1 max
+ * iter,2 factorisation failed), solve_cycles (shader clock), stationarity residual } */
+
+void cmpc_default_config(cmpc_config* cfg);                      /* ergoCubGazeboV1 values, N=20 */
+int cmpc_dims(int horizon, int* n_x, int* n_p, int* n_g, int* nnz_jac, int* nnz_hess);
+
+int cmpc_create(const cmpc_config* cfg, int batch, int device, cmpc_handle* out);
+int cmpc_destroy(cmpc_handle h);
+const char* cmpc_last_error(cmpc_handle h);                       /* h may be NULL */
+int cmpc_batch(cmpc_handle h);
+void* cmpc_stream(cmpc_handle h);                                 /* hipStream_t of the handle */
+
+/* ---- the hot path: solve a batch, operands resident in device memory ----
+ * dP[B][n_p], dX0[B][n_x] (initial guess), dX[B][n_x] (solution), dInfo[B][CMPC_INFO] or NULL.
+ * Asynchronous on the handle's stream (or on `stream` if non-NULL); nothing is copied. */
+int cmpc_solve_device(cmpc_handle h, const float* dP, const float* dX0, float* dX, float* dInfo,
+                      void* stream);
+/* host buffers (includes the PCIe copies; synchronous). info may be NULL. Returns
+ * CMPC_ERR_NOT_CONVERGED if any problem's status != 0 (the solutions are still written). */
+int cmpc_solve(cmpc_handle h, const float* P, const float* X0, float* X, float* info);
+/* duration of the last solve kernel in ms (HIP events on the launch stream); < 0 if none */
+float cmpc_last_solve_ms(cmpc_handle h);
+
+/* ---- NLP callbacks (what IPOPT evaluated through the generated code), batched on the device ----
+ * any output pointer may be NULL.  dLamG[B][n_g], lam_f scalar (hess of lam_f f + lam_g^T g).
+ * dJac[B][nnz_jac] / dHess[B][nnz_hess] are in the reference's CCS nonzero order
+ * (cmpc_nlp_sparsity gives row/col per nonzero; tmp.c:66-67 for N=12). */
+int cmpc_eval_nlp_device(cmpc_handle h, const float* dX, const float* dP, const float* dLamG,
+                         float lam_f, float* dF, float* dG, float* dGradF, float* dJac,
+                         float* dHess, void* stream);
+int cmpc_nlp_sparsity(int horizon, int* jac_row, int* jac_col, int* hess_row, int* hess_col);
+
+/* ---- class-shaped setters (host buffers -> the handle's own device P, X0) ----
+ * batch-major float32; NULL keeps the previous value (zeros initially).
+ *   state    [B][9]            com0, dcom0, h0 (h and wrench already mass-normalised,
+ *                              CentroidalMPCBlock.cpp:403-410)
+ *   wrench   [B][N][6]         external force (3) and torque (3) per knot, or NULL = 0
+ *   com_ref, h_ref [B][N+1][3]
+ *   R [B][2][N][9] row-major 3x3, upper/lower [B][2][N][3], enabled [B][2][N],
+ *   nominal [B][2][N+1][3], current [B][2][3] */
+int cmpc_set_state(cmpc_handle h, const float* state, const float* wrench);
+int cmpc_set_reference(cmpc_handle h, const float* com_ref, const float* h_ref);
+int cmpc_set_contacts(cmpc_handle h, const float* R, const float* upper, const float* lower,
+                      const float* enabled, const float* nominal, const float* current);
+/* x0: [B][n_x] or NULL = cold start (CoM at com0, feet at nominal, f_z = g/8 per corner);
+ * shift_previous != 0: warm start from the previous solution shifted by one knot
+ * (is_warm_start_enabled, ergoCubGazeboV1/centroidal_mpc.ini:9) */
+int cmpc_set_initial_guess(cmpc_handle h, const float* x0, int shift_previous);
+/* solve the handle's own problem set (set_* above); synchronous */
+int cmpc_advance(cmpc_handle h);
+int cmpc_get_solution(cmpc_handle h, float* X, float* info);
+/* compact output of getOutput(): per problem first-knot corner forces [2][4][3], contact
+ * positions at knot 0 [2][3], next (adjusted) landing position per contact [2][3] and its knot
+ * index [2] (-1 if the contact does not land inside the horizon) */
+int cmpc_get_output(cmpc_handle h, float* forces0, float* pos0, float* next_pos, int* next_knot);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CMPC_H */

@@ -1,0 +1,85 @@
+"""ctypes binding of libcmpc_hip.so (include/cmpc.h).  There is no CPU path: if the HIP library is
+missing or fails to load, every entry point raises."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcmpc_hip.so")
+
+INFO = 8
+
+
+class CmpcConfig(C.Structure):
+    _fields_ = [
+        ("horizon", C.c_int),
+        ("sampling_time", C.c_double),
+        ("friction_coefficient", C.c_double),
+        ("gravity", C.c_double),
+        ("com_weight", C.c_double * 3),
+        ("angular_momentum_weight", C.c_double),
+        ("contact_position_weight", C.c_double),
+        ("force_rate_of_change_weight", C.c_double * 3),
+        ("contact_force_symmetry_weight", C.c_double),
+        ("corners", C.c_double * 24),
+        ("max_iterations", C.c_int),
+        ("tolerance", C.c_double),
+        ("mu_init", C.c_double),
+        ("mu_min", C.c_double),
+        ("exact_hessian", C.c_int),
+        ("final_extrapolation", C.c_int),
+    ]
+
+
+EXPORTS = [
+    "cmpc_default_config", "cmpc_dims", "cmpc_create", "cmpc_destroy", "cmpc_last_error",
+    "cmpc_batch", "cmpc_stream", "cmpc_solve_device", "cmpc_solve", "cmpc_last_solve_ms",
+    "cmpc_eval_nlp_device", "cmpc_nlp_sparsity", "cmpc_set_state", "cmpc_set_reference",
+    "cmpc_set_contacts", "cmpc_set_initial_guess", "cmpc_advance", "cmpc_get_solution",
+    "cmpc_get_output",
+]
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). This package has no CPU fallback.")
+        try:
+            # PyTorch-ROCm wheels bundle their own libamdhip64.so.7; import it first so that this
+            # library binds to the same HIP runtime (two runtimes in one process cannot share the GPU)
+            import torch  # noqa: F401
+        except ImportError:
+            pass
+        L = C.CDLL(LIB_PATH)
+        vp, ip, fp = C.c_void_p, C.POINTER(C.c_int), C.c_void_p
+        L.cmpc_default_config.argtypes = [C.POINTER(CmpcConfig)]
+        L.cmpc_default_config.restype = None
+        L.cmpc_dims.argtypes = [C.c_int, ip, ip, ip, ip, ip]
+        L.cmpc_create.argtypes = [C.POINTER(CmpcConfig), C.c_int, C.c_int, C.POINTER(vp)]
+        L.cmpc_destroy.argtypes = [vp]
+        L.cmpc_last_error.argtypes = [vp]
+        L.cmpc_last_error.restype = C.c_char_p
+        L.cmpc_batch.argtypes = [vp]
+        L.cmpc_stream.argtypes = [vp]
+        L.cmpc_stream.restype = vp
+        L.cmpc_solve_device.argtypes = [vp, fp, fp, fp, fp, vp]
+        L.cmpc_solve.argtypes = [vp, fp, fp, fp, fp]
+        L.cmpc_last_solve_ms.argtypes = [vp]
+        L.cmpc_last_solve_ms.restype = C.c_float
+        L.cmpc_eval_nlp_device.argtypes = [vp, fp, fp, fp, C.c_float, fp, fp, fp, fp, fp, vp]
+        L.cmpc_nlp_sparsity.argtypes = [C.c_int, vp, vp, vp, vp]
+        L.cmpc_set_state.argtypes = [vp, fp, fp]
+        L.cmpc_set_reference.argtypes = [vp, fp, fp]
+        L.cmpc_set_contacts.argtypes = [vp, fp, fp, fp, fp, fp, fp]
+        L.cmpc_set_initial_guess.argtypes = [vp, fp, C.c_int]
+        L.cmpc_advance.argtypes = [vp]
+        L.cmpc_get_solution.argtypes = [vp, fp, fp]
+        L.cmpc_get_output.argtypes = [vp, fp, fp, fp, vp]
+        _lib = L
+    return _lib

@@ -1,0 +1,404 @@
+// C ABI of libcmpc_hip.so (include/cmpc.h): handle management, host<->device plumbing, launches.
+#include "../../include/cmpc.h"
+#include "cmpc_device.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+extern "C" size_t cmpc_solver_lds_bytes(int N);
+extern "C" int cmpc_launch_solver(const CmpcParams* prm, size_t lds_bytes, hipStream_t stream);
+extern "C" int cmpc_launch_nlp_eval(const CmpcParams* prm, const float* dX, const float* dP, const float* dLamG,
+                                    float lam_f, float* dF, float* dG, float* dGradF, float* dJac, float* dHess,
+                                    hipStream_t stream);
+extern "C" int cmpc_launch_warm_shift(const CmpcParams* prm, const float* dXprev, float* dX0, hipStream_t stream);
+
+struct cmpc_handle_s {
+    cmpc_config cfg;
+    CmpcLayout L;
+    int B = 0, device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timed = false;
+    float* dP = nullptr;
+    float* dX0 = nullptr;
+    float* dX = nullptr;
+    float* dInfo = nullptr;
+    std::vector<float> hP, hX0;  // host staging for the class-shaped setters
+    bool have_solution = false, x0_set = false;
+    size_t lds = 0;
+    std::string err;
+};
+
+static thread_local std::string g_err;
+
+static int fail(cmpc_handle h, int code, const std::string& msg)
+{
+    if (h) h->err = msg;
+    g_err = msg;
+    return code;
+}
+#define HIPCHK(h, call)                                                                       \
+    do {                                                                                      \
+        hipError_t e_ = (call);                                                               \
+        if (e_ != hipSuccess)                                                                 \
+            return fail(h, CMPC_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_));  \
+    } while (0)
+
+extern "C" {
+
+void cmpc_default_config(cmpc_config* c)
+{
+    // config/robots/ergoCubGazeboV1/centroidal_mpc.ini:3-42
+    std::memset(c, 0, sizeof(*c));
+    c->horizon = 20;
+    c->sampling_time = 0.06;
+    c->friction_coefficient = 0.33;
+    c->gravity = 9.80665;
+    c->com_weight[0] = 10; c->com_weight[1] = 10; c->com_weight[2] = 200;
+    c->angular_momentum_weight = 1e2;
+    c->contact_position_weight = 2e3;
+    c->force_rate_of_change_weight[0] = c->force_rate_of_change_weight[1] = c->force_rate_of_change_weight[2] = 10;
+    c->contact_force_symmetry_weight = 100;
+    const double cr[4][3] = {{0.08, 0.01, 0}, {0.08, -0.01, 0}, {-0.08, -0.01, 0}, {-0.08, 0.01, 0}};
+    for (int ct = 0; ct < 2; ++ct)
+        for (int j = 0; j < 4; ++j)
+            for (int i = 0; i < 3; ++i) c->corners[ct][j][i] = cr[j][i];
+    c->max_iterations = 40;
+    c->tolerance = 1e-6;
+    c->mu_init = 0.1;
+    c->mu_min = 1e-7;
+    c->exact_hessian = 1;
+    c->final_extrapolation = 0;
+}
+
+int cmpc_dims(int N, int* nx, int* np, int* ng, int* nnzj, int* nnzh)
+{
+    if (N < 1) return CMPC_ERR_ARG;
+    if (nx) *nx = 45 * N + 15;
+    if (np) *np = 50 * N + 27;
+    if (ng) *ng = 53 * N + 15;
+    if (nnzj) *nnzj = 243 * N + 15;
+    if (nnzh) *nnzh = 348 * N - 36;
+    return CMPC_OK;
+}
+
+const char* cmpc_last_error(cmpc_handle h) { return h ? h->err.c_str() : g_err.c_str(); }
+int cmpc_batch(cmpc_handle h) { return h ? h->B : 0; }
+void* cmpc_stream(cmpc_handle h) { return h ? (void*)h->stream : nullptr; }
+
+int cmpc_create(const cmpc_config* cfg, int batch, int device, cmpc_handle* out)
+{
+    if (!cfg || !out || batch < 1) return fail(nullptr, CMPC_ERR_ARG, "cmpc_create: null argument or batch < 1");
+    if (cfg->horizon < 2 || cfg->horizon > CMPC_NMAX)
+        return fail(nullptr, CMPC_ERR_ARG, "cmpc_create: horizon must be in [2, " + std::to_string(CMPC_NMAX) + "]");
+    if (!(cfg->sampling_time > 0) || !(cfg->friction_coefficient > 0))
+        return fail(nullptr, CMPC_ERR_ARG, "cmpc_create: sampling_time and friction_coefficient must be positive");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+        return fail(nullptr, CMPC_ERR_HIP, "cmpc_create: no HIP device (this library has no CPU path)");
+    if (device < 0 || device >= ndev) return fail(nullptr, CMPC_ERR_ARG, "cmpc_create: bad device index");
+    cmpc_handle h = new cmpc_handle_s();
+    h->cfg = *cfg;
+    if (h->cfg.max_iterations <= 0) h->cfg.max_iterations = 40;
+    if (!(h->cfg.tolerance > 0)) h->cfg.tolerance = 1e-6;
+    if (!(h->cfg.mu_init > 0)) h->cfg.mu_init = 0.1;
+    if (!(h->cfg.mu_min > 0)) h->cfg.mu_min = 1e-7;
+    if (!(h->cfg.gravity > 0)) h->cfg.gravity = 9.80665;
+    h->B = batch;
+    h->device = device;
+    cmpc_layout_init(h->L, cfg->horizon);
+    h->lds = cmpc_solver_lds_bytes(cfg->horizon);
+    if (h->lds > 160 * 1024) {
+        const int n = cfg->horizon;
+        delete h;
+        return fail(nullptr, CMPC_ERR_ARG, "cmpc_create: horizon " + std::to_string(n) + " needs more than 160 KiB of LDS per problem");
+    }
+    HIPCHK(h, hipSetDevice(device));
+    HIPCHK(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    HIPCHK(h, hipEventCreate(&h->ev0));
+    HIPCHK(h, hipEventCreate(&h->ev1));
+    HIPCHK(h, hipMalloc(&h->dInfo, sizeof(float) * CMPC_INFO_N * (size_t)batch));
+    *out = h;
+    return CMPC_OK;
+}
+
+int cmpc_destroy(cmpc_handle h)
+{
+    if (!h) return CMPC_OK;
+    hipSetDevice(h->device);
+    if (h->stream) hipStreamSynchronize(h->stream);
+    hipFree(h->dP); hipFree(h->dX0); hipFree(h->dX); hipFree(h->dInfo);
+    if (h->ev0) hipEventDestroy(h->ev0);
+    if (h->ev1) hipEventDestroy(h->ev1);
+    if (h->stream) hipStreamDestroy(h->stream);
+    delete h;
+    return CMPC_OK;
+}
+
+static void fill_params(cmpc_handle h, CmpcParams& p)
+{
+    const cmpc_config& c = h->cfg;
+    std::memset(&p, 0, sizeof(p));
+    p.N = c.horizon; p.B = h->B; p.max_iter = c.max_iterations;
+    p.exact_hessian = c.exact_hessian; p.final_extrap = c.final_extrapolation;
+    p.dt = (float)c.sampling_time; p.mu_fr = (float)c.friction_coefficient; p.grav = (float)c.gravity;
+    p.w_com0 = (float)c.com_weight[0]; p.w_com1 = (float)c.com_weight[1];
+    p.w_h = (float)c.angular_momentum_weight; p.w_pos = (float)c.contact_position_weight;
+    p.w_sym = (float)c.contact_force_symmetry_weight;
+    for (int i = 0; i < 3; ++i) p.D[i] = (float)(2.0 * c.force_rate_of_change_weight[i]);
+    for (int ct = 0; ct < 2; ++ct)
+        for (int j = 0; j < 4; ++j)
+            for (int i = 0; i < 3; ++i) p.corners[12 * ct + 3 * j + i] = (float)c.corners[ct][j][i];
+    for (int k = 0; k <= c.horizon; ++k) {
+        const double wz = 0.5 * c.com_weight[2] * (1.0 + std::exp(-(double)k));
+        p.wz2[k] = (float)(2.0 * wz * wz);
+    }
+    p.tol = (float)c.tolerance; p.mu_init = (float)c.mu_init; p.mu_min = (float)c.mu_min;
+}
+
+int cmpc_solve_device(cmpc_handle h, const float* dP, const float* dX0, float* dX, float* dInfo, void* stream)
+{
+    if (!h || !dP || !dX0 || !dX) return fail(h, CMPC_ERR_ARG, "cmpc_solve_device: null argument");
+    HIPCHK(h, hipSetDevice(h->device));
+    hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+    CmpcParams p;
+    fill_params(h, p);
+    p.P = dP; p.X0 = dX0; p.X = dX; p.info = dInfo ? dInfo : h->dInfo;
+    HIPCHK(h, hipEventRecord(h->ev0, st));
+    int rc = cmpc_launch_solver(&p, h->lds, st);
+    if (rc != 0) return fail(h, CMPC_ERR_HIP, std::string("solver launch: ") + hipGetErrorString((hipError_t)rc));
+    HIPCHK(h, hipEventRecord(h->ev1, st));
+    h->timed = true;
+    return CMPC_OK;
+}
+
+float cmpc_last_solve_ms(cmpc_handle h)
+{
+    if (!h || !h->timed) return -1.f;
+    float ms = -1.f;
+    if (hipEventSynchronize(h->ev1) != hipSuccess) return -1.f;
+    if (hipEventElapsedTime(&ms, h->ev0, h->ev1) != hipSuccess) return -1.f;
+    return ms;
+}
+
+static int ensure_buffers(cmpc_handle h)
+{
+    const size_t nP = (size_t)h->B * h->L.np, nX = (size_t)h->B * h->L.nx;
+    if (!h->dP) HIPCHK(h, hipMalloc(&h->dP, sizeof(float) * nP));
+    if (!h->dX0) HIPCHK(h, hipMalloc(&h->dX0, sizeof(float) * nX));
+    if (!h->dX) HIPCHK(h, hipMalloc(&h->dX, sizeof(float) * nX));
+    if (h->hP.empty()) h->hP.assign(nP, 0.f);
+    return CMPC_OK;
+}
+
+static int check_status(cmpc_handle h, const std::vector<float>& info)
+{
+    int bad = 0, first = -1;
+    for (int b = 0; b < h->B; ++b)
+        if (info[(size_t)b * CMPC_INFO_N + 5] != 0.f) { if (first < 0) first = b; ++bad; }
+    if (bad) {
+        char buf[160];
+        std::snprintf(buf, sizeof(buf), "%d of %d problems did not converge (first: %d, status %d, kkt %.3g)", bad, h->B, first,
+                      (int)info[(size_t)first * CMPC_INFO_N + 5], info[(size_t)first * CMPC_INFO_N + 1]);
+        return fail(h, CMPC_ERR_NOT_CONVERGED, buf);
+    }
+    return CMPC_OK;
+}
+
+int cmpc_solve(cmpc_handle h, const float* P, const float* X0, float* X, float* info)
+{
+    if (!h || !P || !X0 || !X) return fail(h, CMPC_ERR_ARG, "cmpc_solve: null argument");
+    HIPCHK(h, hipSetDevice(h->device));
+    int rc = ensure_buffers(h);
+    if (rc) return rc;
+    const size_t nP = (size_t)h->B * h->L.np, nX = (size_t)h->B * h->L.nx;
+    HIPCHK(h, hipMemcpyAsync(h->dP, P, sizeof(float) * nP, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->dX0, X0, sizeof(float) * nX, hipMemcpyHostToDevice, h->stream));
+    rc = cmpc_solve_device(h, h->dP, h->dX0, h->dX, h->dInfo, nullptr);
+    if (rc) return rc;
+    std::vector<float> hinfo((size_t)h->B * CMPC_INFO_N);
+    HIPCHK(h, hipMemcpyAsync(X, h->dX, sizeof(float) * nX, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(hinfo.data(), h->dInfo, sizeof(float) * hinfo.size(), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (info) std::memcpy(info, hinfo.data(), sizeof(float) * hinfo.size());
+    h->have_solution = true;
+    return check_status(h, hinfo);
+}
+
+// ---------------- class-shaped setters ----------------
+int cmpc_set_state(cmpc_handle h, const float* state, const float* wrench)
+{
+    if (!h || !state) return fail(h, CMPC_ERR_ARG, "cmpc_set_state: null argument");
+    int rc = ensure_buffers(h);
+    if (rc) return rc;
+    const int N = h->cfg.horizon;
+    for (int b = 0; b < h->B; ++b) {
+        float* p = h->hP.data() + (size_t)b * h->L.np;
+        std::memcpy(p + h->L.p_com0, state + 9 * (size_t)b, sizeof(float) * 9);
+        for (int k = 0; k < N; ++k)
+            for (int i = 0; i < 3; ++i) {
+                p[h->L.p_fext + 3 * k + i] = wrench ? wrench[((size_t)b * N + k) * 6 + i] : 0.f;
+                p[h->L.p_text + 3 * k + i] = wrench ? wrench[((size_t)b * N + k) * 6 + 3 + i] : 0.f;
+            }
+    }
+    return CMPC_OK;
+}
+
+int cmpc_set_reference(cmpc_handle h, const float* com_ref, const float* h_ref)
+{
+    if (!h || !com_ref || !h_ref) return fail(h, CMPC_ERR_ARG, "cmpc_set_reference: null argument");
+    int rc = ensure_buffers(h);
+    if (rc) return rc;
+    const size_t n = 3 * (size_t)(h->cfg.horizon + 1);
+    for (int b = 0; b < h->B; ++b) {
+        float* p = h->hP.data() + (size_t)b * h->L.np;
+        std::memcpy(p + h->L.p_comref, com_ref + n * b, sizeof(float) * n);
+        std::memcpy(p + h->L.p_href, h_ref + n * b, sizeof(float) * n);
+    }
+    return CMPC_OK;
+}
+
+int cmpc_set_contacts(cmpc_handle h, const float* R, const float* upper, const float* lower, const float* enabled,
+                      const float* nominal, const float* current)
+{
+    if (!h || !R || !upper || !lower || !enabled || !nominal || !current)
+        return fail(h, CMPC_ERR_ARG, "cmpc_set_contacts: null argument");
+    int rc = ensure_buffers(h);
+    if (rc) return rc;
+    const int N = h->cfg.horizon;
+    for (int b = 0; b < h->B; ++b) {
+        float* p = h->hP.data() + (size_t)b * h->L.np;
+        for (int ct = 0; ct < 2; ++ct) {
+            const size_t bc = (size_t)b * 2 + ct;
+            for (int k = 0; k < N; ++k) {
+                const float* Rk = R + (bc * N + k) * 9;  // row-major
+                for (int r = 0; r < 3; ++r)
+                    for (int cc = 0; cc < 3; ++cc) p[h->L.p_R[ct] + 9 * k + 3 * cc + r] = Rk[3 * r + cc];
+                const float e = enabled[bc * N + k];
+                if (e != 0.f && e != 1.f) return fail(h, CMPC_ERR_ARG, "cmpc_set_contacts: enabled must be 0 or 1");
+                p[h->L.p_gam[ct] + k] = e;
+                for (int i = 0; i < 3; ++i) {
+                    p[h->L.p_up[ct] + 3 * k + i] = upper[(bc * N + k) * 3 + i];
+                    p[h->L.p_lo[ct] + 3 * k + i] = lower[(bc * N + k) * 3 + i];
+                    if (p[h->L.p_up[ct] + 3 * k + i] < p[h->L.p_lo[ct] + 3 * k + i])
+                        return fail(h, CMPC_ERR_ARG, "cmpc_set_contacts: bounding box upper < lower");
+                }
+            }
+            std::memcpy(p + h->L.p_nom[ct], nominal + bc * 3 * (N + 1), sizeof(float) * 3 * (N + 1));
+            std::memcpy(p + h->L.p_cur[ct], current + bc * 3, sizeof(float) * 3);
+        }
+    }
+    return CMPC_OK;
+}
+
+static void cold_start(cmpc_handle h)
+{
+    const int N = h->cfg.horizon;
+    h->hX0.assign((size_t)h->B * h->L.nx, 0.f);
+    for (int b = 0; b < h->B; ++b) {
+        const float* p = h->hP.data() + (size_t)b * h->L.np;
+        float* x = h->hX0.data() + (size_t)b * h->L.nx;
+        for (int k = 0; k <= N; ++k)
+            for (int i = 0; i < 3; ++i) x[h->L.o_com + 3 * k + i] = p[h->L.p_com0 + i];
+        for (int ct = 0; ct < 2; ++ct) {
+            std::memcpy(x + h->L.o_pos[ct], p + h->L.p_nom[ct], sizeof(float) * 3 * (N + 1));
+            for (int j = 0; j < 4; ++j)
+                for (int k = 0; k < N; ++k) x[h->L.o_f[ct][j] + 3 * k + 2] = (float)(h->cfg.gravity / 8.0);
+        }
+    }
+}
+
+int cmpc_set_initial_guess(cmpc_handle h, const float* x0, int shift_previous)
+{
+    if (!h) return fail(h, CMPC_ERR_ARG, "cmpc_set_initial_guess: null handle");
+    int rc = ensure_buffers(h);
+    if (rc) return rc;
+    HIPCHK(h, hipSetDevice(h->device));
+    const size_t nX = (size_t)h->B * h->L.nx;
+    if (x0) {
+        HIPCHK(h, hipMemcpyAsync(h->dX0, x0, sizeof(float) * nX, hipMemcpyHostToDevice, h->stream));
+    } else if (shift_previous && h->have_solution) {
+        CmpcParams p;
+        fill_params(h, p);
+        int r = cmpc_launch_warm_shift(&p, h->dX, h->dX0, h->stream);
+        if (r != 0) return fail(h, CMPC_ERR_HIP, "warm-start shift launch failed");
+    } else {
+        cold_start(h);
+        HIPCHK(h, hipMemcpyAsync(h->dX0, h->hX0.data(), sizeof(float) * nX, hipMemcpyHostToDevice, h->stream));
+    }
+    h->x0_set = true;
+    return CMPC_OK;
+}
+
+int cmpc_advance(cmpc_handle h)
+{
+    if (!h) return fail(h, CMPC_ERR_ARG, "cmpc_advance: null handle");
+    int rc = ensure_buffers(h);
+    if (rc) return rc;
+    HIPCHK(h, hipSetDevice(h->device));
+    if (!h->x0_set) { rc = cmpc_set_initial_guess(h, nullptr, 0); if (rc) return rc; }
+    HIPCHK(h, hipMemcpyAsync(h->dP, h->hP.data(), sizeof(float) * h->hP.size(), hipMemcpyHostToDevice, h->stream));
+    rc = cmpc_solve_device(h, h->dP, h->dX0, h->dX, h->dInfo, nullptr);
+    if (rc) return rc;
+    std::vector<float> hinfo((size_t)h->B * CMPC_INFO_N);
+    HIPCHK(h, hipMemcpyAsync(hinfo.data(), h->dInfo, sizeof(float) * hinfo.size(), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->have_solution = true;
+    h->x0_set = false;  // the next tick picks its own start unless told otherwise
+    return check_status(h, hinfo);
+}
+
+int cmpc_get_solution(cmpc_handle h, float* X, float* info)
+{
+    if (!h || !h->have_solution) return fail(h, CMPC_ERR_ARG, "cmpc_get_solution: no solution yet");
+    HIPCHK(h, hipSetDevice(h->device));
+    if (X) HIPCHK(h, hipMemcpyAsync(X, h->dX, sizeof(float) * (size_t)h->B * h->L.nx, hipMemcpyDeviceToHost, h->stream));
+    if (info) HIPCHK(h, hipMemcpyAsync(info, h->dInfo, sizeof(float) * (size_t)h->B * CMPC_INFO_N, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return CMPC_OK;
+}
+
+int cmpc_get_output(cmpc_handle h, float* forces0, float* pos0, float* next_pos, int* next_knot)
+{
+    if (!h || !h->have_solution) return fail(h, CMPC_ERR_ARG, "cmpc_get_output: no solution yet");
+    std::vector<float> X((size_t)h->B * h->L.nx);
+    int rc = cmpc_get_solution(h, X.data(), nullptr);
+    if (rc) return rc;
+    const int N = h->cfg.horizon;
+    for (int b = 0; b < h->B; ++b) {
+        const float* x = X.data() + (size_t)b * h->L.nx;
+        const float* p = h->hP.data() + (size_t)b * h->L.np;
+        for (int ct = 0; ct < 2; ++ct) {
+            for (int j = 0; j < 4; ++j)
+                for (int i = 0; i < 3; ++i)
+                    if (forces0) forces0[(((size_t)b * 2 + ct) * 4 + j) * 3 + i] = x[h->L.o_f[ct][j] + i];
+            int land = -1;  // first knot after a swing stage whose successor is in contact (or the horizon end)
+            for (int k = 0; k < N; ++k)
+                if (p[h->L.p_gam[ct] + k] < 0.5f && (k + 1 == N || p[h->L.p_gam[ct] + k + 1] > 0.5f)) { land = k + 1; break; }
+            for (int i = 0; i < 3; ++i) {
+                if (pos0) pos0[((size_t)b * 2 + ct) * 3 + i] = x[h->L.o_pos[ct] + i];
+                if (next_pos) next_pos[((size_t)b * 2 + ct) * 3 + i] = land >= 0 ? x[h->L.o_pos[ct] + 3 * land + i] : x[h->L.o_pos[ct] + i];
+            }
+            if (next_knot) next_knot[(size_t)b * 2 + ct] = land;
+        }
+    }
+    return CMPC_OK;
+}
+
+int cmpc_eval_nlp_device(cmpc_handle h, const float* dX, const float* dP, const float* dLamG, float lam_f, float* dF,
+                         float* dG, float* dGradF, float* dJac, float* dHess, void* stream)
+{
+    if (!h || !dX || !dP) return fail(h, CMPC_ERR_ARG, "cmpc_eval_nlp_device: null argument");
+    if (dHess && !dLamG) return fail(h, CMPC_ERR_ARG, "cmpc_eval_nlp_device: the Hessian needs lam_g");
+    HIPCHK(h, hipSetDevice(h->device));
+    CmpcParams p;
+    fill_params(h, p);
+    int rc = cmpc_launch_nlp_eval(&p, dX, dP, dLamG, lam_f, dF, dG, dGradF, dJac, dHess, stream ? (hipStream_t)stream : h->stream);
+    if (rc != 0) return fail(h, CMPC_ERR_HIP, std::string("nlp eval launch: ") + hipGetErrorString((hipError_t)rc));
+    return CMPC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,65 @@
+// Shared host/device definitions of the centroidal-MPC kernels (gfx950).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#define CMPC_NS 15   // stage state: com, dcom, h, posL, posR
+#define CMPC_NF 24   // corner forces (contact c, corner j, axis i -> 12c+3j+i)
+#define CMPC_NQ 6    // foot-frame landing offsets (3c+i)
+#define CMPC_NU 30
+#define CMPC_NXA 39  // NS + NF: the previous force rides along as state (force-rate cost)
+#define CMPC_NI 44   // inequality rows per stage: 32 friction + 6 q upper + 6 q lower
+#define CMPC_LP 465  // packed lower triangle of a 30x30
+#define CMPC_NMAX 40 // largest horizon the kernels are built for
+#define CMPC_INFO_N 8
+
+// x / p index layout of the reference's generated NLP (tmp.c:62-67)
+struct CmpcLayout {
+    int N;
+    int p_R[2], p_up[2], p_lo[2], p_gam[2], p_nom[2], p_cur[2];
+    int p_com0, p_dcom0, p_h0, p_comref, p_href, p_fext, p_text, np;
+    int o_com, o_dcom, o_h, o_pos[2], o_vel[2], o_f[2][4], nx, ng;
+};
+
+__host__ __device__ inline void cmpc_layout_init(CmpcLayout& L, int N)
+{
+    int o = 0;
+    L.N = N;
+    for (int c = 0; c < 2; ++c) {
+        L.p_R[c] = o; o += 9 * N;
+        L.p_up[c] = o; o += 3 * N;
+        L.p_lo[c] = o; o += 3 * N;
+        L.p_gam[c] = o; o += N;
+        L.p_nom[c] = o; o += 3 * (N + 1);
+        L.p_cur[c] = o; o += 3;
+    }
+    L.p_com0 = o; o += 3; L.p_dcom0 = o; o += 3; L.p_h0 = o; o += 3;
+    L.p_comref = o; o += 3 * (N + 1); L.p_href = o; o += 3 * (N + 1);
+    L.p_fext = o; o += 3 * N; L.p_text = o; o += 3 * N;
+    L.np = o;
+    o = 0;
+    L.o_com = o; o += 3 * (N + 1); L.o_dcom = o; o += 3 * (N + 1); L.o_h = o; o += 3 * (N + 1);
+    for (int c = 0; c < 2; ++c) {
+        L.o_pos[c] = o; o += 3 * (N + 1);
+        L.o_vel[c] = o; o += 3 * N;
+        for (int j = 0; j < 4; ++j) { L.o_f[c][j] = o; o += 3 * N; }
+    }
+    L.nx = o;
+    L.ng = 53 * N + 15;
+}
+
+// kernel parameters (passed by value)
+struct CmpcParams {
+    int N, B, max_iter, exact_hessian, final_extrap;
+    float dt, mu_fr, grav;
+    float w_com0, w_com1, w_h, w_pos, w_sym;
+    float D[3];                  // 2 * force_rate_of_change_weight
+    float corners[24];           // [c][j][3]
+    float wz2[CMPC_NMAX + 1];    // 2 w_z(k)^2, w_z(k) = (w_cz/2)(1+exp(-k))
+    float tol, mu_init, mu_min;
+    const float* P;              // [B][np]
+    const float* X0;             // [B][nx]
+    float* X;                    // [B][nx]
+    float* info;                 // [B][CMPC_INFO_N] or null
+    float* scratch;              // per-problem factor storage when it does not fit in LDS
+    long long scratch_stride;    // floats per problem
+};

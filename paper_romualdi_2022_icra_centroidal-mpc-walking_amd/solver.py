@@ -1,0 +1,247 @@
+"""Host-side mirror of the reference's CentroidalMPC surface for a batch of problems.
+
+Reference interface (BipedalLocomotion::ReducedModelControllers::CentroidalMPC, used at
+src/centroidal-mpc-walking/src/CentroidalMPCBlock.cpp:144,407,579,609,615,622):
+    initialize / setState / setReferenceTrajectory / setContactPhaseList / advance / getOutput
+Every mutator returns bool like the reference's (False => the caller logs and aborts the tick,
+CentroidalMPCBlock.cpp:609-619); `last_error` holds the text.  All compute happens in
+libcmpc_hip.so (hand-written gfx950 kernels) through the C ABI of include/cmpc.h.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+
+from . import _capi
+from .config import GRAVITY, CentroidalMPCConfig, from_ini
+from .contacts import PlannedContact, sample_schedule
+from .layout import Layout
+
+
+def _c_config(cfg: CentroidalMPCConfig, tolerance=None, mu_min=None, max_iterations=None,
+              exact_hessian=True, final_extrapolation=False) -> _capi.CmpcConfig:
+    c = _capi.CmpcConfig()
+    c.horizon = cfg.N
+    c.sampling_time = cfg.sampling_time
+    c.friction_coefficient = cfg.static_friction_coefficient
+    c.gravity = GRAVITY
+    c.com_weight[:] = cfg.com_weight
+    c.angular_momentum_weight = cfg.angular_momentum_weight
+    c.contact_position_weight = cfg.contact_position_weight
+    c.force_rate_of_change_weight[:] = cfg.force_rate_of_change_weight
+    c.contact_force_symmetry_weight = cfg.contact_force_symmetry_weight
+    c.corners[:] = np.asarray([cc.corners for cc in cfg.contacts], np.float64).reshape(-1)
+    c.max_iterations = max_iterations or cfg.ipopt_max_iteration
+    # the reference's ipopt_tolerance (1e-4 / 1e-2) is looser than the parity target; the GPU
+    # solver always converges at least to 1e-6 so that its answer is reproducible to 1e-4
+    c.tolerance = tolerance if tolerance is not None else min(cfg.ipopt_tolerance, 1e-6)
+    c.mu_init = 0.1
+    c.mu_min = mu_min if mu_min is not None else c.tolerance / 10.0
+    c.exact_hessian = int(exact_hessian)
+    c.final_extrapolation = int(final_extrapolation)
+    return c
+
+
+class BatchSolver:
+    """Thin RAII wrapper of a cmpc_handle: device-resident batched solve."""
+
+    def __init__(self, cfg: CentroidalMPCConfig, batch: int, device: int = 0, **opts):
+        self.cfg = cfg
+        self.layout = Layout(cfg.N)
+        self.batch = batch
+        self._lib = _capi.lib()
+        self._ccfg = _c_config(cfg, **opts)
+        h = C.c_void_p()
+        rc = self._lib.cmpc_create(C.byref(self._ccfg), batch, device, C.byref(h))
+        if rc != 0:
+            raise RuntimeError(f"cmpc_create failed ({rc}): {self._lib.cmpc_last_error(None).decode()}")
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.cmpc_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    @property
+    def last_error(self) -> str:
+        return self._lib.cmpc_last_error(self._h).decode()
+
+    def solve_device(self, dP, dX0, dX=None, dInfo=None, stream=None):
+        """torch CUDA tensors float32: P[B,np], X0[B,nx] -> X[B,nx], info[B,8].  Launches on
+        torch's current stream unless `stream` (a raw hipStream_t) is given; asynchronous."""
+        import torch
+        L = self.layout
+        assert dP.is_cuda and dP.dtype == torch.float32 and dP.is_contiguous() and tuple(dP.shape) == (self.batch, L.np)
+        assert dX0.is_cuda and dX0.dtype == torch.float32 and dX0.is_contiguous() and tuple(dX0.shape) == (self.batch, L.nx)
+        if dX is None:
+            dX = torch.empty_like(dX0)
+        if dInfo is None:
+            dInfo = torch.empty((self.batch, _capi.INFO), dtype=torch.float32, device=dP.device)
+        if stream is None:
+            stream = torch.cuda.current_stream(dP.device).cuda_stream
+        rc = self._lib.cmpc_solve_device(self._h, dP.data_ptr(), dX0.data_ptr(), dX.data_ptr(), dInfo.data_ptr(), stream)
+        if rc != 0:
+            raise RuntimeError(f"cmpc_solve_device failed ({rc}): {self.last_error}")
+        return dX, dInfo
+
+    def solve_host(self, P: np.ndarray, X0: np.ndarray):
+        """numpy float32 in/out through the PCIe-inclusive entry point.  Returns (X, info, rc)."""
+        L = self.layout
+        P = np.ascontiguousarray(P, np.float32)
+        X0 = np.ascontiguousarray(X0, np.float32)
+        assert P.shape == (self.batch, L.np) and X0.shape == (self.batch, L.nx)
+        X = np.empty_like(X0)
+        info = np.empty((self.batch, _capi.INFO), np.float32)
+        rc = self._lib.cmpc_solve(self._h, P.ctypes.data, X0.ctypes.data, X.ctypes.data, info.ctypes.data)
+        if rc not in (0, -3):
+            raise RuntimeError(f"cmpc_solve failed ({rc}): {self.last_error}")
+        return X, info, rc
+
+    def last_solve_ms(self) -> float:
+        return float(self._lib.cmpc_last_solve_ms(self._h))
+
+
+class CentroidalMPCOutput:
+    """What getOutput() exposes downstream (WholeBodyQPBlock.cpp:824-829, 1319-1335): per contact
+    the first-knot corner forces (world frame, mass-normalised) and pose, plus the step-adjusted
+    next landing position (CentroidalMPCBlock.cpp:598, 626)."""
+
+    def __init__(self, names, forces0, pos0, next_pos, next_knot):
+        self.contact_names = names
+        self.forces = forces0        # [B,2,4,3]
+        self.positions = pos0        # [B,2,3]
+        self.next_positions = next_pos  # [B,2,3]
+        self.next_knots = next_knot  # [B,2]
+
+
+class CentroidalMPC:
+    """Batch counterpart of BipedalLocomotion::ReducedModelControllers::CentroidalMPC."""
+
+    def __init__(self, batch: int = 1, device: int = 0):
+        self._batch = batch
+        self._device = device
+        self._solver: Optional[BatchSolver] = None
+        self._out: Optional[CentroidalMPCOutput] = None
+        self.last_error = ""
+        self._valid = False
+
+    # -- initialize(handler): handler = CentroidalMPCConfig, ini text, or dict of options
+    def initialize(self, handler, **solver_opts) -> bool:
+        try:
+            cfg = from_ini(handler) if isinstance(handler, str) else handler
+            if not isinstance(cfg, CentroidalMPCConfig):
+                raise TypeError("initialize() needs a CentroidalMPCConfig or the text of a centroidal_mpc.ini")
+            self.cfg = cfg
+            self._solver = BatchSolver(cfg, self._batch, self._device, **solver_opts)
+            self._lib = self._solver._lib
+            self._h = self._solver._h
+            return True
+        except Exception as e:  # mirrors the reference: log + return false
+            self.last_error = str(e)
+            return False
+
+    def _ok(self, rc) -> bool:
+        if rc != 0:
+            self.last_error = self._solver.last_error
+            return False
+        return True
+
+    def _need_init(self) -> bool:
+        if self._solver is None:
+            self.last_error = "initialize() has not been called"
+            return False
+        return True
+
+    def set_state(self, com, dcom, angular_momentum, external_wrench=None) -> bool:
+        """com, dcom, angular_momentum: [B,3]; external_wrench [B,6] (applied at every knot) or
+        [B,N,6] or None.  h and the wrench are mass-normalised (CentroidalMPCBlock.cpp:403-410)."""
+        if not self._need_init():
+            return False
+        B, N = self._batch, self.cfg.N
+        st = np.concatenate([np.reshape(com, (B, 3)), np.reshape(dcom, (B, 3)), np.reshape(angular_momentum, (B, 3))], 1)
+        st = np.ascontiguousarray(st, np.float32)
+        w = None
+        if external_wrench is not None:
+            w = np.asarray(external_wrench, np.float32)
+            if w.ndim == 2:
+                w = np.broadcast_to(w[:, None, :], (B, N, 6))
+            w = np.ascontiguousarray(w.reshape(B, N, 6))
+        return self._ok(self._lib.cmpc_set_state(self._h, st.ctypes.data, w.ctypes.data if w is not None else None))
+
+    def set_reference_trajectory(self, com, angular_momentum) -> bool:
+        """com, angular_momentum: [B,N+1,3] (the reference passes N+1 knots, CentroidalMPCBlock.cpp:230-235)."""
+        if not self._need_init():
+            return False
+        B, N = self._batch, self.cfg.N
+        c = np.ascontiguousarray(np.reshape(com, (B, N + 1, 3)), np.float32)
+        h = np.ascontiguousarray(np.reshape(angular_momentum, (B, N + 1, 3)), np.float32)
+        return self._ok(self._lib.cmpc_set_reference(self._h, c.ctypes.data, h.ctypes.data))
+
+    def set_contact_phase_list(self, lists, t0: float = 0.0) -> bool:
+        """lists: one dict {contact_name: [PlannedContact,...]} for every problem of the batch (or a
+        single dict shared by all), sampled by contacts.sample_schedule; or a dict of ready
+        tensors with keys R, upper, lower, enabled, nominal, current."""
+        if not self._need_init():
+            return False
+        B = self._batch
+        try:
+            if isinstance(lists, dict) and "R" in lists:
+                t = lists
+            else:
+                if isinstance(lists, dict):
+                    one = sample_schedule(self.cfg, lists, t0)
+                    t = {k: np.broadcast_to(v, (B,) + v.shape) for k, v in one.items()}
+                else:
+                    parts = [sample_schedule(self.cfg, l, t0) for l in lists]
+                    t = {k: np.stack([p[k] for p in parts]) for k in parts[0]}
+            self._sched = t
+            a = {k: np.ascontiguousarray(t[k], np.float32) for k in ("R", "upper", "lower", "enabled", "nominal", "current")}
+        except Exception as e:
+            self.last_error = str(e)
+            return False
+        return self._ok(self._lib.cmpc_set_contacts(self._h, a["R"].ctypes.data, a["upper"].ctypes.data, a["lower"].ctypes.data,
+                                                    a["enabled"].ctypes.data, a["nominal"].ctypes.data, a["current"].ctypes.data))
+
+    def set_initial_guess(self, x0=None, shift_previous=False) -> bool:
+        if not self._need_init():
+            return False
+        if x0 is not None:
+            x0 = np.ascontiguousarray(x0, np.float32)
+        return self._ok(self._lib.cmpc_set_initial_guess(self._h, x0.ctypes.data if x0 is not None else None, int(shift_previous)))
+
+    def advance(self) -> bool:
+        if not self._need_init():
+            return False
+        self._valid = False
+        rc = self._lib.cmpc_advance(self._h)
+        if rc != 0:
+            self.last_error = self._solver.last_error
+            return False
+        B = self._batch
+        f0 = np.empty((B, 2, 4, 3), np.float32)
+        p0 = np.empty((B, 2, 3), np.float32)
+        pn = np.empty((B, 2, 3), np.float32)
+        kn = np.empty((B, 2), np.int32)
+        if not self._ok(self._lib.cmpc_get_output(self._h, f0.ctypes.data, p0.ctypes.data, pn.ctypes.data, kn.ctypes.data)):
+            return False
+        self._out = CentroidalMPCOutput([c.contact_name for c in self.cfg.contacts], f0, p0, pn, kn)
+        self._valid = True
+        return True
+
+    def get_output(self) -> CentroidalMPCOutput:
+        return self._out
+
+    def is_output_valid(self) -> bool:
+        return self._valid
+
+    def get_solution(self):
+        L = Layout(self.cfg.N)
+        X = np.empty((self._batch, L.nx), np.float32)
+        info = np.empty((self._batch, _capi.INFO), np.float32)
+        if not self._ok(self._lib.cmpc_get_solution(self._h, X.ctypes.data, info.ctypes.data)):
+            return None, None
+        return X, info

@@ -1,0 +1,21 @@
+"""Diagnostic (GPU box): per-phase shader-clock shares of the solver kernel, from the
+-DCMPC_PROFILE build (libcmpc_hip_prof.so).  Shares only; never quote its run time."""
+import ctypes as C, os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: F401  (same HIP runtime)
+import cmpc_amd as cm
+cm._capi.LIB_PATH = os.path.join(os.path.dirname(cm._capi.LIB_PATH), "libcmpc_hip_prof.so")
+names = ["geo+AB", "PB/PA/PpB/PpA+Pd", "Quu", "panel", "rhs", "Qss", "chol", "Wsolve", "store", "Pupdate",
+         "residuals", "backward(total)", "fwd1", "steps+muaff", "delta", "fwd2", "steplen+costate", "update+conv"]
+cfg, P, X0 = cm.synthetic.config2_perturbed_com(256)
+s = cm.BatchSolver(cfg, 256)
+X, info, rc = s.solve_host(P, X0)
+out = (C.c_longlong * 32)()
+cm._capi.lib().cmpc_profile_read(out, 1)
+v = np.array(out[:18], float)
+tot = v[10:].sum()
+print("iters block0", info[0, 0], "total cycles (sum of phases) %.3g" % tot, "kernel cycles %.3g" % info[0, 6])
+for n, x in zip(names, v):
+    print("%-22s %12.0f  %5.1f%%  per stage-iter %8.0f" % (n, x, 100 * x / tot, x / (info[0, 0] * cfg.N)))
