@@ -56,7 +56,8 @@ typedef struct {
     double corners[2][4][3];  /* [CONTACT_i] corner_j, contacts in alphabetical name order        */
     /* solver options (ipopt_tolerance / ipopt_max_iteration take the place of IPOPT's) */
     int max_iterations;       /* Newton iteration budget per solve (default 40)                   */
-    double tolerance;         /* on primal residuals, complementarity and 0.1 x Newton step (default 1e-6) */
+    double tolerance;         /* on the primal residuals and on max t*z (default 1e-6)                 */
+    double step_tolerance;    /* on the last Newton step, max-norm over states and forces (default 1e-4) */
     double mu_init;           /* initial barrier parameter (default 0.1)                          */
     double mu_min;            /* final barrier parameter (default 1e-7)                           */
     int exact_hessian;        /* 1 (default): Lagrangian Hessian; 0: Gauss-Newton                 */

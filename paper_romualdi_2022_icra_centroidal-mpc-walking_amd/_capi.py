@@ -25,6 +25,7 @@ class CmpcConfig(C.Structure):
         ("corners", C.c_double * 24),
         ("max_iterations", C.c_int),
         ("tolerance", C.c_double),
+        ("step_tolerance", C.c_double),
         ("mu_init", C.c_double),
         ("mu_min", C.c_double),
         ("exact_hessian", C.c_int),

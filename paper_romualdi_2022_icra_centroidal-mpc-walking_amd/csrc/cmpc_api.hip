@@ -2,13 +2,14 @@
 #include "../../include/cmpc.h"
 #include "cmpc_device.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <string>
 #include <vector>
 
-extern "C" size_t cmpc_solver_lds_bytes(int N);
+extern "C" size_t cmpc_solver_lds_bytes(int N, int factors_global);
 extern "C" int cmpc_launch_solver(const CmpcParams* prm, size_t lds_bytes, hipStream_t stream);
 extern "C" int cmpc_launch_nlp_eval(const CmpcParams* prm, const float* dX, const float* dP, const float* dLamG,
                                     float lam_f, float* dF, float* dG, float* dGradF, float* dJac, float* dHess,
@@ -26,6 +27,9 @@ struct cmpc_handle_s {
     float* dX0 = nullptr;
     float* dX = nullptr;
     float* dInfo = nullptr;
+    CmpcConsts* dConsts = nullptr;
+    float* dScratch = nullptr;   // factor storage when the horizon's LDS image exceeds 160 KiB
+    long long scratch_stride = 0;
     std::vector<float> hP, hX0;  // host staging for the class-shaped setters
     bool have_solution = false, x0_set = false;
     size_t lds = 0;
@@ -46,6 +50,8 @@ static int fail(cmpc_handle h, int code, const std::string& msg)
         if (e_ != hipSuccess)                                                                 \
             return fail(h, CMPC_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_));  \
     } while (0)
+
+static void fill_consts(cmpc_handle h, CmpcConsts& q);
 
 extern "C" {
 
@@ -68,6 +74,7 @@ void cmpc_default_config(cmpc_config* c)
             for (int i = 0; i < 3; ++i) c->corners[ct][j][i] = cr[j][i];
     c->max_iterations = 40;
     c->tolerance = 1e-6;
+    c->step_tolerance = 1e-4;
     c->mu_init = 0.1;
     c->mu_min = 1e-7;
     c->exact_hessian = 1;
@@ -104,23 +111,36 @@ int cmpc_create(const cmpc_config* cfg, int batch, int device, cmpc_handle* out)
     h->cfg = *cfg;
     if (h->cfg.max_iterations <= 0) h->cfg.max_iterations = 40;
     if (!(h->cfg.tolerance > 0)) h->cfg.tolerance = 1e-6;
+    if (!(h->cfg.step_tolerance > 0)) h->cfg.step_tolerance = 100.0 * h->cfg.tolerance;
     if (!(h->cfg.mu_init > 0)) h->cfg.mu_init = 0.1;
     if (!(h->cfg.mu_min > 0)) h->cfg.mu_min = 1e-7;
     if (!(h->cfg.gravity > 0)) h->cfg.gravity = 9.80665;
     h->B = batch;
     h->device = device;
     cmpc_layout_init(h->L, cfg->horizon);
-    h->lds = cmpc_solver_lds_bytes(cfg->horizon);
+    h->lds = cmpc_solver_lds_bytes(cfg->horizon, 0);
+    const bool fg = h->lds > 160 * 1024;
+    if (fg) {
+        h->lds = cmpc_solver_lds_bytes(cfg->horizon, 1);
+        h->scratch_stride = (long long)(CMPC_LP + CMPC_NU * CMPC_NS) * cfg->horizon;
+    }
     if (h->lds > 160 * 1024) {
         const int n = cfg->horizon;
         delete h;
         return fail(nullptr, CMPC_ERR_ARG, "cmpc_create: horizon " + std::to_string(n) + " needs more than 160 KiB of LDS per problem");
     }
     HIPCHK(h, hipSetDevice(device));
+    if (fg) HIPCHK(h, hipMalloc(&h->dScratch, sizeof(float) * (size_t)h->scratch_stride * (size_t)batch));
     HIPCHK(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     HIPCHK(h, hipEventCreate(&h->ev0));
     HIPCHK(h, hipEventCreate(&h->ev1));
     HIPCHK(h, hipMalloc(&h->dInfo, sizeof(float) * CMPC_INFO_N * (size_t)batch));
+    HIPCHK(h, hipMalloc(&h->dConsts, sizeof(CmpcConsts)));
+    {
+        CmpcConsts q;
+        fill_consts(h, q);
+        HIPCHK(h, hipMemcpy(h->dConsts, &q, sizeof(q), hipMemcpyHostToDevice));
+    }
     *out = h;
     return CMPC_OK;
 }
@@ -130,7 +150,7 @@ int cmpc_destroy(cmpc_handle h)
     if (!h) return CMPC_OK;
     hipSetDevice(h->device);
     if (h->stream) hipStreamSynchronize(h->stream);
-    hipFree(h->dP); hipFree(h->dX0); hipFree(h->dX); hipFree(h->dInfo);
+    hipFree(h->dP); hipFree(h->dX0); hipFree(h->dX); hipFree(h->dInfo); hipFree(h->dConsts); hipFree(h->dScratch);
     if (h->ev0) hipEventDestroy(h->ev0);
     if (h->ev1) hipEventDestroy(h->ev1);
     if (h->stream) hipStreamDestroy(h->stream);
@@ -138,25 +158,39 @@ int cmpc_destroy(cmpc_handle h)
     return CMPC_OK;
 }
 
-static void fill_params(cmpc_handle h, CmpcParams& p)
+static void fill_consts(cmpc_handle h, CmpcConsts& q)
 {
     const cmpc_config& c = h->cfg;
-    std::memset(&p, 0, sizeof(p));
-    p.N = c.horizon; p.B = h->B; p.max_iter = c.max_iterations;
-    p.exact_hessian = c.exact_hessian; p.final_extrap = c.final_extrapolation;
-    p.dt = (float)c.sampling_time; p.mu_fr = (float)c.friction_coefficient; p.grav = (float)c.gravity;
-    p.w_com0 = (float)c.com_weight[0]; p.w_com1 = (float)c.com_weight[1];
-    p.w_h = (float)c.angular_momentum_weight; p.w_pos = (float)c.contact_position_weight;
-    p.w_sym = (float)c.contact_force_symmetry_weight;
-    for (int i = 0; i < 3; ++i) p.D[i] = (float)(2.0 * c.force_rate_of_change_weight[i]);
+    std::memset(&q, 0, sizeof(q));
+    q.N = c.horizon; q.max_iter = c.max_iterations;
+    q.exact_hessian = c.exact_hessian; q.final_extrap = c.final_extrapolation;
+    q.dt = (float)c.sampling_time; q.mu_fr = (float)c.friction_coefficient; q.grav = (float)c.gravity;
+    q.w_com0 = (float)c.com_weight[0]; q.w_com1 = (float)c.com_weight[1];
+    q.w_h = (float)c.angular_momentum_weight; q.w_pos = (float)c.contact_position_weight;
+    q.w_sym = (float)c.contact_force_symmetry_weight;
+    for (int i = 0; i < 3; ++i) q.D[i] = (float)(2.0 * c.force_rate_of_change_weight[i]);
     for (int ct = 0; ct < 2; ++ct)
         for (int j = 0; j < 4; ++j)
-            for (int i = 0; i < 3; ++i) p.corners[12 * ct + 3 * j + i] = (float)c.corners[ct][j][i];
+            for (int i = 0; i < 3; ++i) q.corners[12 * ct + 3 * j + i] = (float)c.corners[ct][j][i];
     for (int k = 0; k <= c.horizon; ++k) {
         const double wz = 0.5 * c.com_weight[2] * (1.0 + std::exp(-(double)k));
-        p.wz2[k] = (float)(2.0 * wz * wz);
+        q.wz2[k] = (float)(2.0 * wz * wz);
     }
-    p.tol = (float)c.tolerance; p.mu_init = (float)c.mu_init; p.mu_min = (float)c.mu_min;
+    q.tol = (float)c.tolerance; q.step_tol = (float)c.step_tolerance; q.mu_init = (float)c.mu_init; q.mu_min = (float)c.mu_min;
+    // Levenberg shift: 0.5 % of the smallest cost curvature (2 w_rate).  It does not move the fixed
+    // point (the right-hand side is exact) but damps the directions the cost does not see
+    {
+        double dmin = 2.0 * c.force_rate_of_change_weight[0];
+        for (int i = 1; i < 3; ++i) dmin = std::min(dmin, 2.0 * c.force_rate_of_change_weight[i]);
+        q.reg = (float)std::max(1e-4, 5e-3 * dmin);
+    }
+}
+
+static void fill_params(cmpc_handle h, CmpcParams& p)
+{
+    std::memset(&p, 0, sizeof(p));
+    p.kc = h->dConsts; p.N = h->cfg.horizon; p.B = h->B;
+    p.scratch = h->dScratch; p.scratch_stride = h->scratch_stride;
 }
 
 int cmpc_solve_device(cmpc_handle h, const float* dP, const float* dX0, float* dX, float* dInfo, void* stream)

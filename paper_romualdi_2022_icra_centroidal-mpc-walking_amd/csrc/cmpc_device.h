@@ -47,19 +47,27 @@ __host__ __device__ inline void cmpc_layout_init(CmpcLayout& L, int N)
     L.ng = 53 * N + 15;
 }
 
-// kernel parameters (passed by value)
-struct CmpcParams {
-    int N, B, max_iter, exact_hessian, final_extrap;
+// problem-independent constants; the kernels copy them to LDS once (kernel arguments live in
+// SGPRs, and ~100 of them would be spilled and re-read all through the sweeps)
+struct CmpcConsts {
+    int N, max_iter, exact_hessian, final_extrap;
     float dt, mu_fr, grav;
     float w_com0, w_com1, w_h, w_pos, w_sym;
     float D[3];                  // 2 * force_rate_of_change_weight
+    float tol, step_tol, mu_init, mu_min;
+    float reg;                   // Levenberg shift on the diagonal of every stage Hessian Quu
     float corners[24];           // [c][j][3]
     float wz2[CMPC_NMAX + 1];    // 2 w_z(k)^2, w_z(k) = (w_cz/2)(1+exp(-k))
-    float tol, mu_init, mu_min;
+};
+
+// kernel parameters (passed by value)
+struct CmpcParams {
+    const CmpcConsts* kc;        // device memory
+    int N, B;
     const float* P;              // [B][np]
     const float* X0;             // [B][nx]
     float* X;                    // [B][nx]
     float* info;                 // [B][CMPC_INFO_N] or null
-    float* scratch;              // per-problem factor storage when it does not fit in LDS
+    float* scratch;              // per-problem factor storage when it does not fit in LDS, else null
     long long scratch_stride;    // floats per problem
 };

@@ -1,0 +1,454 @@
+// Batched evaluation of the reference NLP's callbacks on gfx950: f, g, grad f, jac g, hess L.
+//
+// These are the five functions IPOPT calls through the reference's CasADi-generated code
+// (src/centroidal-mpc-walking/config/robots/ergoCubGazeboV1/tmp.c: nlp_fg :12430, nlp_grad
+// :24791, nlp_hess_l :58926, nlp_jac_fg :71962), for a batch and for any horizon N.  Jacobian and
+// Hessian non-zeros come out in the reference's CCS order (casadi_s5 / casadi_s4, tmp.c:66-67):
+// cmpc_nlp_sparsity() builds that order (sort by column, then row) from the structural pattern.
+//
+// One workgroup per problem: x, p and lam_g are staged in LDS (12 KB at N=20), every output
+// element is one thread's closed-form expression, output rows are written coalesced.  The path is
+// HBM-write bound (~45 KB out per problem when the Hessian is requested).
+#include "cmpc_device.h"
+
+#include <algorithm>
+#include <vector>
+
+namespace {
+
+// ---- non-zero descriptors: kind | k<<4 | c<<10 | j<<11 | a<<13 | b<<15 | face<<17 ----
+enum : int {
+    J_ONE = 0, J_MONE, J_MDT, J_DCOM_F, J_H_F, J_H_POS, J_H_COM, J_POS_VEL, J_BBOX, J_FRIC,
+    H_COMX = 0, H_COMY, H_COMZ, H_H, H_POS, H_FF, H_RATE, H_F_POS, H_F_COM
+};
+__host__ __device__ inline int mk(int kind, int k, int c = 0, int j = 0, int a = 0, int b = 0, int face = 0)
+{
+    return kind | (k << 4) | (c << 10) | (j << 11) | (a << 13) | (b << 15) | (face << 17);
+}
+
+struct GLay {  // g-row offsets (SURVEY 8a-NLP 'Constraints')
+    int g_init, g_com, g_dcom, g_h, g_pos[2], g_bbox[2], g_fric[2];
+};
+__host__ __device__ inline void glay_init(GLay& G, int N)
+{
+    int o = 0;
+    G.g_init = o; o += 15;
+    G.g_com = o; o += 3 * N; G.g_dcom = o; o += 3 * N; G.g_h = o; o += 3 * N;
+    G.g_pos[0] = o; o += 3 * N; G.g_pos[1] = o; o += 3 * N;
+    for (int c = 0; c < 2; ++c) { G.g_bbox[c] = o; o += 3 * N; G.g_fric[c] = o; o += 16 * N; }
+}
+
+struct Trip { int row, col, desc; };
+
+// skew-matrix entry [v]x(a,b), a != b
+__device__ inline float skew(const float* v, int a, int b)
+{
+    const int o = 3 - a - b;
+    return ((b - a + 3) % 3 == 1) ? -v[o] : v[o];
+}
+
+__global__ __launch_bounds__(256) void cmpc_nlp_eval_kernel(CmpcParams kp, const float* __restrict__ X, const float* __restrict__ P,
+                                                            const float* __restrict__ LamG, float lam_f, float* __restrict__ F,
+                                                            float* __restrict__ Gout, float* __restrict__ GradF, float* __restrict__ Jac,
+                                                            float* __restrict__ Hess, const int* __restrict__ jdesc,
+                                                            const int* __restrict__ hdesc, int nnzj, int nnzh)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, NT = 256;
+    const int b = blockIdx.x;
+    const int N = kp.N;
+    CmpcConsts& K = *reinterpret_cast<CmpcConsts*>(smem);
+    {
+        const int* src = reinterpret_cast<const int*>(kp.kc);
+        int* dst = reinterpret_cast<int*>(smem);
+        for (int e = tid; e < (int)(sizeof(CmpcConsts) / 4); e += NT) dst[e] = src[e];
+    }
+    CmpcLayout L;
+    cmpc_layout_init(L, N);
+    GLay G;
+    glay_init(G, N);
+    float* x = reinterpret_cast<float*>(smem + ((sizeof(CmpcConsts) + 15) & ~15));
+    float* p = x + ((L.nx + 3) & ~3);
+    float* lam = p + ((L.np + 3) & ~3);
+    float* red = lam + ((L.ng + 3) & ~3);
+    for (int e = tid; e < L.nx; e += NT) x[e] = X[(size_t)b * L.nx + e];
+    for (int e = tid; e < L.np; e += NT) p[e] = P[(size_t)b * L.np + e];
+    if (LamG) for (int e = tid; e < L.ng; e += NT) lam[e] = LamG[(size_t)b * L.ng + e];
+    __syncthreads();
+    const float dt = K.dt;
+
+    auto gam = [&](int c, int k) { return p[L.p_gam[c] + k]; };
+    auto rvec = [&](int c, int j, int k, float* r) {
+        const float* R = p + L.p_R[c] + 9 * k;
+        const float* cn = K.corners + 12 * c + 3 * j;
+        for (int i = 0; i < 3; ++i)
+            r[i] = R[i] * cn[0] + R[3 + i] * cn[1] + R[6 + i] * cn[2] + x[L.o_pos[c] + 3 * k + i] - x[L.o_com + 3 * k + i];
+    };
+    auto fcsum = [&](int c, int k, float* Fc) {
+        for (int i = 0; i < 3; ++i)
+            Fc[i] = x[L.o_f[c][0] + 3 * k + i] + x[L.o_f[c][1] + 3 * k + i] + x[L.o_f[c][2] + 3 * k + i] + x[L.o_f[c][3] + 3 * k + i];
+    };
+
+    // ---------------- f ----------------
+    if (F) {
+        float acc = 0.f;
+        for (int e = tid; e < 3 * (N + 1); e += NT) {
+            const int k = e / 3, i = e % 3;
+            const float ec = x[L.o_com + e] - p[L.p_comref + e];
+            acc += (i == 0 ? K.w_com0 : (i == 1 ? K.w_com1 : 0.5f * K.wz2[k])) * ec * ec;
+            const float eh = x[L.o_h + e] - p[L.p_href + e];
+            acc += K.w_h * eh * eh;
+            for (int c = 0; c < 2; ++c) {
+                const float ep = x[L.o_pos[c] + e] - p[L.p_nom[c] + e];
+                acc += K.w_pos * ep * ep;
+            }
+        }
+        for (int e = tid; e < 2 * N * 3; e += NT) {
+            const int c = e / (3 * N), k = (e % (3 * N)) / 3, i = e % 3;
+            const float g = gam(c, k);
+            float mean = 0.f;
+            for (int j = 0; j < 4; ++j) mean += 0.25f * x[L.o_f[c][j] + 3 * k + i];
+            for (int j = 0; j < 4; ++j) {
+                const float fv = x[L.o_f[c][j] + 3 * k + i];
+                const float es = fv - g * mean;
+                acc += K.w_sym * es * es;
+                if (k + 1 < N) {
+                    const float d = x[L.o_f[c][j] + 3 * (k + 1) + i] - fv;
+                    acc += 0.5f * K.D[i] * d * d;
+                }
+            }
+        }
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+        if ((tid & 63) == 0) red[tid >> 6] = acc;
+        __syncthreads();
+        if (tid == 0) F[b] = red[0] + red[1] + red[2] + red[3];
+    }
+    // ---------------- g ----------------
+    if (Gout) {
+        float* g = Gout + (size_t)b * L.ng;
+        for (int r = tid; r < L.ng; r += NT) {
+            float v;
+            if (r < 15) {
+                const int i = r % 3;
+                v = r < 3 ? x[L.o_com + i] : r < 6 ? x[L.o_dcom + i] : r < 9 ? x[L.o_h + i] : r < 12 ? x[L.o_pos[0] + i] : x[L.o_pos[1] + i];
+            } else if (r < G.g_dcom) {
+                const int e = r - G.g_com, k = e / 3;
+                v = x[L.o_com + e + 3] - (x[L.o_com + e] + dt * x[L.o_dcom + e]);
+                (void)k;
+            } else if (r < G.g_h) {
+                const int e = r - G.g_dcom, k = e / 3, i = e % 3;
+                float acc = p[L.p_fext + e] - (i == 2 ? K.grav : 0.f);
+                for (int c = 0; c < 2; ++c) {
+                    float Fc[3];
+                    fcsum(c, k, Fc);
+                    acc += gam(c, k) * Fc[i];
+                }
+                v = x[L.o_dcom + e + 3] - (x[L.o_dcom + e] + dt * acc);
+            } else if (r < G.g_pos[0]) {
+                const int e = r - G.g_h, k = e / 3, i = e % 3, a1 = (i + 1) % 3, a2 = (i + 2) % 3;
+                float tor = p[L.p_text + e];
+                for (int c = 0; c < 2; ++c) {
+                    float t = 0.f;
+                    for (int j = 0; j < 4; ++j) {
+                        float rr[3];
+                        rvec(c, j, k, rr);
+                        const float* f = x + L.o_f[c][j] + 3 * k;
+                        t += rr[a1] * f[a2] - rr[a2] * f[a1];
+                    }
+                    tor += gam(c, k) * t;
+                }
+                v = x[L.o_h + e + 3] - (x[L.o_h + e] + dt * tor);
+            } else if (r < G.g_bbox[0]) {
+                const int c = r < G.g_pos[1] ? 0 : 1, e = r - G.g_pos[c], k = e / 3;
+                v = x[L.o_pos[c] + e + 3] - (x[L.o_pos[c] + e] + dt * (1.f - gam(c, k)) * x[L.o_vel[c] + e]);
+            } else {
+                const int c = r < G.g_bbox[1] ? 0 : 1;
+                if (r < G.g_fric[c]) {
+                    const int e = r - G.g_bbox[c], k = e / 3, i = e % 3;
+                    const float* R = p + L.p_R[c] + 9 * k;
+                    v = 0.f;
+                    for (int a = 0; a < 3; ++a) v += R[3 * i + a] * (x[L.o_pos[c] + 3 * (k + 1) + a] - p[L.p_nom[c] + 3 * (k + 1) + a]);
+                } else {
+                    const int e = r - G.g_fric[c], k = e / 16, j = (e % 16) / 4, face = e % 4;
+                    const float* R = p + L.p_R[c] + 9 * k;
+                    const float* f = x + L.o_f[c][j] + 3 * k;
+                    const float sx = (face == 0 || face == 3) ? 1.f : -1.f, sy = face < 2 ? 1.f : -1.f;
+                    float fl[3];
+                    for (int m = 0; m < 3; ++m) fl[m] = R[3 * m] * f[0] + R[3 * m + 1] * f[1] + R[3 * m + 2] * f[2];
+                    v = sx * fl[0] + sy * fl[1] - K.mu_fr * fl[2];
+                }
+            }
+            g[r] = v;
+        }
+    }
+    // ---------------- grad f ----------------
+    if (GradF) {
+        float* gf = GradF + (size_t)b * L.nx;
+        for (int e = tid; e < L.nx; e += NT) {
+            float v = 0.f;
+            if (e < L.o_dcom) {
+                const int k = e / 3, i = e % 3;
+                v = (i == 0 ? 2.f * K.w_com0 : (i == 1 ? 2.f * K.w_com1 : K.wz2[k])) * (x[e] - p[L.p_comref + e]);
+            } else if (e < L.o_h) {
+                v = 0.f;
+            } else if (e < L.o_pos[0]) {
+                v = 2.f * K.w_h * (x[e] - p[L.p_href + e - L.o_h]);
+            } else {
+                const int c = e < L.o_pos[1] ? 0 : 1;
+                const int e2 = e - L.o_pos[c];
+                if (e2 < 3 * (N + 1)) v = 2.f * K.w_pos * (x[e] - p[L.p_nom[c] + e2]);
+                else if (e2 < 3 * (N + 1) + 3 * N) v = 0.f;
+                else {
+                    const int e3 = e2 - 3 * (N + 1) - 3 * N, j = e3 / (3 * N), k = (e3 % (3 * N)) / 3, i = e3 % 3;
+                    const float g = gam(c, k);
+                    float mean = 0.f;
+                    for (int l = 0; l < 4; ++l) mean += 0.25f * x[L.o_f[c][l] + 3 * k + i];
+                    const float es = x[e] - g * mean, esum = 4.f * mean * (1.f - g);
+                    v = 2.f * K.w_sym * (es - 0.25f * g * esum);
+                    if (k > 0) v += K.D[i] * (x[e] - x[e - 3]);
+                    if (k + 1 < N) v -= K.D[i] * (x[e + 3] - x[e]);
+                    (void)j;
+                }
+            }
+            gf[e] = v;
+        }
+    }
+    // ---------------- jac g (CCS order) ----------------
+    if (Jac) {
+        float* jo = Jac + (size_t)b * nnzj;
+        for (int e = tid; e < nnzj; e += NT) {
+            const int d = jdesc[e];
+            const int kind = d & 15, k = (d >> 4) & 63, c = (d >> 10) & 1, j = (d >> 11) & 3, a = (d >> 13) & 3, bb = (d >> 15) & 3,
+                      face = (d >> 17) & 3;
+            float v;
+            switch (kind) {
+                case J_ONE: v = 1.f; break;
+                case J_MONE: v = -1.f; break;
+                case J_MDT: v = -dt; break;
+                case J_DCOM_F: v = -dt * gam(c, k); break;
+                case J_H_F: {
+                    float rr[3];
+                    rvec(c, j, k, rr);
+                    v = -dt * gam(c, k) * skew(rr, a, bb);
+                } break;
+                case J_H_POS: {
+                    float Fc[3];
+                    fcsum(c, k, Fc);
+                    v = dt * gam(c, k) * skew(Fc, a, bb);
+                } break;
+                case J_H_COM: {
+                    float F0[3], F1[3], Fs[3];
+                    fcsum(0, k, F0);
+                    fcsum(1, k, F1);
+                    for (int i = 0; i < 3; ++i) Fs[i] = gam(0, k) * F0[i] + gam(1, k) * F1[i];
+                    v = -dt * skew(Fs, a, bb);
+                } break;
+                case J_POS_VEL: v = -dt * (1.f - gam(c, k)); break;
+                case J_BBOX: v = p[L.p_R[c] + 9 * k + 3 * a + bb]; break;  // a = bbox row i, bb = pos component
+                default: {  // J_FRIC: bb = force component
+                    const float* R = p + L.p_R[c] + 9 * k;
+                    const float sx = (face == 0 || face == 3) ? 1.f : -1.f, sy = face < 2 ? 1.f : -1.f;
+                    v = sx * R[bb] + sy * R[3 + bb] - K.mu_fr * R[6 + bb];
+                } break;
+            }
+            jo[e] = v;
+        }
+    }
+    // ---------------- hess L (CCS order, full symmetric) ----------------
+    if (Hess) {
+        GLay Gl = G;
+        float* ho = Hess + (size_t)b * nnzh;
+        for (int e = tid; e < nnzh; e += NT) {
+            const int d = hdesc[e];
+            const int kind = d & 15, k = (d >> 4) & 63, c = (d >> 10) & 1, j = (d >> 11) & 3, a = (d >> 13) & 3, bb = (d >> 15) & 3,
+                      l = (d >> 17) & 3;
+            float v;
+            switch (kind) {
+                case H_COMX: v = lam_f * 2.f * K.w_com0; break;
+                case H_COMY: v = lam_f * 2.f * K.w_com1; break;
+                case H_COMZ: v = lam_f * K.wz2[k]; break;
+                case H_H: v = lam_f * 2.f * K.w_h; break;
+                case H_POS: v = lam_f * 2.f * K.w_pos; break;
+                case H_FF: {
+                    const float g = gam(c, k);
+                    v = 2.f * K.w_sym * ((j == l ? 1.f : 0.f) - 0.25f * g * (2.f - g));
+                    if (j == l) v += K.D[a] * (float)((k > 0) + (k + 1 < N));
+                    v *= lam_f;
+                } break;
+                case H_RATE: v = -lam_f * K.D[a]; break;
+                default: {
+                    const float* lh = lam + Gl.g_h + 3 * k;
+                    const float s = dt * gam(c, k) * skew(lh, a, bb);
+                    v = (kind == H_F_POS) ? -s : s;
+                } break;
+            }
+            ho[e] = v;
+        }
+    }
+}
+
+// warm start: previous solution shifted by one knot (last knot repeated); is_warm_start_enabled of
+// the reference (ergoCubGazeboV1/centroidal_mpc.ini:9)
+__global__ __launch_bounds__(256) void cmpc_warm_shift_kernel(int N, int B, const float* __restrict__ Xp, float* __restrict__ X0)
+{
+    CmpcLayout L;
+    cmpc_layout_init(L, N);
+    const int b = blockIdx.x;
+    const float* xp = Xp + (size_t)b * L.nx;
+    float* x0 = X0 + (size_t)b * L.nx;
+    for (int e = threadIdx.x; e < L.nx; e += 256) {
+        // every block of x is 3 x (N+1) or 3 x N, column = knot: find block start and length
+        int start, len;
+        if (e < L.o_pos[0]) { start = (e / (3 * (N + 1))) * 3 * (N + 1); len = 3 * (N + 1); }
+        else {
+            const int c = e < L.o_pos[1] ? 0 : 1, e2 = e - L.o_pos[c];
+            if (e2 < 3 * (N + 1)) { start = L.o_pos[c]; len = 3 * (N + 1); }
+            else { start = L.o_pos[c] + 3 * (N + 1) + ((e2 - 3 * (N + 1)) / (3 * N)) * 3 * N; len = 3 * N; }
+        }
+        const int off = e - start;
+        const int src = off + 3 < len ? e + 3 : e;  // shift by one knot, repeat the last
+        x0[e] = xp[src];
+    }
+}
+
+void build_sparsity(int N, std::vector<Trip>& J, std::vector<Trip>& H)
+{
+    CmpcLayout L;
+    cmpc_layout_init(L, N);
+    GLay G;
+    glay_init(G, N);
+    J.clear(); H.clear();
+    for (int i = 0; i < 3; ++i) {
+        J.push_back({G.g_init + i, L.o_com + i, mk(J_ONE, 0)});
+        J.push_back({G.g_init + 3 + i, L.o_dcom + i, mk(J_ONE, 0)});
+        J.push_back({G.g_init + 6 + i, L.o_h + i, mk(J_ONE, 0)});
+        J.push_back({G.g_init + 9 + i, L.o_pos[0] + i, mk(J_ONE, 0)});
+        J.push_back({G.g_init + 12 + i, L.o_pos[1] + i, mk(J_ONE, 0)});
+    }
+    for (int k = 0; k < N; ++k) {
+        for (int i = 0; i < 3; ++i) {
+            J.push_back({G.g_com + 3 * k + i, L.o_com + 3 * (k + 1) + i, mk(J_ONE, k)});
+            J.push_back({G.g_com + 3 * k + i, L.o_com + 3 * k + i, mk(J_MONE, k)});
+            J.push_back({G.g_com + 3 * k + i, L.o_dcom + 3 * k + i, mk(J_MDT, k)});
+            J.push_back({G.g_dcom + 3 * k + i, L.o_dcom + 3 * (k + 1) + i, mk(J_ONE, k)});
+            J.push_back({G.g_dcom + 3 * k + i, L.o_dcom + 3 * k + i, mk(J_MONE, k)});
+            J.push_back({G.g_h + 3 * k + i, L.o_h + 3 * (k + 1) + i, mk(J_ONE, k)});
+            J.push_back({G.g_h + 3 * k + i, L.o_h + 3 * k + i, mk(J_MONE, k)});
+        }
+        for (int c = 0; c < 2; ++c) {
+            for (int j = 0; j < 4; ++j) {
+                for (int i = 0; i < 3; ++i) J.push_back({G.g_dcom + 3 * k + i, L.o_f[c][j] + 3 * k + i, mk(J_DCOM_F, k, c, j)});
+                for (int a = 0; a < 3; ++a)
+                    for (int b = 0; b < 3; ++b)
+                        if (a != b) J.push_back({G.g_h + 3 * k + a, L.o_f[c][j] + 3 * k + b, mk(J_H_F, k, c, j, a, b)});
+                for (int face = 0; face < 4; ++face)
+                    for (int b = 0; b < 3; ++b)
+                        J.push_back({G.g_fric[c] + 16 * k + 4 * j + face, L.o_f[c][j] + 3 * k + b, mk(J_FRIC, k, c, j, 0, b, face)});
+            }
+            for (int a = 0; a < 3; ++a)
+                for (int b = 0; b < 3; ++b)
+                    if (a != b) J.push_back({G.g_h + 3 * k + a, L.o_pos[c] + 3 * k + b, mk(J_H_POS, k, c, 0, a, b)});
+            for (int i = 0; i < 3; ++i) {
+                J.push_back({G.g_pos[c] + 3 * k + i, L.o_pos[c] + 3 * (k + 1) + i, mk(J_ONE, k)});
+                J.push_back({G.g_pos[c] + 3 * k + i, L.o_pos[c] + 3 * k + i, mk(J_MONE, k)});
+                J.push_back({G.g_pos[c] + 3 * k + i, L.o_vel[c] + 3 * k + i, mk(J_POS_VEL, k, c)});
+                for (int a = 0; a < 3; ++a) J.push_back({G.g_bbox[c] + 3 * k + i, L.o_pos[c] + 3 * (k + 1) + a, mk(J_BBOX, k, c, 0, i, a)});
+            }
+        }
+        for (int a = 0; a < 3; ++a)
+            for (int b = 0; b < 3; ++b)
+                if (a != b) J.push_back({G.g_h + 3 * k + a, L.o_com + 3 * k + b, mk(J_H_COM, k, 0, 0, a, b)});
+    }
+    for (int k = 0; k <= N; ++k) {
+        H.push_back({L.o_com + 3 * k, L.o_com + 3 * k, mk(H_COMX, k)});
+        H.push_back({L.o_com + 3 * k + 1, L.o_com + 3 * k + 1, mk(H_COMY, k)});
+        H.push_back({L.o_com + 3 * k + 2, L.o_com + 3 * k + 2, mk(H_COMZ, k)});
+        for (int i = 0; i < 3; ++i) {
+            H.push_back({L.o_h + 3 * k + i, L.o_h + 3 * k + i, mk(H_H, k)});
+            for (int c = 0; c < 2; ++c) H.push_back({L.o_pos[c] + 3 * k + i, L.o_pos[c] + 3 * k + i, mk(H_POS, k)});
+        }
+    }
+    for (int k = 0; k < N; ++k)
+        for (int c = 0; c < 2; ++c)
+            for (int j = 0; j < 4; ++j) {
+                const int fj = L.o_f[c][j] + 3 * k;
+                for (int l = 0; l < 4; ++l)
+                    for (int i = 0; i < 3; ++i) H.push_back({fj + i, L.o_f[c][l] + 3 * k + i, mk(H_FF, k, c, j, i, 0, l)});
+                if (k + 1 < N)
+                    for (int i = 0; i < 3; ++i) {
+                        H.push_back({fj + i, fj + 3 + i, mk(H_RATE, k, c, j, i)});
+                        H.push_back({fj + 3 + i, fj + i, mk(H_RATE, k, c, j, i)});
+                    }
+                for (int a = 0; a < 3; ++a)
+                    for (int b = 0; b < 3; ++b) {
+                        if (a == b) continue;
+                        H.push_back({fj + a, L.o_pos[c] + 3 * k + b, mk(H_F_POS, k, c, j, a, b)});
+                        H.push_back({L.o_pos[c] + 3 * k + b, fj + a, mk(H_F_POS, k, c, j, a, b)});
+                        H.push_back({fj + a, L.o_com + 3 * k + b, mk(H_F_COM, k, c, j, a, b)});
+                        H.push_back({L.o_com + 3 * k + b, fj + a, mk(H_F_COM, k, c, j, a, b)});
+                    }
+            }
+    auto ccs = [](const Trip& u, const Trip& v) { return u.col != v.col ? u.col < v.col : u.row < v.row; };
+    std::sort(J.begin(), J.end(), ccs);
+    std::sort(H.begin(), H.end(), ccs);
+}
+
+struct DescCache {
+    int N = -1, device = -1;
+    int *dJ = nullptr, *dH = nullptr;
+    int nnzj = 0, nnzh = 0;
+};
+DescCache g_cache;
+
+}  // namespace
+
+extern "C" int cmpc_nlp_sparsity(int N, int* jac_row, int* jac_col, int* hess_row, int* hess_col)
+{
+    if (N < 1 || N > CMPC_NMAX) return -1;
+    std::vector<Trip> J, H;
+    build_sparsity(N, J, H);
+    for (size_t i = 0; i < J.size(); ++i) {
+        if (jac_row) jac_row[i] = J[i].row;
+        if (jac_col) jac_col[i] = J[i].col;
+    }
+    for (size_t i = 0; i < H.size(); ++i) {
+        if (hess_row) hess_row[i] = H[i].row;
+        if (hess_col) hess_col[i] = H[i].col;
+    }
+    return 0;
+}
+
+extern "C" int cmpc_launch_nlp_eval(const CmpcParams* prm, const float* dX, const float* dP, const float* dLamG, float lam_f,
+                                    float* dF, float* dG, float* dGradF, float* dJac, float* dHess, hipStream_t stream)
+{
+    const int N = prm->N;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return (int)e;
+    if (g_cache.N != N || g_cache.device != dev) {
+        std::vector<Trip> J, H;
+        build_sparsity(N, J, H);
+        std::vector<int> dj(J.size()), dh(H.size());
+        for (size_t i = 0; i < J.size(); ++i) dj[i] = J[i].desc;
+        for (size_t i = 0; i < H.size(); ++i) dh[i] = H[i].desc;
+        if (g_cache.dJ) (void)hipFree(g_cache.dJ);
+        if (g_cache.dH) (void)hipFree(g_cache.dH);
+        if ((e = hipMalloc(&g_cache.dJ, dj.size() * sizeof(int))) != hipSuccess) return (int)e;
+        if ((e = hipMalloc(&g_cache.dH, dh.size() * sizeof(int))) != hipSuccess) return (int)e;
+        if ((e = hipMemcpy(g_cache.dJ, dj.data(), dj.size() * sizeof(int), hipMemcpyHostToDevice)) != hipSuccess) return (int)e;
+        if ((e = hipMemcpy(g_cache.dH, dh.data(), dh.size() * sizeof(int), hipMemcpyHostToDevice)) != hipSuccess) return (int)e;
+        g_cache.N = N; g_cache.device = dev; g_cache.nnzj = (int)dj.size(); g_cache.nnzh = (int)dh.size();
+    }
+    CmpcLayout L;
+    cmpc_layout_init(L, N);
+    const size_t lds = ((sizeof(CmpcConsts) + 15) & ~(size_t)15) + 4 * (size_t)(((L.nx + 3) & ~3) + ((L.np + 3) & ~3) + ((L.ng + 3) & ~3) + 8);
+    hipLaunchKernelGGL(cmpc_nlp_eval_kernel, dim3(prm->B), dim3(256), lds, stream, *prm, dX, dP, dLamG, lam_f, dF, dG, dGradF, dJac, dHess,
+                       g_cache.dJ, g_cache.dH, g_cache.nnzj, g_cache.nnzh);
+    return (int)hipGetLastError();
+}
+
+extern "C" int cmpc_launch_warm_shift(const CmpcParams* prm, const float* dXprev, float* dX0, hipStream_t stream)
+{
+    hipLaunchKernelGGL(cmpc_warm_shift_kernel, dim3(prm->B), dim3(256), 0, stream, prm->N, prm->B, dXprev, dX0);
+    return (int)hipGetLastError();
+}

@@ -10,10 +10,20 @@
 // state, contact velocities eliminated -- is stated once in oracle/ipm_ref.c (CPU, float64), which
 // is test infrastructure; this file is the product and shares no code with it.
 //
-// Arithmetic: float32 storage and matrix work (linearisation, value-function updates, triangular
-// solves); float64 where cancellation decides the answer: dynamics defects, right-hand-side /
-// costate recursions, and the 30x30 stage Hessian Quu + its Cholesky (barrier terms z/t span
-// 1e-6..1e9 next to cost curvature of order 10).
+// Arithmetic: float32 storage and matrix work; float64 where cancellation decides the answer:
+// dynamics defects, right-hand-side / costate recursions, and the 3x3 diagonal blocks of the stage
+// Hessian Quu through its Cholesky (barrier terms z/t span 1e-6..1e9 inside one corner's block
+// next to cost curvature of order 10).
+//
+// Structure of one stage of the backward sweep (256 threads = 4 waves, ~5 barriers):
+//   1. G = P [B;E], T1 = Pss A           sparse: every column of A, B has <= 3 non-zeros
+//   2. Quu, Qus, Qss, right-hand sides    (Quu diag blocks in float64)
+//   3. fused Cholesky + panel solve       one wave, matrix rows in registers: lanes 0-29 hold the
+//      rows of Quu, lanes 30-63 hold rows of [Qus | I | qu]^T, so L^{-1}[Qus | I | qu] falls out of
+//      the same rank-1 updates (v_readlane broadcasts, no LDS traffic, no barriers)
+//   4. P = [Qss 0; 0 D] - W^T W           30-term dot products on 16-byte LDS reads
+// The vector sweeps (forward, corrector right-hand side, costates) run on one wave without
+// workgroup barriers.
 #include "cmpc_device.h"
 
 #define NS CMPC_NS
@@ -23,15 +33,17 @@
 #define NXA CMPC_NXA
 #define NI CMPC_NI
 #define LP CMPC_LP
-#define PLD 39   // leading dim of P (odd: column walks are conflict-free)
-#define QLD 47   // leading dim of the solve panel [Qus (15) | I (30) | pad]
-#define QCOLS 46  // 15 (Qus) + 30 (identity -> L^{-1}) + 1 (qu -> lq)
-#define QULD 31  // leading dim of Quu (doubles)
+#define PLD 39     // leading dim of P (odd: column walks are conflict-free)
+#define GLD 30     // G = P [B;E]  (39 x 30)
+#define RLD 36     // leading dim of the row-major float panels (16-byte aligned rows)
+#define NPAN 46    // panel rows: 15 (Qus^T) + 30 (I) + 1 (qu)
+#define GEO 36     // floats of stage geometry: r[24] | Fc[6] | Fsum[3] | pad
+#define NTRI 780   // lower-triangular entries of a 39x39
 
 namespace {
 
 #ifdef CMPC_PROFILE
-// diagnostic build only: per-phase shader-clock sums of workgroup 0 -> prm.scratch[0..31]
+// diagnostic build only: per-phase shader-clock sums of workgroup 0
 __device__ long long g_prof[32];
 #define PROF_DECL long long pt_ = __builtin_amdgcn_s_memtime()
 #define PROF(slot) do { long long n_ = __builtin_amdgcn_s_memtime(); if (threadIdx.x == 0 && blockIdx.x == 0) g_prof[slot] += n_ - pt_; pt_ = n_; } while (0)
@@ -41,24 +53,23 @@ __device__ long long g_prof[32];
 #endif
 
 struct Ctx {
-    // problem
     CmpcLayout L;
     int N;
-    float dt;
     const float* sp;     // parameter vector in LDS
-    // iterate
     float *S, *U, *T, *Z;
     double* LAM;
-    // step
     float *dS, *dU, *dT, *dZ, *d;
-    // factors
-    float *Lf, *Ws, *lqs;
-    // stage workspace
-    float *P0, *P1, *Qx, *A, *Bm, *PA, *PB, *PpB, *PpA, *arow, *geo;
-    double *Quu, *pv, *pn, *qu, *qs, *Pd, *lqd, *sig, *gco, *redd;
+    float *Lf, *Ws, *lqs;  // factors
+    float *geoA;           // N x GEO
+    float *P0, *P1, *G, *T1, *QuuF, *Pan, *Bval, *Aval, *arow, *ybuf, *fpv, *fpn;
+    int *Brow, *Arow;
+    unsigned short* tri;
+    double *QuuD, *pv, *pn, *qs, *Pd, *sig, *gco, *redd;
     float* red;
     int* flag;
 };
+
+__device__ inline void wave_lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
 __device__ inline float gam_of(const Ctx& c, int ct, int k) { return c.sp[c.L.p_gam[ct] + k]; }
 // reference stores vec(R) column-major: R(r,cc) = R[3*cc + r]
@@ -74,43 +85,44 @@ __device__ inline float qlo(const Ctx& c, int k, int m) { return c.sp[c.L.p_lo[m
 __device__ inline float qhi(const Ctx& c, int k, int m) { return c.sp[c.L.p_up[m / 3] + 3 * k + m % 3]; }
 
 // friction row i (0..31) of stage k: a = R (sx, sy, -mu)^T, acting on corner i/4
-__device__ inline void fric_row(const Ctx& c, const CmpcParams& prm, int k, int i, float a[3])
+__device__ inline void fric_row(const Ctx& c, const CmpcConsts& prm, int k, int i, float& a0, float& a1, float& a2)
 {
     const int ct = i >> 4, face = i & 3;
     const float* R = c.sp + c.L.p_R[ct] + 9 * k;
     const float sx = (face == 0 || face == 3) ? 1.f : -1.f;
     const float sy = (face < 2) ? 1.f : -1.f;
-#pragma unroll
-    for (int r = 0; r < 3; ++r) a[r] = sx * Rm(R, r, 0) + sy * Rm(R, r, 1) - prm.mu_fr * Rm(R, r, 2);
+    a0 = sx * Rm(R, 0, 0) + sy * Rm(R, 0, 1) - prm.mu_fr * Rm(R, 0, 2);
+    a1 = sx * Rm(R, 1, 0) + sy * Rm(R, 1, 1) - prm.mu_fr * Rm(R, 1, 2);
+    a2 = sx * Rm(R, 2, 0) + sy * Rm(R, 2, 1) - prm.mu_fr * Rm(R, 2, 2);
 }
 
 __device__ inline bool row_active(const Ctx& c, int k, int i) { return i < 32 ? true : qfree(c, k, (i - 32) % 6); }
 
 // a_i^T u - b_i   (<= 0 feasible)
-__device__ inline float row_val(const Ctx& c, const CmpcParams& prm, int k, int i, const float* u)
+__device__ inline float row_val(const Ctx& c, const CmpcConsts& prm, int k, int i, const float* u)
 {
     if (i < 32) {
-        float a[3];
-        fric_row(c, prm, k, i, a);
+        float a0, a1, a2;
+        fric_row(c, prm, k, i, a0, a1, a2);
         const float* f = u + 3 * (i >> 2);
-        return a[0] * f[0] + a[1] * f[1] + a[2] * f[2];
+        return a0 * f[0] + a1 * f[1] + a2 * f[2];
     }
     if (i < 38) return u[24 + i - 32] - qhi(c, k, i - 32);
     return qlo(c, k, i - 38) - u[24 + i - 38];
 }
-__device__ inline float row_dot(const Ctx& c, const CmpcParams& prm, int k, int i, const float* du)
+__device__ inline float row_dot(const Ctx& c, const CmpcConsts& prm, int k, int i, const float* du)
 {
     if (i < 32) {
-        float a[3];
-        fric_row(c, prm, k, i, a);
+        float a0, a1, a2;
+        fric_row(c, prm, k, i, a0, a1, a2);
         const float* f = du + 3 * (i >> 2);
-        return a[0] * f[0] + a[1] * f[1] + a[2] * f[2];
+        return a0 * f[0] + a1 * f[1] + a2 * f[2];
     }
     if (i < 38) return du[24 + i - 32];
     return -du[24 + i - 38];
 }
 
-__device__ inline float qdiag(const CmpcParams& prm, int k, int i)
+__device__ inline float qdiag(const CmpcConsts& prm, int k, int i)
 {
     if (i == 0) return 2.f * prm.w_com0;
     if (i == 1) return 2.f * prm.w_com1;
@@ -121,7 +133,7 @@ __device__ inline float qdiag(const CmpcParams& prm, int k, int i)
 }
 
 // gradient of the tracking cost w.r.t. component i of s_k
-__device__ inline double grad_track(const Ctx& c, const CmpcParams& prm, int k, int i)
+__device__ inline double grad_track(const Ctx& c, const CmpcConsts& prm, int k, int i)
 {
     const float* s = c.S + NS * k;
     if (i < 3) return (double)qdiag(prm, k, i) * ((double)s[i] - (double)c.sp[c.L.p_comref + 3 * k + i]);
@@ -132,7 +144,7 @@ __device__ inline double grad_track(const Ctx& c, const CmpcParams& prm, int k, 
 }
 
 // gradient of the force-symmetry cost w.r.t. force component m (0..23) of stage k
-__device__ inline double grad_sym(const Ctx& c, const CmpcParams& prm, int k, int m)
+__device__ inline double grad_sym(const Ctx& c, const CmpcConsts& prm, int k, int m)
 {
     const int ct = m / 12, i = m % 3;
     const float* u = c.U + NU * k + 12 * ct;
@@ -172,34 +184,36 @@ __device__ inline double block_sum(double v, double* red, int tid)
     return r;
 }
 
-// ---- geometry of stage k: r_cj = R c_j + pos_c - com (8x3), Fc (2x3, plain sums), Fsum (gam-weighted) ----
-// geo layout: r[24] | Fc[6] | Fsum[3]
-__device__ inline void stage_geo(const Ctx& c, const CmpcParams& prm, int k, int tid)
+// ---- geometry of every stage for the current iterate: r_cj = R c_j + pos_c - com (8x3), Fc (2x3,
+// plain corner sums), Fsum (gam-weighted sum) ----
+template <int NT>
+__device__ inline void all_geo(const Ctx& c, const CmpcConsts& prm, int tid)
 {
-    const float* s = c.S + NS * k;
-    const float* u = c.U + NU * k;
-    if (tid < 24) {
-        const int ct = tid / 12, j = (tid % 12) / 3, i = tid % 3;
-        const float* R = c.sp + c.L.p_R[ct] + 9 * k;
-        const float* cn = prm.corners + 12 * ct + 3 * j;
-        c.geo[tid] = Rm(R, i, 0) * cn[0] + Rm(R, i, 1) * cn[1] + Rm(R, i, 2) * cn[2] + s[9 + 3 * ct + i] - s[i];
-    } else if (tid < 30) {
-        const int ct = (tid - 24) / 3, i = (tid - 24) % 3;
-        const float* f = u + 12 * ct;
-        c.geo[tid] = f[i] + f[3 + i] + f[6 + i] + f[9 + i];
-    } else if (tid < 33) {
-        const int i = tid - 30;
-        float v = 0.f;
-        for (int ct = 0; ct < 2; ++ct) {
+    for (int e = tid; e < c.N * 33; e += NT) {
+        const int k = e / 33, t = e % 33;
+        const float* s = c.S + NS * k;
+        const float* u = c.U + NU * k;
+        float v;
+        if (t < 24) {
+            const int ct = t / 12, j = (t % 12) / 3, i = t % 3;
+            const float* R = c.sp + c.L.p_R[ct] + 9 * k;
+            const float* cn = prm.corners + 12 * ct + 3 * j;
+            v = Rm(R, i, 0) * cn[0] + Rm(R, i, 1) * cn[1] + Rm(R, i, 2) * cn[2] + s[9 + 3 * ct + i] - s[i];
+        } else if (t < 30) {
+            const int ct = (t - 24) / 3, i = (t - 24) % 3;
             const float* f = u + 12 * ct;
-            v += gam_of(c, ct, k) * (f[i] + f[3 + i] + f[6 + i] + f[9 + i]);
+            v = f[i] + f[3 + i] + f[6 + i] + f[9 + i];
+        } else {
+            const int i = t - 30;
+            v = gam_of(c, 0, k) * (u[i] + u[3 + i] + u[6 + i] + u[9 + i])
+                + gam_of(c, 1, k) * (u[12 + i] + u[15 + i] + u[18 + i] + u[21 + i]);
         }
-        c.geo[tid] = v;
+        c.geoA[GEO * k + t] = v;
     }
 }
 
 // dynamics defect component i of stage k in float64: phi_k(s_k,u_k)[i] - s_{k+1}[i]
-__device__ inline double defect(const Ctx& c, const CmpcParams& prm, int k, int i)
+__device__ inline double defect(const Ctx& c, const CmpcConsts& prm, int k, int i)
 {
     const float* s = c.S + NS * k;
     const float* u = c.U + NU * k;
@@ -245,44 +259,47 @@ __device__ inline double defect(const Ctx& c, const CmpcParams& prm, int k, int 
     }
 }
 
-// (B_k^T v)[m] for a 15-vector v (double), closed form (needs stage_geo of stage k)
-__device__ inline double Bt_vec(const Ctx& c, const CmpcParams& prm, int k, int m, const double* v)
+// (B_k^T v)[m], closed form.  T = float or double
+template <typename T>
+__device__ inline T Bt_vec(const Ctx& c, const CmpcConsts& prm, int k, int m, const T* v)
 {
+    const float* geo = c.geoA + GEO * k;
     if (m < 24) {
         const int ct = m / 12, i = m % 3;
-        const float* r = c.geo + 3 * (m / 3);
+        const float* r = geo + 3 * (m / 3);
         const int a1 = (i + 1) % 3, a2 = (i + 2) % 3;
-        // (lam_h x r)_i = lh[a1] r[a2] - lh[a2] r[a1]
-        return (double)prm.dt * (double)gam_of(c, ct, k) * (v[3 + i] + v[6 + a1] * (double)r[a2] - v[6 + a2] * (double)r[a1]);
+        return (T)prm.dt * (T)gam_of(c, ct, k) * (v[3 + i] + v[6 + a1] * (T)r[a2] - v[6 + a2] * (T)r[a1]);
     }
     const int q = m - 24, ct = q / 3, a = q % 3;
-    if (!qfree(c, k, q)) return 0.0;
+    if (!qfree(c, k, q)) return (T)0;
     const float* R = c.sp + c.L.p_R[ct] + 9 * k;
-    const double g1 = 1.0 - (double)gam_of(c, ct, k);
-    return g1 * ((double)Rm(R, 0, a) * v[9 + 3 * ct] + (double)Rm(R, 1, a) * v[10 + 3 * ct] + (double)Rm(R, 2, a) * v[11 + 3 * ct]);
+    const T g1 = (T)1 - (T)gam_of(c, ct, k);
+    return g1 * ((T)Rm(R, 0, a) * v[9 + 3 * ct] + (T)Rm(R, 1, a) * v[10 + 3 * ct] + (T)Rm(R, 2, a) * v[11 + 3 * ct]);
 }
 
-// (A_k^T v)[i] for a 15-vector v (double), closed form (needs stage_geo of stage k)
-__device__ inline double At_vec(const Ctx& c, const CmpcParams& prm, int k, int i, const double* v)
+// (A_k^T v)[i], closed form
+template <typename T>
+__device__ inline T At_vec(const Ctx& c, const CmpcConsts& prm, int k, int i, const T* v)
 {
-    const double dt = prm.dt;
-    if (i < 3) {  // com: v_com + dt (v_h x Fsum)_i
+    const float* geo = c.geoA + GEO * k;
+    const T dt = (T)prm.dt;
+    if (i < 3) {
         const int a1 = (i + 1) % 3, a2 = (i + 2) % 3;
-        const float* Fs = c.geo + 30;
-        return v[i] + dt * (v[6 + a1] * (double)Fs[a2] - v[6 + a2] * (double)Fs[a1]);
+        const float* Fs = geo + 30;
+        return v[i] + dt * (v[6 + a1] * (T)Fs[a2] - v[6 + a2] * (T)Fs[a1]);
     }
     if (i < 6) return dt * v[i - 3] + v[i];
     if (i < 9) return v[i];
     const int ct = (i - 9) / 3, a = (i - 9) % 3, a1 = (a + 1) % 3, a2 = (a + 2) % 3;
-    const float* Fc = c.geo + 24 + 3 * ct;
-    const double gam = gam_of(c, ct, k);
-    // gam v_pos + dt gam (Fc x v_h)_a
-    return gam * (v[i] + dt * ((double)Fc[a1] * v[6 + a2] - (double)Fc[a2] * v[6 + a1]));
+    const float* Fc = geo + 24 + 3 * ct;
+    const T gam = (T)gam_of(c, ct, k);
+    return gam * (v[i] + dt * ((T)Fc[a1] * v[6 + a2] - (T)Fc[a2] * v[6 + a1]));
 }
 
-// (A_k ds + B_k du)[i]  (float, closed form; needs stage_geo of stage k)
-__device__ inline float AB_step(const Ctx& c, const CmpcParams& prm, int k, int i, const float* ds, const float* du)
+// (A_k ds + B_k du)[i]  (float, closed form)
+__device__ inline float AB_step(const Ctx& c, const CmpcConsts& prm, int k, int i, const float* ds, const float* du)
 {
+    const float* geo = c.geoA + GEO * k;
     const float dt = prm.dt;
     if (i < 3) return ds[i] + dt * ds[3 + i];
     if (i < 6) {
@@ -300,8 +317,9 @@ __device__ inline float AB_step(const Ctx& c, const CmpcParams& prm, int k, int 
         for (int ct = 0; ct < 2; ++ct) {
             float t = 0.f;
             const float e1 = ds[9 + 3 * ct + a1] - ds[a1], e2 = ds[9 + 3 * ct + a2] - ds[a2];
+#pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const float* r = c.geo + 12 * ct + 3 * j;
+                const float* r = geo + 12 * ct + 3 * j;
                 const float* df = du + 12 * ct + 3 * j;
                 const float* f = c.U + NU * k + 12 * ct + 3 * j;
                 t += r[a1] * df[a2] - r[a2] * df[a1] + e1 * f[a2] - e2 * f[a1];
@@ -314,67 +332,116 @@ __device__ inline float AB_step(const Ctx& c, const CmpcParams& prm, int k, int 
     const float* R = c.sp + c.L.p_R[ct] + 9 * k;
     const float gam = gam_of(c, ct, k);
     float land = 0.f;
+#pragma unroll
     for (int m = 0; m < 3; ++m)
         if (qfree(c, k, 3 * ct + m)) land += Rm(R, a, m) * du[24 + 3 * ct + m];
     return gam * ds[i] + (1.f - gam) * land;
 }
 
-// ---- dense A (15x15) and B (15x30) of stage k into LDS (needs stage_geo) ----
-template <int NT>
-__device__ inline void build_AB(const Ctx& c, const CmpcParams& prm, int k, int tid)
-{
-    for (int e = tid; e < NS * NS + NS * NU; e += NT) {
-        if (e < NS * NS) c.A[e] = 0.f;
-        else c.Bm[e - NS * NS] = 0.f;
-    }
-    __syncthreads();
-    const float dt = prm.dt;
-    if (tid < 8) {  // corner columns of B
-        const int ct = tid >> 2, col = 3 * tid;
-        const float g = dt * gam_of(c, ct, k);
-        const float* r = c.geo + 3 * tid;
-        for (int i = 0; i < 3; ++i) c.Bm[(3 + i) * NU + col + i] = g;
-        c.Bm[6 * NU + col + 1] = -g * r[2]; c.Bm[6 * NU + col + 2] = g * r[1];
-        c.Bm[7 * NU + col + 0] = g * r[2];  c.Bm[7 * NU + col + 2] = -g * r[0];
-        c.Bm[8 * NU + col + 0] = -g * r[1]; c.Bm[8 * NU + col + 1] = g * r[0];
-    } else if (tid < 10) {  // contact blocks
-        const int ct = tid - 8, col = 9 + 3 * ct;
-        const float gam = gam_of(c, ct, k);
-        const float g = -dt * gam;
-        const float* Fc = c.geo + 24 + 3 * ct;
-        const float* R = c.sp + c.L.p_R[ct] + 9 * k;
-        c.A[6 * NS + col + 1] = -g * Fc[2]; c.A[6 * NS + col + 2] = g * Fc[1];
-        c.A[7 * NS + col + 0] = g * Fc[2];  c.A[7 * NS + col + 2] = -g * Fc[0];
-        c.A[8 * NS + col + 0] = -g * Fc[1]; c.A[8 * NS + col + 1] = g * Fc[0];
-        for (int i = 0; i < 3; ++i) {
-            c.A[(col + i) * NS + col + i] = gam;
-            for (int a = 0; a < 3; ++a)
-                if (qfree(c, k, 3 * ct + a)) c.Bm[(col + i) * NU + 24 + 3 * ct + a] = (1.f - gam) * Rm(R, i, a);
-        }
-    } else if (tid == 10) {
-        const float* Fs = c.geo + 30;
-        for (int i = 0; i < 9; ++i) c.A[i * NS + i] = 1.f;
-        for (int i = 0; i < 3; ++i) c.A[i * NS + 3 + i] = dt;
-        c.A[6 * NS + 1] = -dt * Fs[2]; c.A[6 * NS + 2] = dt * Fs[1];
-        c.A[7 * NS + 0] = dt * Fs[2];  c.A[7 * NS + 2] = -dt * Fs[0];
-        c.A[8 * NS + 0] = -dt * Fs[1]; c.A[8 * NS + 1] = dt * Fs[0];
-    }
-    __syncthreads();
-}
-
 __device__ inline int lpk(int i, int j) { return i * (i + 1) / 2 + j; }  // packed lower (i >= j)
 
-// ---- Riccati backward sweep (matrices + right-hand side).  dZ holds the per-row complementarity
-// target (0 for the affine step).  Returns (uniformly) 0 ok, 1 non-positive pivot. ----
+__device__ inline float readlane_f(float x, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), lane)); }
+__device__ inline double readlane_d(double x, int lane)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(x), lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(x), lane);
+    return __hiloint2double(hi, lo);
+}
+
+// ---- fused Cholesky + panel solve, one wave, rows in registers ----
+// lanes 0..29: row `lane` of the symmetric matrix (v[c], c <= lane, float; its own 3x3 diagonal
+// block in dd[], float64).  Lanes >= 30: a row of the panel [Qus | I | qu]^T (30 floats).
+// On exit v[] holds the row of L (lanes < 30) or of (L^{-1} [Qus | I | qu])^T.  Returns true if a
+// pivot was not positive (uniform across the wave).
+__device__ inline bool chol_solve_fused(float (&v)[NU], double (&dd)[3], int lane)
+{
+    bool bad = false;
+    const int myblk = lane / 3;
+#pragma unroll
+    for (int j = 0; j < NU; ++j) {
+        const int b = j / 3, jm = j % 3;
+        double piv = readlane_d(dd[jm], j);
+        if (!(piv > 0.0)) { bad = true; piv = 1.0; }
+        double rinv = (double)rsqrtf((float)piv);
+        rinv = rinv * (1.5 - 0.5 * piv * rinv * rinv);
+        rinv = rinv * (1.5 - 0.5 * piv * rinv * rinv);
+        const float rinvf = (float)rinv;
+        const bool inblk = (myblk == b);
+        const double ld = inblk ? dd[jm] * rinv : (double)(v[j] * rinvf);
+        const float lf = (float)ld;
+        v[j] = lf;
+        // own diagonal block (float64): entries (lane, 3*myblk + m)
+#pragma unroll
+        for (int m = 0; m < 3; ++m) {
+            const int src = 3 * myblk + m;
+            const double other = __shfl(ld, src & 63);
+            if (src > j && src <= lane) dd[m] -= ld * other;
+        }
+        // everything else (float32): v[c] -= l_ij * l_cj
+#pragma unroll
+        for (int cc = j + 1; cc < NU; ++cc) v[cc] -= lf * readlane_f(lf, cc);
+    }
+    return bad;
+}
+
+// phase 3 of a backward stage, kept out of line so that its ~40 VGPRs of matrix rows and its
+// stream of v_readlane broadcasts get a register allocation of their own
+__device__ inline void stage_factor(const float* QuuF, const double* QuuD, float* Pan, float* Lf, float* Ws, float* lq,
+                                          float D0, float D1, float D2, int* flag, int tid)
+{
+    const int lane = tid & 63, wv = tid >> 6;
+    const int prow = lane - 30 + 34 * wv;  // panel row of lanes >= 30
+    const bool isL = lane < NU;
+    const bool active = isL || prow < NPAN;
+    float v[NU];
+    double dd[3] = {0.0, 0.0, 0.0};
+    {
+        const float* src = isL ? QuuF + lane * RLD : Pan + (active ? prow : 0) * RLD;
+#pragma unroll
+        for (int q4 = 0; q4 < 8; ++q4) {
+            const float4 t4 = *reinterpret_cast<const float4*>(src + 4 * q4);
+            if (4 * q4 + 0 < NU) v[4 * q4 + 0] = t4.x;
+            if (4 * q4 + 1 < NU) v[4 * q4 + 1] = t4.y;
+            if (4 * q4 + 2 < NU) v[4 * q4 + 2] = t4.z;
+            if (4 * q4 + 3 < NU) v[4 * q4 + 3] = t4.w;
+        }
+        if (isL) {
+            dd[0] = QuuD[9 * (lane / 3) + 3 * (lane % 3) + 0];
+            dd[1] = QuuD[9 * (lane / 3) + 3 * (lane % 3) + 1];
+            dd[2] = QuuD[9 * (lane / 3) + 3 * (lane % 3) + 2];
+        }
+    }
+    const bool bad = chol_solve_fused(v, dd, lane);
+    if (bad && tid == 0) *flag = 1;
+    if (!isL && active) {
+        if (prow < NS) {
+#pragma unroll
+            for (int a = 0; a < NU; ++a) { Ws[a * NS + prow] = v[a]; Pan[prow * RLD + a] = v[a]; }
+        } else if (prow < NS + NU) {
+            const int m = prow - NS;
+            const float dm = (m % 3 == 0) ? D0 : ((m % 3 == 1) ? D1 : D2);
+            const float sc = m < NF ? -dm : 0.f;
+#pragma unroll
+            for (int a = 0; a < NU; ++a)
+                if (a >= m) { Lf[lpk(a, m)] = v[a]; Pan[prow * RLD + a] = sc * v[a]; }
+        } else {
+#pragma unroll
+            for (int a = 0; a < NU; ++a) { lq[a] = v[a]; Pan[prow * RLD + a] = v[a]; }
+        }
+    }
+}
+
+// ---- Riccati backward sweep (matrices + right-hand side of the affine step).
+// Returns (uniformly) 0 ok, 1 non-positive pivot. ----
 template <int NT>
-__device__ int riccati_backward(const Ctx& c, const CmpcParams& prm, int tid, bool use_exact, bool affine)
+__device__ int riccati_backward(const Ctx& c, const CmpcConsts& prm, int tid, bool use_exact, float reg)
 {
     const int N = c.N;
     float* Pcur = c.P0;  // value function of stage k+1
     float* Pnew = c.P1;
     bool havep = false;
-    // terminal value
     for (int e = tid; e < NXA * PLD; e += NT) Pcur[e] = 0.f;
+    if (tid == 0) *c.flag = 0;
     __syncthreads();
     if (tid < NS) {
         Pcur[tid * PLD + tid] = qdiag(prm, N, tid);
@@ -385,68 +452,100 @@ __device__ int riccati_backward(const Ctx& c, const CmpcParams& prm, int tid, bo
     for (int k = N - 1; k >= 0; --k) {
         const bool pk = k > 0;
         const float* u = c.U + NU * k;
+        const float* geo = c.geoA + GEO * k;
         PROF_DECL;
-        stage_geo(c, prm, k, tid);
-        __syncthreads();
-        build_AB<NT>(c, prm, k, tid);
-        PROF(0);
-        // ---- per-row barrier coefficients ----
-        if (tid < NI) {
-            double sg = 0.0, gc = 0.0;
-            if (row_active(c, k, tid)) {
-                const double t = c.T[NI * k + tid], z = c.Z[NI * k + tid];
-                const double cmu = affine ? 0.0 : (double)c.dZ[NI * k + tid];
-                const double r = (double)row_val(c, prm, k, tid, u) + t;
-                sg = z / t;
-                gc = cmu / t + sg * r;
-            }
-            c.sig[tid] = sg; c.gco[tid] = gc;
-            if (tid < 32) {
-                float a[3];
-                fric_row(c, prm, k, tid, a);
-                c.arow[3 * tid] = a[0]; c.arow[3 * tid + 1] = a[1]; c.arow[3 * tid + 2] = a[2];
-            }
-        }
-        // ---- PB = Pss B, PA = Pss A, PpB = Pps B, PpA = Pps A ----
-        for (int e = tid; e < NS * NU + NS * NS + (havep ? NF * NU + NF * NS : 0); e += NT) {
-            if (e < NS * NU) {
-                const int i = e / NU, j = e % NU;
-                const int a0 = j < 24 ? 3 : 9 + 3 * ((j - 24) / 3), a1 = j < 24 ? 9 : a0 + 3;
-                float v = 0.f;
-                for (int a = a0; a < a1; ++a) v += Pcur[i * PLD + a] * c.Bm[a * NU + j];
-                c.PB[e] = v;
-            } else if (e < NS * NU + NS * NS) {
-                const int e2 = e - NS * NU, i = e2 / NS, j = e2 % NS;
-                float v = 0.f;
-                for (int a = 0; a < NS; ++a) v += Pcur[i * PLD + a] * c.A[a * NS + j];
-                c.PA[e2] = v;
-            } else if (e < NS * NU + NS * NS + NF * NU) {
-                const int e2 = e - NS * NU - NS * NS, i = e2 / NU, j = e2 % NU;
-                const int a0 = j < 24 ? 3 : 9 + 3 * ((j - 24) / 3), a1 = j < 24 ? 9 : a0 + 3;
-                float v = 0.f;
-                for (int a = a0; a < a1; ++a) v += Pcur[(NS + i) * PLD + a] * c.Bm[a * NU + j];
-                c.PpB[e2] = v;
+        // ---- phase 0: column descriptors of A and B, barrier coefficients ----
+        if (tid < NU) {
+            int r0, r1, r2;
+            float v0, v1, v2;
+            if (tid < NF) {
+                const int ct = tid / 12, a = tid % 3, a1 = (a + 1) % 3, a2 = (a + 2) % 3;
+                const float g = prm.dt * gam_of(c, ct, k);
+                const float* r = geo + 3 * (tid / 3);
+                r0 = 3 + a; v0 = g;
+                r1 = 6 + a1; v1 = g * r[a2];
+                r2 = 6 + a2; v2 = -g * r[a1];
             } else {
-                const int e2 = e - NS * NU - NS * NS - NF * NU, i = e2 / NS, j = e2 % NS;
-                float v = 0.f;
-                for (int a = 0; a < NS; ++a) v += Pcur[(NS + i) * PLD + a] * c.A[a * NS + j];
-                c.PpA[e2] = v;
+                const int q = tid - 24, ct = q / 3, m = q % 3;
+                const float* R = c.sp + c.L.p_R[ct] + 9 * k;
+                const float g1 = qfree(c, k, q) ? 1.f - gam_of(c, ct, k) : 0.f;
+                r0 = 9 + 3 * ct; r1 = r0 + 1; r2 = r0 + 2;
+                v0 = g1 * Rm(R, 0, m); v1 = g1 * Rm(R, 1, m); v2 = g1 * Rm(R, 2, m);
             }
+            c.Brow[3 * tid] = r0; c.Brow[3 * tid + 1] = r1; c.Brow[3 * tid + 2] = r2;
+            c.Bval[3 * tid] = v0; c.Bval[3 * tid + 1] = v1; c.Bval[3 * tid + 2] = v2;
+        } else if (tid >= 32 && tid < 32 + NS) {
+            const int j = tid - 32;
+            int r0 = j, r1 = j, r2 = j;
+            float v0 = 1.f, v1 = 0.f, v2 = 0.f;
+            if (j < 3) {
+                const float* Fs = geo + 30;
+                r1 = 6 + (j + 1) % 3; v1 = prm.dt * Fs[(j + 2) % 3];
+                r2 = 6 + (j + 2) % 3; v2 = -prm.dt * Fs[(j + 1) % 3];
+            } else if (j < 6) {
+                r0 = j - 3; v0 = prm.dt; r1 = j; v1 = 1.f;
+            } else if (j >= 9) {
+                const int ct = (j - 9) / 3, cc = (j - 9) % 3;
+                const float gam = gam_of(c, ct, k);
+                const float* Fc = geo + 24 + 3 * ct;
+                v0 = gam;
+                r1 = 6 + (cc + 1) % 3; v1 = -prm.dt * gam * Fc[(cc + 2) % 3];
+                r2 = 6 + (cc + 2) % 3; v2 = prm.dt * gam * Fc[(cc + 1) % 3];
+            }
+            c.Arow[3 * j] = r0; c.Arow[3 * j + 1] = r1; c.Arow[3 * j + 2] = r2;
+            c.Aval[3 * j] = v0; c.Aval[3 * j + 1] = v1; c.Aval[3 * j + 2] = v2;
+        } else if (tid >= 64 && tid < 64 + NI) {
+            const int i = tid - 64;
+            double sg = 0.0, gc = 0.0;
+            if (row_active(c, k, i)) {
+                const double t = c.T[NI * k + i], z = c.Z[NI * k + i];
+                const double r = (double)row_val(c, prm, k, i, u) + t;
+                sg = z / t;
+                gc = sg * r;  // affine step: complementarity target 0
+            }
+            c.sig[i] = sg; c.gco[i] = gc;
+            if (i < 32) {
+                float a0, a1, a2;
+                fric_row(c, prm, k, i, a0, a1, a2);
+                c.arow[3 * i] = a0; c.arow[3 * i + 1] = a1; c.arow[3 * i + 2] = a2;
+            }
+        } else if (tid >= 128 && tid < 128 + NXA) {
+            // Pd = P [d; 0] + pv  (float64)
+            const int r = tid - 128;
+            double acc = c.pv[r];
+            if (r < NS || havep) {
+#pragma unroll
+                for (int a = 0; a < NS; ++a) acc += (double)Pcur[r * PLD + a] * (double)c.d[NS * k + a];
+            }
+            c.Pd[r] = acc;
         }
-        // Pd = P [d; 0] + pv  (float64, 39)
-        if (tid < NXA) {
-            double acc = c.pv[tid];
-            if (tid < NS || havep)
-                for (int a = 0; a < NS; ++a) acc += (double)Pcur[tid * PLD + a] * (double)c.d[NS * k + a];
-            c.Pd[tid] = acc;
+        __syncthreads();
+        PROF(0);
+        // ---- phase 1: G = P [B;E] (39 x 30), T1 = Pss A (15 x 15) ----
+        {
+            const int nrow = havep ? NXA : NS;
+            for (int e = tid; e < nrow * NU + NS * NS; e += NT) {
+                if (e < nrow * NU) {
+                    const int r = e / NU, i = e % NU;
+                    float v = Pcur[r * PLD + c.Brow[3 * i]] * c.Bval[3 * i] + Pcur[r * PLD + c.Brow[3 * i + 1]] * c.Bval[3 * i + 1]
+                              + Pcur[r * PLD + c.Brow[3 * i + 2]] * c.Bval[3 * i + 2];
+                    if (havep && i < NF) v += Pcur[r * PLD + NS + i];
+                    c.G[r * GLD + i] = v;
+                } else {
+                    const int e2 = e - nrow * NU, i = e2 / NS, j = e2 % NS;
+                    c.T1[e2] = Pcur[i * PLD + c.Arow[3 * j]] * c.Aval[3 * j] + Pcur[i * PLD + c.Arow[3 * j + 1]] * c.Aval[3 * j + 1]
+                               + Pcur[i * PLD + c.Arow[3 * j + 2]] * c.Aval[3 * j + 2];
+                }
+            }
         }
         __syncthreads();
         PROF(1);
-        // ---- Quu (float64) ----
+        // ---- phase 2: Quu (lower; diag 3x3 blocks also in float64), panel [Qus | I | qu]^T, Qss, qs ----
         for (int e = tid; e < NU * NU; e += NT) {
             const int i = e / NU, j = e % NU;
+            if (j > i) continue;
             double v = 0.0;
-            if (i < NF && j < NF) {
+            if (i < NF) {  // then j < NF too
                 const int ci = i / 12, cj = j / 12;
                 if (ci == cj && (i % 3) == (j % 3)) {
                     const double gam = gam_of(c, ci, k);
@@ -459,32 +558,23 @@ __device__ int riccati_backward(const Ctx& c, const CmpcParams& prm, int tid, bo
                         v += c.sig[r0 + f] * (double)c.arow[3 * (r0 + f) + i % 3] * (double)c.arow[3 * (r0 + f) + j % 3];
                 }
                 if (i == j && pk) v += (double)prm.D[i % 3];
-                if (havep) v += (double)Pcur[(NS + i) * PLD + NS + j];
-            } else if (i == j) {  // q diagonal
+            } else if (i == j) {
                 v = qfree(c, k, i - 24) ? c.sig[32 + i - 24] + c.sig[38 + i - 24] : 1.0;
             }
-            {   // B^T P B
-                const int a0 = i < 24 ? 3 : 9 + 3 * ((i - 24) / 3), a1 = i < 24 ? 9 : a0 + 3;
-                double acc = 0.0;
-                for (int a = a0; a < a1; ++a) acc += (double)c.Bm[a * NU + i] * (double)c.PB[a * NU + j];
-                v += acc;
-            }
-            if (havep) {
-                if (i < NF) v += (double)c.PpB[i * NU + j];
-                if (j < NF) v += (double)c.PpB[j * NU + i];
-            }
-            c.Quu[i * QULD + j] = v;
+            if (i == j) v += (double)reg;
+            v += (double)c.Bval[3 * i] * (double)c.G[c.Brow[3 * i] * GLD + j] + (double)c.Bval[3 * i + 1] * (double)c.G[c.Brow[3 * i + 1] * GLD + j]
+                 + (double)c.Bval[3 * i + 2] * (double)c.G[c.Brow[3 * i + 2] * GLD + j];
+            if (havep && i < NF) v += (double)c.G[(NS + i) * GLD + j];
+            c.QuuF[i * RLD + j] = (float)v;
+            if (i / 3 == j / 3) c.QuuD[9 * (i / 3) + 3 * (i % 3) + j % 3] = v;
         }
-        PROF(2);
-        // ---- solve panel Qx = [Qus | I] ----
-        for (int e = tid; e < NU * QCOLS; e += NT) {
-            const int i = e / QCOLS, j = e % QCOLS;
+        for (int e = tid; e < (NPAN - 1) * NU; e += NT) {
+            const int r = e / NU, i = e % NU;  // panel row r (column of [Qus | I]), entry i
             float v;
-            if (j < NS) {
-                const int a0 = i < 24 ? 3 : 9 + 3 * ((i - 24) / 3), a1 = i < 24 ? 9 : a0 + 3;
-                v = 0.f;
-                for (int a = a0; a < a1; ++a) v += c.Bm[a * NU + i] * c.PA[a * NS + j];
-                if (havep && i < NF) v += c.PpA[i * NS + j];
+            if (r < NS) {
+                const int j = r;
+                v = c.G[c.Arow[3 * j] * GLD + i] * c.Aval[3 * j] + c.G[c.Arow[3 * j + 1] * GLD + i] * c.Aval[3 * j + 1]
+                    + c.G[c.Arow[3 * j + 2] * GLD + i] * c.Aval[3 * j + 2];
                 if (use_exact && i < NF) {
                     // S[f_cj, pos_c] = dt gam [lam_h]x ; S[f_cj, com] = -dt gam [lam_h]x
                     const int ct = i / 12, a = i % 3;
@@ -493,21 +583,18 @@ __device__ int riccati_backward(const Ctx& c, const CmpcParams& prm, int tid, bo
                     if (j < 3) { b = j; sgn = -1.f; }
                     else if (j >= 9 + 3 * ct && j < 12 + 3 * ct) { b = j - 9 - 3 * ct; sgn = 1.f; }
                     if (b >= 0 && b != a) {
-                        // [l]x(a,b): (0,1)=-l2 (0,2)=l1 (1,0)=l2 (1,2)=-l0 (2,0)=-l1 (2,1)=l0
                         const int o = 3 - a - b;
                         const float lv = (float)c.LAM[NS * (k + 1) + 6 + o];
                         const float sk = ((b - a + 3) % 3 == 1) ? -lv : lv;
                         v += sgn * prm.dt * gam_of(c, ct, k) * sk;
                     }
                 }
-            } else if (j < NS + NU) {
-                v = (j - NS == i) ? 1.f : 0.f;
-            } else continue;  // column 45 (qu) is written with the right-hand sides below
-            c.Qx[i * QLD + j] = v;
+            } else {
+                v = (r - NS == i) ? 1.f : 0.f;
+            }
+            c.Pan[r * RLD + i] = v;
         }
-        PROF(3);
-        // ---- right-hand sides (float64) ----
-        if (tid < NU) {
+        if (tid < NU) {  // qu (float64 -> float: it vanishes at convergence, so float keeps its relative accuracy)
             double g;
             if (tid < NF) {
                 g = grad_sym(c, prm, k, tid);
@@ -520,216 +607,132 @@ __device__ int riccati_backward(const Ctx& c, const CmpcParams& prm, int tid, bo
                 const int q = tid - 24;
                 g = qfree(c, k, q) ? c.gco[32 + q] - c.gco[38 + q] : 0.0;
             }
-            g += Bt_vec(c, prm, k, tid, c.Pd);
-            // qu -> 0 at convergence, so float keeps its relative accuracy through the solve
-            c.Qx[tid * QLD + NS + NU] = (float)g;
+            g += Bt_vec<double>(c, prm, k, tid, c.Pd);
+            c.Pan[(NPAN - 1) * RLD + tid] = (float)g;
         } else if (tid >= 64 && tid < 64 + NS) {
             const int i = tid - 64;
-            c.qs[i] = grad_track(c, prm, k, i) + At_vec(c, prm, k, i, c.Pd);
+            c.qs[i] = grad_track(c, prm, k, i) + At_vec<double>(c, prm, k, i, c.Pd);
         }
-        __syncthreads();
-        PROF(4);
-        // ---- Qss = A^T PA + Q  -> Pnew ss block (W^T W subtracted below) ----
-        for (int e = tid; e < NS * NS; e += NT) {
-            const int i = e / NS, j = e % NS;
+        for (int e = tid + 128; e < 128 + NS * NS; e += NT) {  // Qss = A^T T1 + Q
+            const int e2 = e - 128, i = e2 / NS, j = e2 % NS;
             float v = (i == j) ? qdiag(prm, k, i) : 0.f;
-            for (int a = 0; a < NS; ++a) v += c.A[a * NS + i] * c.PA[a * NS + j];
+            v += c.Aval[3 * i] * c.T1[c.Arow[3 * i] * NS + j] + c.Aval[3 * i + 1] * c.T1[c.Arow[3 * i + 1] * NS + j]
+                 + c.Aval[3 * i + 2] * c.T1[c.Arow[3 * i + 2] * NS + j];
             Pnew[i * PLD + j] = v;
         }
-        PROF(5);
-        // ---- Cholesky of Quu in float64 (right-looking; L columns land in place, scaled) ----
-        for (int j = 0; j < NU; ++j) {
-            const double piv = c.Quu[j * QULD + j];
-            if (!(piv > 0.0)) return 1;  // uniform: every thread reads the same LDS word
-            const double rinv = 1.0 / sqrt(piv);
-            __syncthreads();  // everyone has read the pivot / column before it is rescaled
-            // trailing update uses the unscaled column j: A[i][c] -= A[i][j] A[c][j] / piv
-            const int n = NU - 1 - j;
-            for (int e = tid; e < n * n; e += NT) {
-                const int i = j + 1 + e / n, cc = j + 1 + e % n;
-                if (cc <= i) c.Quu[i * QULD + cc] -= c.Quu[i * QULD + j] * c.Quu[cc * QULD + j] * (rinv * rinv);
-            }
-            __syncthreads();
-            if (tid >= j && tid < NU) c.Quu[tid * QULD + j] *= rinv;
-        }
         __syncthreads();
-        PROF(6);
-        // ---- W = L^{-1} [Qus | I]  (one column per thread, float32), lq = L^{-1} qu (float64) ----
-        if (tid < QCOLS) {
-            const int j = tid;
-            const int i0 = (j < NS || j == NS + NU) ? 0 : j - NS;  // identity columns start at their own row
-            for (int i = i0; i < NU; ++i) {
-                float v = c.Qx[i * QLD + j];
-                for (int a = i0; a < i; ++a) v -= (float)c.Quu[i * QULD + a] * c.Qx[a * QLD + j];
-                c.Qx[i * QLD + j] = v / (float)c.Quu[i * QULD + i];
-            }
-        }
+        PROF(2);
+        // ---- phase 3: fused Cholesky + panel solve (waves 0 and 1; each repeats the factorisation) ----
+        if (tid < 128)
+            stage_factor(c.QuuF, c.QuuD, c.Pan, c.Lf + (size_t)LP * k, c.Ws + (size_t)(NU * NS) * k, c.lqs + NU * k,
+                         prm.D[0], prm.D[1], prm.D[2], c.flag, tid);
         __syncthreads();
-        if (tid < NU) c.lqd[tid] = (double)c.Qx[tid * QLD + NS + NU];
-        PROF(7);
-        // ---- store factors: Linv (packed lower), Ws, lq ----
+        PROF(3);
+        if (*c.flag) return 1;
+        // ---- phase 4: P = [Qss 0; 0 D] - W^T W  (rows of the panel are W^T rows; p rows pre-scaled by -D) ----
         {
-            float* Lf = c.Lf + (size_t)LP * k;
-            float* Ws = c.Ws + (size_t)(NU * NS) * k;
-            for (int e = tid; e < NU * NU; e += NT) {
-                const int i = e / NU, j = e % NU;
-                if (j <= i) Lf[lpk(i, j)] = c.Qx[i * QLD + NS + j];
-            }
-            for (int e = tid; e < NU * NS; e += NT) Ws[e] = c.Qx[(e / NS) * QLD + e % NS];
-            if (tid < NU) c.lqs[NU * k + tid] = c.Qx[tid * QLD + NS + NU];
-        }
-        __syncthreads();
-        PROF(8);
-        // ---- value function of stage k:  P = [Qss 0; 0 D] - W^T W,  W = [Ws | Wp], Wp = -Linv[:, :24] D ----
-        {
-            const int ncol = pk ? NXA : NS;
-            for (int e = tid; e < ncol * ncol; e += NT) {
-                const int i = e / ncol, j = e % ncol;
-                if (j > i) continue;
-                float v = 0.f;
-                const int ci = i < NS ? i : NS + (i - NS), cj = j < NS ? j : NS + (j - NS);
-                const int a0 = i < NS ? 0 : i - NS;  // Linv[a][i-NS] = 0 for a < i-NS
-                for (int a = a0; a < NU; ++a) v += c.Qx[a * QLD + ci] * c.Qx[a * QLD + cj];
-                if (i >= NS) v *= prm.D[(i - NS) % 3];
-                if (j >= NS) v *= prm.D[(j - NS) % 3];
-                if ((i >= NS) != (j >= NS)) v = -v;  // one factor of (-D)
-                // (-D)(-D) = +, so ss and pp blocks get -W^T W
+            const int ntri = pk ? NTRI : NS * (NS + 1) / 2;
+            for (int e = tid; e < ntri; e += NT) {
+                const unsigned short ij = c.tri[e];
+                const int i = ij >> 8, j = ij & 255;
+                const float4* ri = reinterpret_cast<const float4*>(c.Pan + i * RLD);
+                const float4* rj = reinterpret_cast<const float4*>(c.Pan + j * RLD);
+                float acc = 0.f;
+#pragma unroll
+                for (int q4 = 0; q4 < 8; ++q4) {
+                    const float4 x = ri[q4], y = rj[q4];
+                    acc += x.x * y.x + x.y * y.y;
+                    if (q4 < 7) acc += x.z * y.z + x.w * y.w;  // columns 30, 31 are padding
+                }
                 float base = 0.f;
-                if (i < NS) base = Pnew[i * PLD + j];       // Qss
+                if (i < NS) base = Pnew[i * PLD + j];
                 else if (i == j) base = prm.D[(i - NS) % 3];
-                float r;
-                if ((i >= NS) != (j >= NS)) r = base - v;    // sp block: -Ws^T Wp = +Ws^T Linv D -> v already negated
-                else r = base - v;
+                const float r = base - acc;
                 Pnew[i * PLD + j] = r;
                 Pnew[j * PLD + i] = r;
             }
             // gradient of the value function (float64)
-            if (tid >= 64 && tid < 64 + ncol) {
-                const int i = tid - 64;
+            const int ncol = pk ? NXA : NS;
+            if (tid >= 192 && tid < 192 + NXA) {
+                const int i = tid - 192;
                 double v = 0.0;
-                if (i < NS) {
-                    for (int a = 0; a < NU; ++a) v += (double)c.Qx[a * QLD + i] * c.lqd[a];
-                    c.pn[i] = c.qs[i] - v;
-                } else {
-                    const int m = i - NS;
-                    for (int a = m; a < NU; ++a) v += (double)c.Qx[a * QLD + NS + m] * c.lqd[a];
-                    // qp = -D (u - u_prev);  Wp^T lq = -D Linv[:,m]^T lq
-                    c.pn[i] = -(double)prm.D[m % 3] * ((double)u[m] - (double)c.U[NU * (k - 1) + m]) + (double)prm.D[m % 3] * v;
+                if (i < ncol) {
+                    const float* ri = c.Pan + i * RLD;
+                    const float* rl = c.Pan + (NPAN - 1) * RLD;
+#pragma unroll
+                    for (int a = 0; a < NU; ++a) v += (double)ri[a] * (double)rl[a];
+                    if (i < NS) v = c.qs[i] - v;
+                    else {
+                        const int m = i - NS;
+                        v = -(double)prm.D[m % 3] * ((double)u[m] - (double)c.U[NU * (k - 1) + m]) - v;
+                    }
                 }
+                c.pn[i] = v;
             }
         }
         __syncthreads();
-        if (tid < NXA) c.pv[tid] = (tid < (pk ? NXA : NS)) ? c.pn[tid] : 0.0;
-        {   // swap
+        PROF(4);
+        if (tid < NXA) c.pv[tid] = c.pn[tid];
+        {
             float* t = Pcur; Pcur = Pnew; Pnew = t;
         }
         havep = pk;
         __syncthreads();
-        PROF(9);
     }
     return 0;
 }
 
-// ---- vector-only backward sweep for the corrector: the row coefficients change by DG = CMU/t
-// (dZ holds CMU); updates lq in place ----
+// ---- forward sweep on wave 0: dS, dU.  All threads then compute dT, dZ (dZ holds the per-row
+// complementarity target on entry unless affine). ----
 template <int NT>
-__device__ void riccati_delta(const Ctx& c, const CmpcParams& prm, int tid)
+__device__ void riccati_forward(const Ctx& c, const CmpcConsts& prm, int tid, bool affine)
 {
     const int N = c.N;
-    bool havep = false;
-    if (tid < NXA) c.pv[tid] = 0.0;
-    __syncthreads();
-    for (int k = N - 1; k >= 0; --k) {
-        const bool pk = k > 0;
-        const float* Lf = c.Lf + (size_t)LP * k;
-        const float* Ws = c.Ws + (size_t)(NU * NS) * k;
-        stage_geo(c, prm, k, tid);
-        if (tid >= 64 && tid < 64 + NI) {
-            const int i = tid - 64;
-            c.gco[i] = row_active(c, k, i) ? (double)c.dZ[NI * k + i] / (double)c.T[NI * k + i] : 0.0;
-            if (i < 32) {
-                float a[3];
-                fric_row(c, prm, k, i, a);
-                c.arow[3 * i] = a[0]; c.arow[3 * i + 1] = a[1]; c.arow[3 * i + 2] = a[2];
-            }
-        }
-        __syncthreads();
-        if (tid < NU) {
-            double g;
-            if (tid < NF) {
-                const int r0 = 4 * (tid / 3);
-                g = 0.0;
+    if (tid < 64) {
+        float ymax = 0.f;
+        if (tid < NS) c.dS[tid] = 0.f;
+        wave_lds_sync();
+        for (int k = 0; k < N; ++k) {
+            const float* Lf = c.Lf + (size_t)LP * k;
+            const float* Ws = c.Ws + (size_t)(NU * NS) * k;
+            if (tid < NU) {
+                const int i = tid;
+                float v = c.lqs[NU * k + i];
 #pragma unroll
-                for (int f = 0; f < 4; ++f) g += c.gco[r0 + f] * (double)c.arow[3 * (r0 + f) + tid % 3];
-                if (havep) g += c.pv[NS + tid];
-            } else {
-                const int q = tid - 24;
-                g = qfree(c, k, q) ? c.gco[32 + q] - c.gco[38 + q] : 0.0;
+                for (int a = 0; a < NS; ++a) v += Ws[i * NS + a] * c.dS[NS * k + a];
+                if (k > 0) {  // Wp dp = -Linv[:, :24] D dp   (loads past the row end are masked, not skipped)
+                    const float* dp = c.dU + NU * (k - 1);
+                    const float* Li = Lf + lpk(i, 0);
+                    const float D0 = prm.D[0], D1 = prm.D[1], D2 = prm.D[2];
+#pragma unroll
+                    for (int a = 0; a < NF; ++a) {
+                        const float l = Li[a];
+                        v -= (a <= i ? l : 0.f) * (a % 3 == 0 ? D0 : (a % 3 == 1 ? D1 : D2)) * dp[a];
+                    }
+                }
+                c.ybuf[i] = -v;
+                ymax = fmaxf(ymax, fabsf(v));
             }
-            c.qu[tid] = g + Bt_vec(c, prm, k, tid, c.pv);
+            wave_lds_sync();
+            if (tid < NU) {  // du = Linv^T y
+                float v = 0.f;
+#pragma unroll
+                for (int a = 0; a < NU; ++a) {
+                    const float l = Lf[lpk(a, 0) + (tid <= a ? tid : 0)];
+                    v += (a >= tid ? l : 0.f) * c.ybuf[a];
+                }
+                c.dU[NU * k + tid] = v;
+            }
+            wave_lds_sync();
+            if (tid < NS) c.dS[NS * (k + 1) + tid] = AB_step(c, prm, k, tid, c.dS + NS * k, c.dU + NU * k) + c.d[NS * k + tid];
+            wave_lds_sync();
         }
-        __syncthreads();
-        if (tid < NU) {  // dl = Linv dq (lower-triangular mat-vec)
-            double v = 0.0;
-            for (int a = 0; a <= tid; ++a) v += (double)Lf[lpk(tid, a)] * c.qu[a];
-            c.lqd[tid] = v;
-            c.lqs[NU * k + tid] += (float)v;
-        }
-        __syncthreads();
-        if (tid < NXA) {
-            double v;
-            if (tid < NS) {
-                v = At_vec(c, prm, k, tid, c.pv);
-                for (int a = 0; a < NU; ++a) v -= (double)Ws[a * NS + tid] * c.lqd[a];
-            } else if (pk) {
-                const int m = tid - NS;
-                v = 0.0;
-                for (int a = m; a < NU; ++a) v += (double)Lf[lpk(a, m)] * c.lqd[a];
-                v *= (double)prm.D[m % 3];
-            } else v = 0.0;
-            c.pn[tid] = v;
-        }
-        __syncthreads();
-        if (tid < NXA) c.pv[tid] = c.pn[tid];
-        havep = pk;
-        __syncthreads();
+        // curvature-weighted size of the step: y = L^T du, |y|^2 = du^T Quu du
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) ymax = fmaxf(ymax, __shfl_xor(ymax, o));
+        if (tid == 0) c.red[4] = ymax;
     }
-}
-
-// ---- forward sweep: dS, dU, then dT and dZ (dZ holds the complementarity target on entry
-// unless affine) ----
-template <int NT>
-__device__ void riccati_forward(const Ctx& c, const CmpcParams& prm, int tid, bool affine)
-{
-    const int N = c.N;
-    float* y = c.red + 8;  // 30 floats of scratch
-    if (tid < NS) c.dS[tid] = 0.f;
     __syncthreads();
-    for (int k = 0; k < N; ++k) {
-        const float* Lf = c.Lf + (size_t)LP * k;
-        const float* Ws = c.Ws + (size_t)(NU * NS) * k;
-        stage_geo(c, prm, k, tid);
-        if (tid >= 64 && tid < 64 + NU) {
-            const int i = tid - 64;
-            float v = c.lqs[NU * k + i];
-            for (int a = 0; a < NS; ++a) v += Ws[i * NS + a] * c.dS[NS * k + a];
-            if (k > 0) {  // Wp dp = -Linv[:, :24] D dp
-                const float* dp = c.dU + NU * (k - 1);
-                const int na = i < NF ? i + 1 : NF;
-                for (int a = 0; a < na; ++a) v -= Lf[lpk(i, a)] * prm.D[a % 3] * dp[a];
-            }
-            y[i] = -v;
-        }
-        __syncthreads();
-        if (tid < NU) {  // du = Linv^T y
-            float v = 0.f;
-            for (int a = tid; a < NU; ++a) v += Lf[lpk(a, tid)] * y[a];
-            c.dU[NU * k + tid] = v;
-        }
-        __syncthreads();
-        if (tid < NS) c.dS[NS * (k + 1) + tid] = AB_step(c, prm, k, tid, c.dS + NS * k, c.dU + NU * k) + c.d[NS * k + tid];
-        __syncthreads();
-    }
     for (int e = tid; e < N * NI; e += NT) {
         const int k = e / NI, i = e % NI;
         float dt_ = 0.f, dz_ = 0.f;
@@ -741,6 +744,79 @@ __device__ void riccati_forward(const Ctx& c, const CmpcParams& prm, int tid, bo
             dz_ = (cmu - z * t) / t - (z / t) * dt_;
         }
         c.dT[e] = dt_; c.dZ[e] = dz_;
+    }
+    __syncthreads();
+}
+
+// ---- corrector right-hand side on wave 0: the row coefficients change by CMU/t (dZ holds CMU);
+// updates lq in place through the stored factors ----
+__device__ void riccati_delta(const Ctx& c, const CmpcConsts& prm, int tid)
+{
+    const int N = c.N;
+    if (tid < 64) {
+        bool havep = false;
+        if (tid < NXA) c.fpv[tid] = 0.f;
+        wave_lds_sync();
+        for (int k = N - 1; k >= 0; --k) {
+            const bool pk = k > 0;
+            const float* Lf = c.Lf + (size_t)LP * k;
+            const float* Ws = c.Ws + (size_t)(NU * NS) * k;
+            if (tid < NU) {
+                float g;
+                if (tid < NF) {
+                    const int r0 = 4 * (tid / 3);
+                    g = 0.f;
+#pragma unroll
+                    for (int f = 0; f < 4; ++f) {
+                        float a0, a1, a2;
+                        fric_row(c, prm, k, r0 + f, a0, a1, a2);
+                        const float av = (tid % 3 == 0) ? a0 : ((tid % 3 == 1) ? a1 : a2);
+                        g += c.dZ[NI * k + r0 + f] / c.T[NI * k + r0 + f] * av;
+                    }
+                    if (havep) g += c.fpv[NS + tid];
+                } else {
+                    const int q = tid - 24;
+                    g = qfree(c, k, q) ? c.dZ[NI * k + 32 + q] / c.T[NI * k + 32 + q] - c.dZ[NI * k + 38 + q] / c.T[NI * k + 38 + q] : 0.f;
+                }
+                c.ybuf[tid] = g + Bt_vec<float>(c, prm, k, tid, c.fpv);
+            }
+            wave_lds_sync();
+            if (tid < NU) {  // dl = Linv dq
+                float v = 0.f;
+                const float* Li = Lf + lpk(tid, 0);
+#pragma unroll
+                for (int a = 0; a < NU; ++a) {
+                    const float l = Li[a <= tid ? a : 0];
+                    v += (a <= tid ? l : 0.f) * c.ybuf[a];
+                }
+                c.ybuf[32 + tid] = v;
+                c.lqs[NU * k + tid] += v;
+            }
+            wave_lds_sync();
+            if (tid < NXA) {
+                float v;
+                const float* dl = c.ybuf + 32;
+                if (tid < NS) {
+                    v = At_vec<float>(c, prm, k, tid, c.fpv);
+#pragma unroll
+                    for (int a = 0; a < NU; ++a) v -= Ws[a * NS + tid] * dl[a];
+                } else if (pk) {
+                    const int m = tid - NS;
+                    v = 0.f;
+#pragma unroll
+                    for (int a = 0; a < NU; ++a) {
+                        const float l = Lf[lpk(a, 0) + (m <= a ? m : 0)];
+                        v += (a >= m ? l : 0.f) * dl[a];
+                    }
+                    v *= prm.D[m % 3];
+                } else v = 0.f;
+                c.fpn[tid] = v;
+            }
+            wave_lds_sync();
+            if (tid < NXA) c.fpv[tid] = c.fpn[tid];
+            havep = pk;
+            wave_lds_sync();
+        }
     }
     __syncthreads();
 }
@@ -759,92 +835,127 @@ __device__ void step_lengths(const Ctx& c, int tid, float tau, float& ap, float&
     ad = block_min<NT>(a_d, c.red, tid);
 }
 
-// new costates (backward), blended into LAM with step ap:  lam_k = gs_k + Q_k ds_k + S_k^T du_k + A_k^T lam_{k+1}
-template <int NT>
-__device__ void costate_update(const Ctx& c, const CmpcParams& prm, int tid, float ap, bool use_exact)
+// new costates (backward, wave 0), blended into LAM with step ap:
+//   lam_k = gs_k + Q_k ds_k + S_k^T du_k + A_k^T lam_{k+1}
+__device__ void costate_update(const Ctx& c, const CmpcConsts& prm, int tid, float ap, bool use_exact)
 {
     const int N = c.N;
-    // pv <- full-step lam_{k+1}
-    if (tid < NS) c.pv[tid] = grad_track(c, prm, N, tid) + (double)qdiag(prm, N, tid) * (double)c.dS[NS * N + tid];
-    __syncthreads();
-    if (tid < NS) c.LAM[NS * N + tid] += (double)ap * (c.pv[tid] - c.LAM[NS * N + tid]);
-    for (int k = N - 1; k >= 1; --k) {
-        stage_geo(c, prm, k, tid);
-        // dFc (gam-weighted force-step sums) for the S^T du term, using the OLD lam_{k+1} (the one the Hessian used)
-        if (tid >= 64 && tid < 70) {
-            const int ct = (tid - 64) / 3, i = (tid - 64) % 3;
-            const float* df = c.dU + NU * k + 12 * ct;
-            c.gco[tid - 64] = (double)gam_of(c, ct, k) * ((double)df[i] + df[3 + i] + df[6 + i] + df[9 + i]);
-        }
-        __syncthreads();
-        if (tid < NS) {
-            double v = grad_track(c, prm, k, tid) + (double)qdiag(prm, k, tid) * (double)c.dS[NS * k + tid] + At_vec(c, prm, k, tid, c.pv);
-            if (use_exact && (tid < 3 || tid >= 9)) {
-                // Sx = dt [lh]x with lh = lam_h,k+1 used in the Hessian (= c.qs scratch holds it)
-                const double* lh = c.qs;  // 3 doubles, old lam_h of stage k+1
-                const int i = tid < 3 ? tid : (tid - 9) % 3;
-                const int a1 = (i + 1) % 3, a2 = (i + 2) % 3;
-                double F[3];
-                if (tid < 3) { F[0] = c.gco[0] + c.gco[3]; F[1] = c.gco[1] + c.gco[4]; F[2] = c.gco[2] + c.gco[5]; }
-                else { const int ct = (tid - 9) / 3; F[0] = c.gco[3 * ct]; F[1] = c.gco[3 * ct + 1]; F[2] = c.gco[3 * ct + 2]; }
-                // (Sx^T F)_i = dt (F x lh)_i ... Sx^T = -dt[lh]x  -> (Sx^T F) = -dt (lh x F) = dt (F x lh)
-                const double sxtf = (double)prm.dt * (F[a1] * lh[a2] - F[a2] * lh[a1]);
-                v += (tid < 3) ? -sxtf : sxtf;
+    if (tid < 64) {
+        if (tid < 3) c.qs[tid] = c.LAM[NS * N + 6 + tid];  // lam_h,N the Hessian used
+        if (tid < NS) c.pv[tid] = grad_track(c, prm, N, tid) + (double)qdiag(prm, N, tid) * (double)c.dS[NS * N + tid];
+        wave_lds_sync();
+        if (tid < NS) c.LAM[NS * N + tid] += (double)ap * (c.pv[tid] - c.LAM[NS * N + tid]);
+        for (int k = N - 1; k >= 1; --k) {
+            if (tid < NS) {
+                double v = grad_track(c, prm, k, tid) + (double)qdiag(prm, k, tid) * (double)c.dS[NS * k + tid] + At_vec<double>(c, prm, k, tid, c.pv);
+                if (use_exact && (tid < 3 || tid >= 9)) {
+                    const double* lh = c.qs;  // old lam_h of stage k+1
+                    const int i = tid < 3 ? tid : (tid - 9) % 3;
+                    const int a1 = (i + 1) % 3, a2 = (i + 2) % 3;
+                    const float* du = c.dU + NU * k;
+                    const double g0 = gam_of(c, 0, k), g1 = gam_of(c, 1, k);
+                    double F1, F2;  // components a1, a2 of the gam-weighted force-step sum
+                    if (tid < 3) {
+                        F1 = g0 * ((double)du[a1] + du[3 + a1] + du[6 + a1] + du[9 + a1]) + g1 * ((double)du[12 + a1] + du[15 + a1] + du[18 + a1] + du[21 + a1]);
+                        F2 = g0 * ((double)du[a2] + du[3 + a2] + du[6 + a2] + du[9 + a2]) + g1 * ((double)du[12 + a2] + du[15 + a2] + du[18 + a2] + du[21 + a2]);
+                    } else {
+                        const int ct = (tid - 9) / 3;
+                        const float* df = du + 12 * ct;
+                        const double g = ct ? g1 : g0;
+                        F1 = g * ((double)df[a1] + df[3 + a1] + df[6 + a1] + df[9 + a1]);
+                        F2 = g * ((double)df[a2] + df[3 + a2] + df[6 + a2] + df[9 + a2]);
+                    }
+                    // (S^T du) = dt (F x lam_h) on pos rows, minus that on com rows
+                    const double sxtf = (double)prm.dt * (F1 * lh[a2] - F2 * lh[a1]);
+                    v += (tid < 3) ? -sxtf : sxtf;
+                }
+                c.pn[tid] = v;
             }
-            c.pn[tid] = v;
+            wave_lds_sync();
+            if (tid < NS) {
+                c.pv[tid] = c.pn[tid];
+                if (tid >= 6 && tid < 9) c.qs[tid - 6] = c.LAM[NS * k + tid];
+                c.LAM[NS * k + tid] += (double)ap * (c.pn[tid] - c.LAM[NS * k + tid]);
+            }
+            wave_lds_sync();
         }
-        __syncthreads();
-        if (tid < NS) {
-            c.pv[tid] = c.pn[tid];
-            if (tid >= 6 && tid < 9) c.qs[tid - 6] = c.LAM[NS * k + tid];  // old lam_h,k for the next (k-1) stage
-            c.LAM[NS * k + tid] += (double)ap * (c.pn[tid] - c.LAM[NS * k + tid]);
-        }
-        __syncthreads();
     }
+    __syncthreads();
 }
 
-template <int NT>
-__global__ __launch_bounds__(NT) void cmpc_solve_kernel(CmpcParams prm)
+// NC > 0: horizon known at compile time (every LDS offset becomes an immediate); NC == 0: runtime N
+// FG: the per-stage factors (Linv, Ws: 915 floats per stage) live in global scratch instead of LDS
+// (horizons whose LDS image would exceed 160 KiB)
+template <int NT, int NC, bool FG>
+__global__ __launch_bounds__(NT) void cmpc_solve_kernel(CmpcParams kp)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int b = blockIdx.x;
-    const int N = prm.N;
+    const int N = NC > 0 ? NC : kp.N;
+    // constants first in LDS
+    CmpcConsts& prmw = *reinterpret_cast<CmpcConsts*>(smem);
+    {
+        const int* src = reinterpret_cast<const int*>(kp.kc);
+        int* dst = reinterpret_cast<int*>(smem);
+        for (int e = tid; e < (int)(sizeof(CmpcConsts) / 4); e += NT) dst[e] = src[e];
+    }
+    const CmpcConsts& prm = prmw;
+    constexpr int KBYTES = (sizeof(CmpcConsts) + 15) & ~15;
     const long long t_start = __builtin_amdgcn_s_memtime();
     Ctx c;
     cmpc_layout_init(c.L, N);
-    c.N = N; c.dt = prm.dt;
-    // ---- carve LDS: doubles first ----
-    double* dp = reinterpret_cast<double*>(smem);
-    c.LAM = dp; dp += NS * (N + 1);
-    c.Quu = dp; dp += NU * QULD;
-    c.pv = dp; dp += 40; c.pn = dp; dp += 40; c.qu = dp; dp += 30; c.qs = dp; dp += 16; c.Pd = dp; dp += 40;
-    c.lqd = dp; dp += 30; c.sig = dp; dp += NI; c.gco = dp; dp += NI; c.redd = dp; dp += 8;
+    c.N = N;
+    // ---- carve LDS: doubles first, then 16-byte aligned float panels ----
+    double* dp = reinterpret_cast<double*>(smem + KBYTES);
+    c.LAM = dp; dp += NS * (N + 1) + ((NS * (N + 1)) & 1);
+    c.QuuD = dp; dp += 90;
+    c.pv = dp; dp += 40; c.pn = dp; dp += 40; c.qs = dp; dp += 16; c.Pd = dp; dp += 40;
+    c.sig = dp; dp += NI; c.gco = dp; dp += NI; c.redd = dp; dp += 8;
     float* fp = reinterpret_cast<float*>(dp);
+    c.QuuF = fp; fp += NU * RLD;
+    c.Pan = fp; fp += NPAN * RLD;
     float* spw = fp; fp += (c.L.np + 3) & ~3;
     c.sp = spw;
     c.S = fp; fp += NS * (N + 1); c.U = fp; fp += NU * N; c.T = fp; fp += NI * N; c.Z = fp; fp += NI * N;
     c.dS = fp; fp += NS * (N + 1); c.dU = fp; fp += NU * N; c.dT = fp; fp += NI * N; c.dZ = fp; fp += NI * N;
     c.d = fp; fp += NS * N;
     c.lqs = fp; fp += NU * N;
+    c.geoA = fp; fp += GEO * N;
     c.P0 = fp; fp += NXA * PLD; c.P1 = fp; fp += NXA * PLD;
-    c.Qx = fp; fp += NU * QLD;
-    c.A = fp; fp += NS * NS; c.Bm = fp; fp += NS * NU; c.PA = fp; fp += NS * NS; c.PB = fp; fp += NS * NU;
-    c.PpB = fp; fp += NF * NU; c.PpA = fp; fp += NF * NS;
-    c.arow = fp; fp += 96; c.geo = fp; fp += 36; c.red = fp; fp += 48;
+    c.G = fp; fp += NXA * GLD; c.T1 = fp; fp += NS * NS;
+    c.Bval = fp; fp += 3 * NU; c.Aval = fp; fp += 3 * NS + 3;
+    c.arow = fp; fp += 96; c.ybuf = fp; fp += 64; c.fpv = fp; fp += 40; c.fpn = fp; fp += 40; c.red = fp; fp += 8;
+    c.Brow = reinterpret_cast<int*>(fp); fp += 3 * NU;
+    c.Arow = reinterpret_cast<int*>(fp); fp += 3 * NS + 3;
     c.flag = reinterpret_cast<int*>(fp); fp += 4;
-    c.Lf = fp; fp += (size_t)LP * N;
-    c.Ws = fp; fp += (size_t)(NU * NS) * N;
+    c.tri = reinterpret_cast<unsigned short*>(fp); fp += NTRI / 2;
+    if (FG) {
+        c.Lf = kp.scratch + (size_t)b * kp.scratch_stride;
+        c.Ws = c.Lf + (size_t)LP * N;
+    } else {
+        c.Lf = fp; fp += (size_t)LP * N;
+        c.Ws = fp; fp += (size_t)(NU * NS) * N;
+    }
 
-    // ---- load the parameter vector (coalesced) ----
+    // ---- one-off tables, parameter vector (coalesced) ----
+    for (int e = tid; e < NTRI; e += NT) {
+        int i = (int)((sqrtf(8.f * (float)e + 1.f) - 1.f) * 0.5f);
+        while ((i + 1) * (i + 2) / 2 <= e) ++i;
+        while (i * (i + 1) / 2 > e) --i;
+        c.tri[e] = (unsigned short)((i << 8) | (e - i * (i + 1) / 2));
+    }
+    for (int e = tid; e < NPAN * RLD; e += NT) c.Pan[e] = 0.f;
+    for (int e = tid; e < NU * RLD; e += NT) c.QuuF[e] = 0.f;
+    if (tid < 90) c.QuuD[tid] = 0.0;
     {
-        const float* gp = prm.P + (size_t)b * c.L.np;
+        const float* gp = kp.P + (size_t)b * c.L.np;
         for (int e = tid; e < c.L.np; e += NT) spw[e] = gp[e];
     }
     __syncthreads();
     // ---- initial iterate from x0 ----
     {
-        const float* x0 = prm.X0 + (size_t)b * c.L.nx;
+        const float* x0 = kp.X0 + (size_t)b * c.L.nx;
         for (int e = tid; e < NS * (N + 1); e += NT) {
             const int k = e / NS, i = e % NS;
             float v;
@@ -891,14 +1002,15 @@ __global__ __launch_bounds__(NT) void cmpc_solve_kernel(CmpcParams prm)
     nrow += 32 * N;
 
     int it = 0, status = 1, gn = 0;
-    float err = 0.f, ep = 0.f, mu_cur = 0.f, es_out = 0.f;
+    float err = 0.f, ep = 0.f, mu_cur = 0.f, step_out = 0.f;
     bool finishing = false;
     for (it = 0; it < prm.max_iter + 1; ++it) {
         if (it == prm.max_iter && !finishing) break;
         // ---- residuals of the current iterate ----
         PROF_DECL;
-        float l_ep = 0.f, l_ec = 0.f, l_es = 0.f;
+        float l_ep = 0.f, l_ec = 0.f;
         double l_mu = 0.0;
+        all_geo<NT>(c, prm, tid);
         for (int e = tid; e < NS * N; e += NT) {
             const double dv = defect(c, prm, e / NS, e % NS);
             c.d[e] = (float)dv;
@@ -913,51 +1025,21 @@ __global__ __launch_bounds__(NT) void cmpc_solve_kernel(CmpcParams prm)
                 l_mu += (double)t * z;
             }
         }
-        // stationarity (float64), one stage at a time through the closed forms
-        for (int k = 0; k <= N; ++k) {
-            if (k < N) stage_geo(c, prm, k, tid);
-            __syncthreads();
-            if (k < N && tid < NU) {
-                if (tid < NF || qfree(c, k, tid - 24)) {
-                    double r = Bt_vec(c, prm, k, tid, c.LAM + NS * (k + 1));
-                    if (tid < NF) {
-                        r += grad_sym(c, prm, k, tid);
-                        const float* u = c.U + NU * k;
-                        if (k > 0) r += (double)prm.D[tid % 3] * ((double)u[tid] - (double)c.U[NU * (k - 1) + tid]);
-                        if (k + 1 < N) r -= (double)prm.D[tid % 3] * ((double)c.U[NU * (k + 1) + tid] - (double)u[tid]);
-                        const int r0 = 4 * (tid / 3);
-                        for (int f = 0; f < 4; ++f) {
-                            float a[3];
-                            fric_row(c, prm, k, r0 + f, a);
-                            r += (double)c.Z[NI * k + r0 + f] * (double)a[tid % 3];
-                        }
-                    } else {
-                        const int q = tid - 24;
-                        r += (double)c.Z[NI * k + 32 + q] - (double)c.Z[NI * k + 38 + q];
-                    }
-                    l_es = fmaxf(l_es, fabsf((float)r));
-                }
-            } else if (k > 0 && tid >= 64 && tid < 64 + NS) {
-                const int i = tid - 64;
-                double r = grad_track(c, prm, k, i) - c.LAM[NS * k + i];
-                if (k < N) r += At_vec(c, prm, k, i, c.LAM + NS * (k + 1));
-                l_es = fmaxf(l_es, fabsf((float)r));
-            }
-            __syncthreads();
-        }
         ep = block_max<NT>(l_ep, c.red, tid);
         const float ec = block_max<NT>(l_ec, c.red, tid);
-        const float es = block_max<NT>(l_es, c.red, tid);
         mu_cur = (float)(block_sum<NT>(l_mu, c.redd, tid) / (double)nrow);
-        es_out = es;
         PROF(10);
-        // ---- predictor (affine scaling) ----
+        // ---- predictor (affine scaling): factorise; on a non-positive pivot fall back to the
+        // Gauss-Newton Hessian, then to a larger Levenberg shift ----
         bool exact = prm.exact_hessian != 0;
-        int fail = riccati_backward<NT>(c, prm, tid, exact, true);
-        if (fail) {
+        float reg = prm.reg;
+        int fail = 1;
+        for (int attempt = 0; attempt < 4; ++attempt) {
+            fail = riccati_backward<NT>(c, prm, tid, exact, reg);
+            if (!fail) break;
             __syncthreads();
             ++gn; exact = false;
-            fail = riccati_backward<NT>(c, prm, tid, false, true);
+            if (attempt > 0) reg *= 1e3f;
         }
         if (fail) { status = 2; break; }
         PROF(11);
@@ -986,29 +1068,29 @@ __global__ __launch_bounds__(NT) void cmpc_solve_kernel(CmpcParams prm)
             c.dZ[e] = row_active(c, e / NI, e % NI) ? mu_t - c.dT[e] * c.dZ[e] : 0.f;  // complementarity target
         __syncthreads();
         PROF(13);
-        riccati_delta<NT>(c, prm, tid);
+        riccati_delta(c, prm, tid);
         PROF(14);
         riccati_forward<NT>(c, prm, tid, false);
         PROF(15);
         step_lengths<NT>(c, tid, fmaxf(0.99f, 1.f - mu_t), ap, ad);
         // ---- costates, then the iterate ----
-        if (tid < 3) c.qs[tid] = c.LAM[NS * N + 6 + tid];
-        __syncthreads();
-        costate_update<NT>(c, prm, tid, ap, exact);
+        costate_update(c, prm, tid, ap, exact);
         PROF(16);
         for (int e = tid; e < NS * (N + 1); e += NT) c.S[e] += ap * c.dS[e];
         for (int e = tid; e < NU * N; e += NT) c.U[e] += ap * c.dU[e];
         for (int e = tid; e < NI * N; e += NT) { c.T[e] += ap * c.dT[e]; c.Z[e] += ad * c.dZ[e]; }
-        // ---- convergence: the Newton step itself is the error estimate.  (The stationarity residual
-        // `es` of a float32-stored iterate cannot go below ~1e-3: one ulp of com_z moves its
-        // gradient by 2 w_z^2 ulp ~ 5e-3; it is reported, not tested.) ----
+        // ---- convergence: the Newton step itself is the error estimate.  Flat directions of the cost
+        // (e.g. the internal force along the line joining the feet) are kept quiet by the Levenberg
+        // shift `reg`.  The stationarity residual of a float32-stored iterate cannot go below ~1e-3
+        // (one ulp of com_z moves its gradient by 2 w_z^2 ulp ~ 5e-3), so it is not the test. ----
         float l_st = 0.f;
         for (int e = tid; e < NS * (N + 1); e += NT) l_st = fmaxf(l_st, fabsf(c.dS[e]));
         for (int e = tid; e < NU * N; e += NT) l_st = fmaxf(l_st, fabsf(c.dU[e]));
         const float step = ap * block_max<NT>(l_st, c.red, tid);
-        err = fmaxf(fmaxf(0.1f * step, ep), ec);
+        step_out = step;
+        err = fmaxf(ep, ec);
         PROF(17);
-        if (err <= prm.tol) {
+        if (err <= prm.tol && step <= prm.step_tol) {
             status = 0;
             if (!prm.final_extrap) { ++it; break; }
             finishing = true;
@@ -1016,7 +1098,7 @@ __global__ __launch_bounds__(NT) void cmpc_solve_kernel(CmpcParams prm)
     }
     // ---- export x in the reference layout ----
     {
-        float* x = prm.X + (size_t)b * c.L.nx;
+        float* x = kp.X + (size_t)b * c.L.nx;
         for (int e = tid; e < NS * (N + 1); e += NT) {
             const int k = e / NS, i = e % NS;
             if (i < 9) x[c.L.o_com + 3 * (N + 1) * (i / 3) + 3 * k + i % 3] = c.S[e];
@@ -1031,10 +1113,10 @@ __global__ __launch_bounds__(NT) void cmpc_solve_kernel(CmpcParams prm)
                 x[c.L.o_vel[ct] + 3 * k + i] = v;
             }
         }
-        if (prm.info && tid == 0) {
-            float* inf = prm.info + (size_t)b * CMPC_INFO_N;
+        if (kp.info && tid == 0) {
+            float* inf = kp.info + (size_t)b * CMPC_INFO_N;
             inf[0] = (float)it; inf[1] = err; inf[2] = mu_cur; inf[3] = (float)gn; inf[4] = ep; inf[5] = (float)status;
-            inf[6] = (float)(__builtin_amdgcn_s_memtime() - t_start); inf[7] = es_out;
+            inf[6] = (float)(__builtin_amdgcn_s_memtime() - t_start); inf[7] = step_out;
         }
     }
 }
@@ -1042,15 +1124,17 @@ __global__ __launch_bounds__(NT) void cmpc_solve_kernel(CmpcParams prm)
 }  // namespace
 
 // LDS bytes the kernel needs for horizon N
-extern "C" size_t cmpc_solver_lds_bytes(int N)
+extern "C" size_t cmpc_solver_lds_bytes(int N, int factors_global)
 {
     CmpcLayout L;
     cmpc_layout_init(L, N);
-    size_t dbl = (size_t)CMPC_NS * (N + 1) + NU * QULD + 40 + 40 + 30 + 16 + 40 + 30 + NI + NI + 8;
-    size_t flt = ((L.np + 3) & ~3) + 2 * ((size_t)NS * (N + 1) + (size_t)NU * N + 2 * (size_t)NI * N) + (size_t)NS * N
-                 + (size_t)NU * N + 2 * NXA * PLD + NU * QLD + 2 * NS * NS + 2 * NS * NU + NF * NU + NF * NS + 96 + 36 + 48 + 4
-                 + (size_t)LP * N + (size_t)NU * NS * N;
-    return dbl * 8 + flt * 4;
+    const size_t nlam = (size_t)NS * (N + 1) + (((size_t)NS * (N + 1)) & 1);
+    const size_t dbl = nlam + 90 + 40 + 40 + 16 + 40 + NI + NI + 8;
+    const size_t flt = (size_t)NU * RLD + (size_t)NPAN * RLD + ((L.np + 3) & ~3)
+                       + 2 * ((size_t)NS * (N + 1) + (size_t)NU * N + 2 * (size_t)NI * N) + (size_t)NS * N + (size_t)NU * N
+                       + (size_t)GEO * N + 2 * NXA * PLD + NXA * GLD + NS * NS + 3 * NU + 3 * NS + 3 + 96 + 64 + 40 + 40 + 8
+                       + 3 * NU + 3 * NS + 3 + 4 + NTRI / 2 + (factors_global ? 0 : (size_t)LP * N + (size_t)NU * NS * N);
+    return ((sizeof(CmpcConsts) + 15) & ~(size_t)15) + dbl * 8 + flt * 4;
 }
 
 #ifdef CMPC_PROFILE
@@ -1065,9 +1149,19 @@ extern "C" int cmpc_profile_read(long long* out, int reset)
 extern "C" int cmpc_launch_solver(const CmpcParams* prm, size_t lds_bytes, hipStream_t stream)
 {
     constexpr int NT = 256;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&cmpc_solve_kernel<NT>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    void (*kern)(CmpcParams) = nullptr;
+    if (prm->scratch) {
+        kern = cmpc_solve_kernel<NT, 0, true>;
+    } else {
+        switch (prm->N) {  // horizons of the shipped configurations get compile-time layouts
+            case 10: kern = cmpc_solve_kernel<NT, 10, false>; break;
+            case 12: kern = cmpc_solve_kernel<NT, 12, false>; break;
+            case 20: kern = cmpc_solve_kernel<NT, 20, false>; break;
+            default: kern = cmpc_solve_kernel<NT, 0, false>; break;
+        }
+    }
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(cmpc_solve_kernel<NT>, dim3(prm->B), dim3(NT), lds_bytes, stream, *prm);
+    hipLaunchKernelGGL(kern, dim3(prm->B), dim3(NT), lds_bytes, stream, *prm);
     return (int)hipGetLastError();
 }

@@ -1,0 +1,183 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP solver through the C ABI against
+(a) the committed float64 goldens, (b) the float64 oracle on freshly seeded batches, and
+(c) size-independent properties at BASELINE.json's full batch sizes.
+
+Tolerance (north_star): <= 1e-4 relative on the CoM trajectory and the contact forces (forces
+modulo the internal-force direction the NLP leaves undetermined, see tests/parity.py); foot
+positions <= 1e-4 m.  The arithmetic is float32 storage / float64 residuals."""
+import os
+
+import numpy as np
+import pytest
+
+import cmpc_amd as cm
+from tests import parity
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+CASES = {"known_answer_n12": lambda: cm.synthetic.standing_known_answer(),
+         "cfg1": lambda: cm.synthetic.config1_plumbing(),
+         "cfg2": lambda: cm.synthetic.config2_perturbed_com(8),
+         "cfg3": lambda: cm.synthetic.config3_external_push(8),
+         "cfg5": lambda: cm.synthetic.config5_footstep_candidates(4)}
+
+
+def _oracle(cfg, P32, X032, nthreads=16):
+    from oracle import oracle_lib as ol, problem_nlp
+    Xr, info = ol.ref_solve_batch(problem_nlp.oracle_cfg(cfg), P32.astype(np.float64), X032.astype(np.float64),
+                                  ol.ipm_opts(tol=1e-9, mu_min=1e-10), nthreads=nthreads)
+    assert (info[:, 5] == 0).all()
+    return Xr
+
+
+def test_hip_library_is_loaded():
+    lib = cm._capi.lib()
+    assert os.path.basename(lib._name) == "libcmpc_hip.so"
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_matches_golden(name, golden_dir):
+    d = np.load(os.path.join(golden_dir, f"argmin_{name}.npz"))
+    cfg = CASES[name]()[0]
+    B = d["P"].shape[0]
+    s = cm.BatchSolver(cfg, B)
+    X, info, rc = s.solve_host(d["P"], d["X0"])
+    assert rc == 0 and (info[:, 5] == 0).all(), (rc, info[:, 5], s.last_error)
+    for b in range(B):
+        e = parity.errors(cfg.N, d["P"][b], X[b], d["x_star"][b])
+        assert e["com"] < TOL and e["force0"] < TOL and e["forces"] < TOL and e["pos"] < TOL, (b, e)
+    s.close()
+
+
+def test_known_answer_objective():
+    """f* = 8.16487469 for the standing problem (float32 inputs: 8.1648620)."""
+    from oracle import oracle_lib as ol, problem_nlp
+    cfg, P, X0 = cm.synthetic.standing_known_answer()
+    s = cm.BatchSolver(cfg, 1)
+    X, info, rc = s.solve_host(P, X0)
+    assert rc == 0
+    f, _ = ol.nlp_fg(problem_nlp.oracle_cfg(cfg), X[0].astype(np.float64), P[0].astype(np.float32).astype(np.float64))
+    assert abs(f - 8.1648620) < 2e-5
+
+
+@pytest.mark.parametrize("gen,B", [(cm.synthetic.config2_perturbed_com, 256), (cm.synthetic.config3_external_push, 256)])
+def test_batch_matches_oracle(gen, B):
+    cfg, P, X0 = gen(B)
+    P32, X032 = P.astype(np.float32), X0.astype(np.float32)
+    s = cm.BatchSolver(cfg, B)
+    X, info, rc = s.solve_host(P32, X032)
+    assert rc == 0, s.last_error
+    Xr = _oracle(cfg, P32, X032)
+    worst = dict(com=0.0, force0=0.0, pos=0.0)
+    for b in range(B):
+        e = parity.errors(cfg.N, P32[b], X[b], Xr[b])
+        for k in worst:
+            worst[k] = max(worst[k], e[k])
+    assert worst["com"] < TOL and worst["force0"] < TOL and worst["pos"] < TOL, worst
+
+
+def test_device_and_host_entry_points_agree():
+    import torch
+    cfg, P, X0 = cm.synthetic.config3_external_push(64)
+    P32, X032 = P.astype(np.float32), X0.astype(np.float32)
+    s = cm.BatchSolver(cfg, 64)
+    Xh, infoh, rc = s.solve_host(P32, X032)
+    dX, dI = s.solve_device(torch.from_numpy(P32).cuda(), torch.from_numpy(X032).cuda())
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(dX.cpu().numpy(), Xh)  # same kernel, same inputs: bit-identical
+    assert s.last_solve_ms() > 0
+
+
+def test_full_size_properties_config3():
+    """B = 4096 (config 3): every problem converges, satisfies the NLP's constraints, batch order is
+    irrelevant (problem b of a permuted batch == permuted problem), and duplicates agree bitwise."""
+    from oracle import oracle_lib as ol, problem_nlp
+    B = 4096
+    cfg, P, X0 = cm.synthetic.config3_external_push(B)
+    P32, X032 = P.astype(np.float32), X0.astype(np.float32)
+    s = cm.BatchSolver(cfg, B)
+    X, info, rc = s.solve_host(P32, X032)
+    assert rc == 0 and (info[:, 5] == 0).all(), s.last_error
+    perm = np.random.default_rng(0).permutation(B)
+    Xp, _, _ = s.solve_host(P32[perm], X032[perm])
+    np.testing.assert_array_equal(Xp, X[perm])
+    # feasibility of a sample with the oracle's g(x): dynamics rows ~0, friction rows <= 0
+    oc = problem_nlp.oracle_cfg(cfg)
+    N = cfg.N
+    for b in range(0, B, 512):
+        _, g = ol.nlp_fg(oc, X[b].astype(np.float64), P32[b].astype(np.float64))
+        lb, ub = problem_nlp.bounds(cfg, P32[b].astype(np.float64))
+        assert np.abs(g[15:15 + 15 * N]).max() < 2e-6          # dynamics
+        assert (g <= ub + 2e-6).all() and (g >= lb - 2e-6).all()
+
+
+def test_step_adjustment_is_active_in_config3():
+    cfg, P, X0 = cm.synthetic.config3_external_push(32)
+    mpc = cm.CentroidalMPC(batch=32)
+    assert mpc.initialize(cfg)
+    L = cm.Layout(cfg.N)
+    s = cm.BatchSolver(cfg, 32)
+    X, info, rc = s.solve_host(P, X0)
+    assert rc == 0
+    land = L.x_pos(X, 0)[:, 14, :]     # left foot lands at knot 14 (Gamma = 1x6, 0x8, 1x6)
+    nominal = np.array([0.1, 0.08, 0.0])
+    d = land - nominal
+    assert (np.abs(d[:, 0]) <= 0.01 + 1e-5).all() and (d[:, 1] >= -1e-5).all() and (d[:, 1] <= 0.05 + 1e-5).all()
+    assert np.abs(d[:, :2]).max() > 5e-5   # pushes move the footstep (w_pos = 2e3 keeps it within ~0.1 mm)
+    assert np.abs(d[:, 2]).max() < 1e-6    # z is an equality row (lower == upper == 0)
+
+
+def test_class_surface_round_trip():
+    """setState / setReferenceTrajectory / setContactPhaseList / advance / getOutput, as
+    CentroidalMPCBlock.cpp:407-622 drives them, reproduce the tensor-level solve."""
+    cfg, P, X0 = cm.synthetic.config3_external_push(16)
+    N, L = cfg.N, cm.Layout(cfg.N)
+    from cmpc_amd.synthetic import _walking_lists
+    mpc = cm.CentroidalMPC(batch=16)
+    assert mpc.initialize(cfg), mpc.last_error
+    st = P[:, L.p_com0:L.p_com0 + 9]
+    wrench = np.zeros((16, N, 6), np.float32)
+    wrench[:, :, :3] = P[:, L.p_fext:L.p_fext + 3 * N].reshape(16, N, 3)
+    assert mpc.set_state(st[:, 0:3], st[:, 3:6], st[:, 6:9], wrench)
+    assert mpc.set_reference_trajectory(P[:, L.p_comref:L.p_comref + 3 * (N + 1)], P[:, L.p_href:L.p_href + 3 * (N + 1)])
+    assert mpc.set_contact_phase_list(_walking_lists(cfg, 6, 8))
+    assert mpc.advance(), mpc.last_error
+    assert mpc.is_output_valid()
+    out = mpc.get_output()
+    s = cm.BatchSolver(cfg, 16)
+    X, info, rc = s.solve_host(P, X0)
+    np.testing.assert_allclose(out.forces, L.first_forces(X), rtol=0, atol=2e-5)
+    assert (out.next_knots[:, 0] == 14).all() and (out.next_knots[:, 1] == -1).all()
+    np.testing.assert_allclose(out.next_positions[:, 0], L.x_pos(X, 0)[:, 14], atol=2e-6)
+    # warm start (previous solution shifted by one knot, is_warm_start_enabled) reaches the same optimum
+    X_cold, _ = mpc.get_solution()
+    assert mpc.set_initial_guess(None, shift_previous=True) and mpc.advance()
+    X_warm, info_warm = mpc.get_solution()
+    assert (info_warm[:, 5] == 0).all()
+    for b in range(16):
+        e = parity.errors(cfg.N, P[b], X_warm[b], X_cold[b])
+        assert e["com"] < TOL and e["force0"] < TOL, e
+
+
+def test_error_paths_return_false_like_the_reference():
+    mpc = cm.CentroidalMPC(batch=2)
+    assert not mpc.advance() and "initialize" in mpc.last_error
+    cfg = cm.config.ergocub_gazebo_v1()
+    assert mpc.initialize(cfg)
+    bad = dict(R=np.zeros((2, 2, cfg.N, 3, 3)), upper=np.zeros((2, 2, cfg.N, 3)), lower=np.ones((2, 2, cfg.N, 3)),
+               enabled=np.ones((2, 2, cfg.N)), nominal=np.zeros((2, 2, cfg.N + 1, 3)), current=np.zeros((2, 2, 3)))
+    assert not mpc.set_contact_phase_list(bad) and "upper < lower" in mpc.last_error
+
+
+def test_long_horizon_uses_global_factor_storage():
+    """N = 30 (config 5) does not fit the 160 KiB LDS image; factors go to HBM scratch."""
+    cfg, P, X0 = cm.synthetic.config5_footstep_candidates(64)
+    P32, X032 = P.astype(np.float32), X0.astype(np.float32)
+    s = cm.BatchSolver(cfg, 64)
+    X, info, rc = s.solve_host(P32, X032)
+    assert rc == 0, s.last_error
+    Xr = _oracle(cfg, P32, X032)
+    for b in range(64):
+        e = parity.errors(cfg.N, P32[b], X[b], Xr[b])
+        assert e["com"] < TOL and e["force0"] < TOL and e["pos"] < TOL, (b, e)

@@ -7,7 +7,7 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: F401  (same HIP runtime)
 import cmpc_amd as cm
 cm._capi.LIB_PATH = os.path.join(os.path.dirname(cm._capi.LIB_PATH), "libcmpc_hip_prof.so")
-names = ["geo+AB", "PB/PA/PpB/PpA+Pd", "Quu", "panel", "rhs", "Qss", "chol", "Wsolve", "store", "Pupdate",
+names = ["ph0 desc+rows+Pd", "ph1 G,T1", "ph2 Quu,panel,Qss", "ph3 fused chol+solve", "ph4 P update", "-", "-", "-", "-", "-",
          "residuals", "backward(total)", "fwd1", "steps+muaff", "delta", "fwd2", "steplen+costate", "update+conv"]
 cfg, P, X0 = cm.synthetic.config2_perturbed_com(256)
 s = cm.BatchSolver(cfg, 256)

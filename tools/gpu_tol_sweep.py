@@ -1,0 +1,23 @@
+"""Developer probe (GPU box): iterations and accuracy against the float64 oracle for several
+termination settings."""
+import os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import cmpc_amd as cm
+from tests import parity
+from oracle import oracle_lib as ol, problem_nlp
+B = 128
+for name, gen in (("cfg2", cm.synthetic.config2_perturbed_com), ("cfg3", cm.synthetic.config3_external_push)):
+    cfg, P, X0 = gen(B)
+    P32, X032 = P.astype(np.float32), X0.astype(np.float32)
+    oc = problem_nlp.oracle_cfg(cfg)
+    Xr, infr = ol.ref_solve_batch(oc, P32.astype(np.float64), X032.astype(np.float64), ol.ipm_opts(tol=1e-9, mu_min=1e-10), nthreads=16)
+    assert (infr[:, 5] == 0).all()
+    for tol, mumin, steptol in ((1e-6, 1e-7, 1e-5), (1e-6, 1e-7, 1e-4), (3e-6, 3e-7, 1e-4), (1e-5, 1e-6, 1e-4), (1e-5, 1e-6, 1e-3), (1e-6, 1e-7, 1e-3)):
+        s = cm.BatchSolver(cfg, B, tolerance=tol, mu_min=mumin, step_tolerance=steptol)
+        X, info, rc = s.solve_host(P32, X032)
+        e = [parity.errors(cfg.N, P32[b], X[b], Xr[b]) for b in range(B)]
+        print(name, "tol %.0e mu_min %.0e step_tol %.0e" % (tol, mumin, steptol), "iters mean %.1f max %d bad %d" % (info[:, 0].mean(), info[:, 0].max(), (info[:, 5] != 0).sum()),
+              "| max err com %.1e force0 %.1e pos %.1e" % (max(x["com"] for x in e), max(x["force0"] for x in e), max(x["pos"] for x in e)))
+        s.close()
