@@ -45,6 +45,7 @@ namespace {
 #ifdef CMPC_PROFILE
 // diagnostic build only: per-phase shader-clock sums of workgroup 0
 __device__ long long g_prof[32];
+__device__ float g_trace[64 * 8];  // per iteration of workgroup 0: mu, ep, ec, step, ap, ad, sigma, mu_t
 #define PROF_DECL long long pt_ = __builtin_amdgcn_s_memtime()
 #define PROF(slot) do { long long n_ = __builtin_amdgcn_s_memtime(); if (threadIdx.x == 0 && blockIdx.x == 0) g_prof[slot] += n_ - pt_; pt_ = n_; } while (0)
 #else
@@ -1083,12 +1084,31 @@ __global__ __launch_bounds__(NT) void cmpc_solve_kernel(CmpcParams kp)
         // (e.g. the internal force along the line joining the feet) are kept quiet by the Levenberg
         // shift `reg`.  The stationarity residual of a float32-stored iterate cannot go below ~1e-3
         // (one ulp of com_z moves its gradient by 2 w_z^2 ulp ~ 5e-3), so it is not the test. ----
+        // The step is measured on what the cost and the dynamics see: the states, the deviation of
+        // each corner force from its foot's mean, the force rate, the landing offsets.  A constant
+        // internal force along the line joining two stance feet changes none of them (the NLP does
+        // not determine it; it only drifts slowly towards the barrier's analytic centre).
         float l_st = 0.f;
         for (int e = tid; e < NS * (N + 1); e += NT) l_st = fmaxf(l_st, fabsf(c.dS[e]));
-        for (int e = tid; e < NU * N; e += NT) l_st = fmaxf(l_st, fabsf(c.dU[e]));
+        for (int e = tid; e < NU * N; e += NT) {
+            const int k = e / NU, m = e % NU;
+            const float du = c.dU[e];
+            if (m < NF) {
+                const float* f = c.dU + NU * k + 12 * (m / 12) + m % 3;
+                const float mean = 0.25f * (f[0] + f[3] + f[6] + f[9]);
+                l_st = fmaxf(l_st, fabsf(du - gam_of(c, m / 12, k) * mean));
+                if (k > 0) l_st = fmaxf(l_st, fabsf(du - c.dU[e - NU]));
+            } else l_st = fmaxf(l_st, fabsf(du));
+        }
         const float step = ap * block_max<NT>(l_st, c.red, tid);
         step_out = step;
         err = fmaxf(ep, ec);
+#ifdef CMPC_PROFILE
+        if (tid == 0 && b == 0 && it < 64) {
+            float* tr = g_trace + 8 * it;
+            tr[0] = mu_cur; tr[1] = ep; tr[2] = ec; tr[3] = step; tr[4] = ap; tr[5] = ad; tr[6] = sigma; tr[7] = mu_t;
+        }
+#endif
         PROF(17);
         if (err <= prm.tol && step <= prm.step_tol) {
             status = 0;
@@ -1144,6 +1164,7 @@ extern "C" int cmpc_profile_read(long long* out, int reset)
     if (reset) { long long z[32] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof(z)); }
     return (int)e;
 }
+extern "C" int cmpc_trace_read(float* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_trace), sizeof(float) * 64 * 8); }
 #endif
 
 extern "C" int cmpc_launch_solver(const CmpcParams* prm, size_t lds_bytes, hipStream_t stream)

@@ -52,6 +52,7 @@ class BatchSolver:
         self.cfg = cfg
         self.layout = Layout(cfg.N)
         self.batch = batch
+        self._device_index = device
         self._lib = _capi.lib()
         self._ccfg = _c_config(cfg, **opts)
         h = C.c_void_p()
@@ -59,6 +60,7 @@ class BatchSolver:
         if rc != 0:
             raise RuntimeError(f"cmpc_create failed ({rc}): {self._lib.cmpc_last_error(None).decode()}")
         self._h = h
+        self._stream = None  # torch.cuda.Stream the kernels are launched on (created lazily)
 
     def close(self):
         if getattr(self, "_h", None):
@@ -83,11 +85,29 @@ class BatchSolver:
         if dInfo is None:
             dInfo = torch.empty((self.batch, _capi.INFO), dtype=torch.float32, device=dP.device)
         if stream is None:
-            stream = torch.cuda.current_stream(dP.device).cuda_stream
+            # a side stream of our own, ordered after torch's current stream and joined back into it:
+            # (the default stream's handle is 0, which the C ABI reads as "the handle's stream")
+            if self._stream is None:
+                self._stream = torch.cuda.Stream(dP.device)
+            cur = torch.cuda.current_stream(dP.device)
+            self._stream.wait_stream(cur)
+            stream = self._stream.cuda_stream
+        else:
+            cur = None
         rc = self._lib.cmpc_solve_device(self._h, dP.data_ptr(), dX0.data_ptr(), dX.data_ptr(), dInfo.data_ptr(), stream)
         if rc != 0:
             raise RuntimeError(f"cmpc_solve_device failed ({rc}): {self.last_error}")
+        if cur is not None:
+            cur.wait_stream(self._stream)
         return dX, dInfo
+
+    @property
+    def launch_stream(self):
+        """torch.cuda.Stream the solve kernel runs on (record timing events here)."""
+        import torch
+        if self._stream is None:
+            self._stream = torch.cuda.Stream(torch.device("cuda", self._device_index))
+        return self._stream
 
     def solve_host(self, P: np.ndarray, X0: np.ndarray):
         """numpy float32 in/out through the PCIe-inclusive entry point.  Returns (X, info, rc)."""

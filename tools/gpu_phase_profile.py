@@ -19,3 +19,10 @@ tot = v[10:].sum()
 print("iters block0", info[0, 0], "total cycles (sum of phases) %.3g" % tot, "kernel cycles %.3g" % info[0, 6])
 for n, x in zip(names, v):
     print("%-22s %12.0f  %5.1f%%  per stage-iter %8.0f" % (n, x, 100 * x / tot, x / (info[0, 0] * cfg.N)))
+
+tr = (C.c_float * 512)()
+cm._capi.lib().cmpc_trace_read(tr)
+tr = np.array(tr[:]).reshape(64, 8)
+print("iteration trace of problem 0:  mu_cur      ep       ec(max tz)  step     ap    ad    sigma    mu_t")
+for i in range(int(info[0, 0])):
+    print("  it %2d  %.2e %.2e %.2e %.2e %.3f %.3f %.2e %.2e" % ((i,) + tuple(tr[i])))
