@@ -120,6 +120,14 @@ def main():
     if rank == 0:
         total = world * B * args.steps
         iters = info[:, 0]
+        traffic = None   # HBM bytes per launch from the committed PMC passes (profiles/), same command
+        try:
+            import glob
+            pm = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))
+            if pm and args.workload == "config2" and B == 256:
+                traffic = json.load(open(pm[-1]))["hbm_bytes_per_launch"]
+        except Exception:
+            traffic = None
         flop_per_launch = float(iters.sum()) * F_ITER_PER_STAGE * cfg.N
         achieved = flop_per_launch / (kern_ms.mean() * 1e-3) / 1e12
         out = {
@@ -136,7 +144,7 @@ def main():
             "iterations_mean": round(float(iters.mean()), 2), "iterations_max": int(iters.max()),
             "converged_fraction": round(float((info[:, 5] == 0).mean()), 4),
             "roofline": {"bound": "mfma", "achieved": round(achieved, 4), "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_F32_TFLOPS, 5), "traffic": None,
+                         "frac": round(achieved / PEAK_F32_TFLOPS, 5), "traffic": traffic,
                          "kernel": "cmpc_solve_kernel", "kernel_ms_avg": round(float(kern_ms.mean()), 4),
                          "algorithmic_flop_per_launch": flop_per_launch,
                          "note": "f32 vector peak == f32-input MFMA peak (157.3 TFLOP/s); flop = executed IP iterations x "

@@ -60,6 +60,35 @@ struct CmpcConsts {
     float wz2[CMPC_NMAX + 1];    // 2 w_z(k)^2, w_z(k) = (w_cz/2)(1+exp(-k))
 };
 
+// The same layout as closed-form index functions.  Device code uses these: indexing the offset arrays
+// of CmpcLayout with a run-time contact/corner number forces the whole struct into scratch memory
+// (private arrays cannot be register-indexed), which turns every LDS access into a scratch load first.
+struct CmpcIdx {
+    int N;
+    __host__ __device__ int pR(int c) const { return c * (19 * N + 6); }
+    __host__ __device__ int pUp(int c) const { return pR(c) + 9 * N; }
+    __host__ __device__ int pLo(int c) const { return pR(c) + 12 * N; }
+    __host__ __device__ int pGam(int c) const { return pR(c) + 15 * N; }
+    __host__ __device__ int pNom(int c) const { return pR(c) + 16 * N; }
+    __host__ __device__ int pCur(int c) const { return pR(c) + 19 * N + 3; }
+    __host__ __device__ int pCom0() const { return 2 * (19 * N + 6); }
+    __host__ __device__ int pDcom0() const { return pCom0() + 3; }
+    __host__ __device__ int pH0() const { return pCom0() + 6; }
+    __host__ __device__ int pComref() const { return pCom0() + 9; }
+    __host__ __device__ int pHref() const { return pComref() + 3 * (N + 1); }
+    __host__ __device__ int pFext() const { return pHref() + 3 * (N + 1); }
+    __host__ __device__ int pText() const { return pFext() + 3 * N; }
+    __host__ __device__ int np() const { return pText() + 3 * N; }
+    __host__ __device__ int oCom() const { return 0; }
+    __host__ __device__ int oDcom() const { return 3 * (N + 1); }
+    __host__ __device__ int oH() const { return 6 * (N + 1); }
+    __host__ __device__ int oPos(int c) const { return 9 * (N + 1) + c * (18 * N + 3); }
+    __host__ __device__ int oVel(int c) const { return oPos(c) + 3 * (N + 1); }
+    __host__ __device__ int oF(int c, int j) const { return oVel(c) + 3 * N + j * 3 * N; }
+    __host__ __device__ int nx() const { return 45 * N + 15; }
+    __host__ __device__ int ng() const { return 53 * N + 15; }
+};
+
 // kernel parameters (passed by value)
 struct CmpcParams {
     const CmpcConsts* kc;        // device memory

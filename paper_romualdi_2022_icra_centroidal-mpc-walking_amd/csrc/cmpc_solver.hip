@@ -54,13 +54,13 @@ __device__ float g_trace[64 * 8];  // per iteration of workgroup 0: mu, ep, ec, 
 #endif
 
 struct Ctx {
-    CmpcLayout L;
+    CmpcIdx L;
     int N;
     const float* sp;     // parameter vector in LDS
     float *S, *U, *T, *Z;
     double* LAM;
     float *dS, *dU, *dT, *dZ, *d;
-    float *Lf, *Ws, *lqs;  // factors
+    float *Lf, *Ws, *lqs;  // per-stage factors: L^{-1} (packed lower), Ws = L^{-1} Qus, lq = L^{-1} qu
     float *geoA;           // N x GEO
     float *P0, *P1, *G, *T1, *QuuF, *Pan, *Bval, *Aval, *arow, *ybuf, *fpv, *fpn;
     int *Brow, *Arow;
@@ -72,24 +72,24 @@ struct Ctx {
 
 __device__ inline void wave_lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
-__device__ inline float gam_of(const Ctx& c, int ct, int k) { return c.sp[c.L.p_gam[ct] + k]; }
+__device__ inline float gam_of(const Ctx& c, int ct, int k) { return c.sp[c.L.pGam(ct) + k]; }
 // reference stores vec(R) column-major: R(r,cc) = R[3*cc + r]
 __device__ inline float Rm(const float* R, int r, int cc) { return R[3 * cc + r]; }
 
 __device__ inline bool qfree(const Ctx& c, int k, int m)
 {
     const int ct = m / 3, i = m % 3;
-    const float lo = c.sp[c.L.p_lo[ct] + 3 * k + i], hi = c.sp[c.L.p_up[ct] + 3 * k + i];
+    const float lo = c.sp[c.L.pLo(ct) + 3 * k + i], hi = c.sp[c.L.pUp(ct) + 3 * k + i];
     return gam_of(c, ct, k) < 0.5f && (hi - lo) > 1e-9f;
 }
-__device__ inline float qlo(const Ctx& c, int k, int m) { return c.sp[c.L.p_lo[m / 3] + 3 * k + m % 3]; }
-__device__ inline float qhi(const Ctx& c, int k, int m) { return c.sp[c.L.p_up[m / 3] + 3 * k + m % 3]; }
+__device__ inline float qlo(const Ctx& c, int k, int m) { return c.sp[c.L.pLo(m / 3) + 3 * k + m % 3]; }
+__device__ inline float qhi(const Ctx& c, int k, int m) { return c.sp[c.L.pUp(m / 3) + 3 * k + m % 3]; }
 
 // friction row i (0..31) of stage k: a = R (sx, sy, -mu)^T, acting on corner i/4
 __device__ inline void fric_row(const Ctx& c, const CmpcConsts& prm, int k, int i, float& a0, float& a1, float& a2)
 {
     const int ct = i >> 4, face = i & 3;
-    const float* R = c.sp + c.L.p_R[ct] + 9 * k;
+    const float* R = c.sp + c.L.pR(ct) + 9 * k;
     const float sx = (face == 0 || face == 3) ? 1.f : -1.f;
     const float sy = (face < 2) ? 1.f : -1.f;
     a0 = sx * Rm(R, 0, 0) + sy * Rm(R, 0, 1) - prm.mu_fr * Rm(R, 0, 2);
@@ -137,11 +137,11 @@ __device__ inline float qdiag(const CmpcConsts& prm, int k, int i)
 __device__ inline double grad_track(const Ctx& c, const CmpcConsts& prm, int k, int i)
 {
     const float* s = c.S + NS * k;
-    if (i < 3) return (double)qdiag(prm, k, i) * ((double)s[i] - (double)c.sp[c.L.p_comref + 3 * k + i]);
+    if (i < 3) return (double)qdiag(prm, k, i) * ((double)s[i] - (double)c.sp[c.L.pComref() + 3 * k + i]);
     if (i < 6) return 0.0;
-    if (i < 9) return 2.0 * prm.w_h * ((double)s[i] - (double)c.sp[c.L.p_href + 3 * k + i - 6]);
+    if (i < 9) return 2.0 * prm.w_h * ((double)s[i] - (double)c.sp[c.L.pHref() + 3 * k + i - 6]);
     const int ct = (i - 9) / 3, a = (i - 9) % 3;
-    return 2.0 * prm.w_pos * ((double)s[i] - (double)c.sp[c.L.p_nom[ct] + 3 * k + a]);
+    return 2.0 * prm.w_pos * ((double)s[i] - (double)c.sp[c.L.pNom(ct) + 3 * k + a]);
 }
 
 // gradient of the force-symmetry cost w.r.t. force component m (0..23) of stage k
@@ -197,7 +197,7 @@ __device__ inline void all_geo(const Ctx& c, const CmpcConsts& prm, int tid)
         float v;
         if (t < 24) {
             const int ct = t / 12, j = (t % 12) / 3, i = t % 3;
-            const float* R = c.sp + c.L.p_R[ct] + 9 * k;
+            const float* R = c.sp + c.L.pR(ct) + 9 * k;
             const float* cn = prm.corners + 12 * ct + 3 * j;
             v = Rm(R, i, 0) * cn[0] + Rm(R, i, 1) * cn[1] + Rm(R, i, 2) * cn[2] + s[9 + 3 * ct + i] - s[i];
         } else if (t < 30) {
@@ -223,7 +223,7 @@ __device__ inline double defect(const Ctx& c, const CmpcConsts& prm, int k, int 
     if (i < 3) return (double)s[i] + dt * (double)s[3 + i] - (double)sn[i];
     if (i < 6) {
         const int a = i - 3;
-        double acc = (double)c.sp[c.L.p_fext + 3 * k + a] - (a == 2 ? (double)prm.grav : 0.0);
+        double acc = (double)c.sp[c.L.pFext() + 3 * k + a] - (a == 2 ? (double)prm.grav : 0.0);
         for (int ct = 0; ct < 2; ++ct) {
             const float* f = u + 12 * ct;
             acc += (double)gam_of(c, ct, k) * ((double)f[a] + (double)f[3 + a] + (double)f[6 + a] + (double)f[9 + a]);
@@ -232,9 +232,9 @@ __device__ inline double defect(const Ctx& c, const CmpcConsts& prm, int k, int 
     }
     if (i < 9) {
         const int a = i - 6, a1 = (a + 1) % 3, a2 = (a + 2) % 3;
-        double tor = (double)c.sp[c.L.p_text + 3 * k + a];
+        double tor = (double)c.sp[c.L.pText() + 3 * k + a];
         for (int ct = 0; ct < 2; ++ct) {
-            const float* R = c.sp + c.L.p_R[ct] + 9 * k;
+            const float* R = c.sp + c.L.pR(ct) + 9 * k;
             const double gam = gam_of(c, ct, k);
             double t = 0.0;
             for (int j = 0; j < 4; ++j) {
@@ -252,9 +252,9 @@ __device__ inline double defect(const Ctx& c, const CmpcConsts& prm, int k, int 
     }
     {
         const int ct = (i - 9) / 3, a = (i - 9) % 3;
-        const float* R = c.sp + c.L.p_R[ct] + 9 * k;
+        const float* R = c.sp + c.L.pR(ct) + 9 * k;
         const double gam = gam_of(c, ct, k);
-        double land = (double)c.sp[c.L.p_nom[ct] + 3 * (k + 1) + a];
+        double land = (double)c.sp[c.L.pNom(ct) + 3 * (k + 1) + a];
         for (int m = 0; m < 3; ++m) land += (double)Rm(R, a, m) * (double)u[24 + 3 * ct + m];
         return gam * (double)s[i] + (1.0 - gam) * land - (double)sn[i];
     }
@@ -273,7 +273,7 @@ __device__ inline T Bt_vec(const Ctx& c, const CmpcConsts& prm, int k, int m, co
     }
     const int q = m - 24, ct = q / 3, a = q % 3;
     if (!qfree(c, k, q)) return (T)0;
-    const float* R = c.sp + c.L.p_R[ct] + 9 * k;
+    const float* R = c.sp + c.L.pR(ct) + 9 * k;
     const T g1 = (T)1 - (T)gam_of(c, ct, k);
     return g1 * ((T)Rm(R, 0, a) * v[9 + 3 * ct] + (T)Rm(R, 1, a) * v[10 + 3 * ct] + (T)Rm(R, 2, a) * v[11 + 3 * ct]);
 }
@@ -330,7 +330,7 @@ __device__ inline float AB_step(const Ctx& c, const CmpcConsts& prm, int k, int 
         return ds[i] + dt * tor;
     }
     const int ct = (i - 9) / 3, a = (i - 9) % 3;
-    const float* R = c.sp + c.L.p_R[ct] + 9 * k;
+    const float* R = c.sp + c.L.pR(ct) + 9 * k;
     const float gam = gam_of(c, ct, k);
     float land = 0.f;
 #pragma unroll
@@ -354,29 +354,33 @@ __device__ inline double readlane_d(double x, int lane)
 // block in dd[], float64).  Lanes >= 30: a row of the panel [Qus | I | qu]^T (30 floats).
 // On exit v[] holds the row of L (lanes < 30) or of (L^{-1} [Qus | I | qu])^T.  Returns true if a
 // pivot was not positive (uniform across the wave).
-__device__ inline bool chol_solve_fused(float (&v)[NU], double (&dd)[3], int lane)
+__device__ inline bool chol_solve_fused(float (&v)[NU], double (&dd)[3], int lane, int fixedmask)
 {
     bool bad = false;
     const int myblk = lane / 3;
 #pragma unroll
     for (int j = 0; j < NU; ++j) {
         const int b = j / 3, jm = j % 3;
+        if (j >= NF && ((fixedmask >> (j - NF)) & 1)) continue;  // identity row/column (fixed q): nothing to do
         double piv = readlane_d(dd[jm], j);
         if (!(piv > 0.0)) { bad = true; piv = 1.0; }
         double rinv = (double)rsqrtf((float)piv);
-        rinv = rinv * (1.5 - 0.5 * piv * rinv * rinv);
-        rinv = rinv * (1.5 - 0.5 * piv * rinv * rinv);
+        rinv = rinv * (1.5 - 0.5 * piv * rinv * rinv);  // one Newton step in float64: ~1e-14 relative
         const float rinvf = (float)rinv;
         const bool inblk = (myblk == b);
         const double ld = inblk ? dd[jm] * rinv : (double)(v[j] * rinvf);
         const float lf = (float)ld;
         v[j] = lf;
-        // own diagonal block (float64): entries (lane, 3*myblk + m)
+        // own 3x3 diagonal block (float64).  Rows of the pivot's block need their partners' column entries in
+        // float64 (two compile-time lanes: v_readlane); rows of later blocks take float partners by ds_bpermute.
+        const double dA = jm < 2 ? readlane_d(ld, j + 1 < NU ? j + 1 : j) : 0.0;
+        const double dB = jm < 1 ? readlane_d(ld, j + 2 < NU ? j + 2 : j) : 0.0;
 #pragma unroll
         for (int m = 0; m < 3; ++m) {
             const int src = 3 * myblk + m;
-            const double other = __shfl(ld, src & 63);
-            if (src > j && src <= lane) dd[m] -= ld * other;
+            const float of = __shfl(lf, src & 63);
+            const double od = inblk ? ((3 * b + m) == j + 1 ? dA : dB) : (double)of;
+            if (src > j && src <= lane) dd[m] -= ld * od;
         }
         // everything else (float32): v[c] -= l_ij * l_cj
 #pragma unroll
@@ -388,7 +392,7 @@ __device__ inline bool chol_solve_fused(float (&v)[NU], double (&dd)[3], int lan
 // phase 3 of a backward stage, kept out of line so that its ~40 VGPRs of matrix rows and its
 // stream of v_readlane broadcasts get a register allocation of their own
 __device__ inline void stage_factor(const float* QuuF, const double* QuuD, float* Pan, float* Lf, float* Ws, float* lq,
-                                          float D0, float D1, float D2, int* flag, int tid)
+                                          float D0, float D1, float D2, int* flag, int tid, int fixedmask)
 {
     const int lane = tid & 63, wv = tid >> 6;
     const int prow = lane - 30 + 34 * wv;  // panel row of lanes >= 30
@@ -412,7 +416,7 @@ __device__ inline void stage_factor(const float* QuuF, const double* QuuD, float
             dd[2] = QuuD[9 * (lane / 3) + 3 * (lane % 3) + 2];
         }
     }
-    const bool bad = chol_solve_fused(v, dd, lane);
+    const bool bad = chol_solve_fused(v, dd, lane, fixedmask);
     if (bad && tid == 0) *flag = 1;
     if (!isL && active) {
         if (prow < NS) {
@@ -468,7 +472,7 @@ __device__ int riccati_backward(const Ctx& c, const CmpcConsts& prm, int tid, bo
                 r2 = 6 + a2; v2 = -g * r[a1];
             } else {
                 const int q = tid - 24, ct = q / 3, m = q % 3;
-                const float* R = c.sp + c.L.p_R[ct] + 9 * k;
+                const float* R = c.sp + c.L.pR(ct) + 9 * k;
                 const float g1 = qfree(c, k, q) ? 1.f - gam_of(c, ct, k) : 0.f;
                 r0 = 9 + 3 * ct; r1 = r0 + 1; r2 = r0 + 2;
                 v0 = g1 * Rm(R, 0, m); v1 = g1 * Rm(R, 1, m); v2 = g1 * Rm(R, 2, m);
@@ -510,6 +514,15 @@ __device__ int riccati_backward(const Ctx& c, const CmpcConsts& prm, int tid, bo
                 fric_row(c, prm, k, i, a0, a1, a2);
                 c.arow[3 * i] = a0; c.arow[3 * i + 1] = a1; c.arow[3 * i + 2] = a2;
             }
+        } else if (tid >= 112 && tid < 121) {
+            // exact-Hessian block dt [lam_h]x (zero for the Gauss-Newton Hessian), row-major 3x3
+            const int a = (tid - 112) / 3, b = (tid - 112) % 3;
+            float sv = 0.f;
+            if (use_exact && a != b) {
+                const float lv = (float)c.LAM[NS * (k + 1) + 6 + (3 - a - b)];
+                sv = prm.dt * (((b - a + 3) % 3 == 1) ? -lv : lv);
+            }
+            c.arow[96 + tid - 112] = sv;
         } else if (tid >= 128 && tid < 128 + NXA) {
             // Pd = P [d; 0] + pv  (float64)
             const int r = tid - 128;
@@ -522,52 +535,68 @@ __device__ int riccati_backward(const Ctx& c, const CmpcConsts& prm, int tid, bo
         }
         __syncthreads();
         PROF(0);
-        // ---- phase 1: G = P [B;E] (39 x 30), T1 = Pss A (15 x 15) ----
+        // ---- phase 1: G = P [B;E] (39 x 30), T1 = Pss A (15 x 15): thread <-> column, its three non-zeros in
+        // registers, rows strided over 8 (G) / all 15 (T1) ----
         {
             const int nrow = havep ? NXA : NS;
-            for (int e = tid; e < nrow * NU + NS * NS; e += NT) {
-                if (e < nrow * NU) {
-                    const int r = e / NU, i = e % NU;
-                    float v = Pcur[r * PLD + c.Brow[3 * i]] * c.Bval[3 * i] + Pcur[r * PLD + c.Brow[3 * i + 1]] * c.Bval[3 * i + 1]
-                              + Pcur[r * PLD + c.Brow[3 * i + 2]] * c.Bval[3 * i + 2];
-                    if (havep && i < NF) v += Pcur[r * PLD + NS + i];
-                    c.G[r * GLD + i] = v;
-                } else {
-                    const int e2 = e - nrow * NU, i = e2 / NS, j = e2 % NS;
-                    c.T1[e2] = Pcur[i * PLD + c.Arow[3 * j]] * c.Aval[3 * j] + Pcur[i * PLD + c.Arow[3 * j + 1]] * c.Aval[3 * j + 1]
-                               + Pcur[i * PLD + c.Arow[3 * j + 2]] * c.Aval[3 * j + 2];
+            if (tid < 8 * NU) {
+                const int i = tid % NU, r0 = tid / NU;
+                const int b0 = c.Brow[3 * i], b1 = c.Brow[3 * i + 1], b2 = c.Brow[3 * i + 2];
+                const float w0 = c.Bval[3 * i], w1 = c.Bval[3 * i + 1], w2 = c.Bval[3 * i + 2];
+                const bool addp = havep && i < NF;
+#pragma unroll
+                for (int rr = 0; rr < 5; ++rr) {
+                    const int r = r0 + 8 * rr;
+                    if (r < nrow) {
+                        const float* Pr = Pcur + r * PLD;
+                        float v = Pr[b0] * w0 + Pr[b1] * w1 + Pr[b2] * w2;
+                        if (addp) v += Pr[NS + i];
+                        c.G[r * GLD + i] = v;
+                    }
                 }
+            }
+            if (tid < NS * NS) {
+                const int i = tid / NS, j = tid % NS;
+                const float* Pr = Pcur + i * PLD;
+                c.T1[tid] = Pr[c.Arow[3 * j]] * c.Aval[3 * j] + Pr[c.Arow[3 * j + 1]] * c.Aval[3 * j + 1] + Pr[c.Arow[3 * j + 2]] * c.Aval[3 * j + 2];
             }
         }
         __syncthreads();
         PROF(1);
-        // ---- phase 2: Quu (lower; diag 3x3 blocks also in float64), panel [Qus | I | qu]^T, Qss, qs ----
-        for (int e = tid; e < NU * NU; e += NT) {
-            const int i = e / NU, j = e % NU;
-            if (j > i) continue;
-            double v = 0.0;
-            if (i < NF) {  // then j < NF too
-                const int ci = i / 12, cj = j / 12;
-                if (ci == cj && (i % 3) == (j % 3)) {
-                    const double gam = gam_of(c, ci, k);
-                    v = 2.0 * prm.w_sym * ((i == j ? 1.0 : 0.0) - 0.25 * gam * (2.0 - gam));
-                }
-                if (i / 3 == j / 3) {  // same corner: friction barrier
+        // ---- phase 2: Quu (lower triangle; float, its 3x3 diagonal blocks in float64), panel [Qus | I | qu]^T,
+        // Qss, qs ----
+        for (int e = tid; e < LP; e += NT) {
+            const unsigned short ij = c.tri[e];
+            const int i = ij >> 8, j = ij & 255;
+            const int b0 = c.Brow[3 * i], b1 = c.Brow[3 * i + 1], b2 = c.Brow[3 * i + 2];
+            // [B;E]^T P [B;E]
+            float vf = c.Bval[3 * i] * c.G[b0 * GLD + j] + c.Bval[3 * i + 1] * c.G[b1 * GLD + j] + c.Bval[3 * i + 2] * c.G[b2 * GLD + j];
+            if (havep && i < NF) vf += c.G[(NS + i) * GLD + j];
+            if (i / 3 == j / 3) {  // diagonal block: cost + barrier terms in float64
+                double v = (double)vf;
+                if (i < NF) {
+                    if ((i % 3) == (j % 3)) {  // same corner, same axis => i == j here
+                        const double gam = gam_of(c, i / 12, k);
+                        v += 2.0 * prm.w_sym * (1.0 - 0.25 * gam * (2.0 - gam));
+                        if (pk) v += (double)prm.D[i % 3];
+                    }
                     const int r0 = 4 * (i / 3);
 #pragma unroll
                     for (int f = 0; f < 4; ++f)
                         v += c.sig[r0 + f] * (double)c.arow[3 * (r0 + f) + i % 3] * (double)c.arow[3 * (r0 + f) + j % 3];
+                    if (i == j) v += (double)reg;
+                } else if (i == j) {
+                    const bool fr = qfree(c, k, i - 24);
+                    v = fr ? v + c.sig[32 + i - 24] + c.sig[38 + i - 24] + (double)reg : 1.0;  // fixed q: exact identity row
                 }
-                if (i == j && pk) v += (double)prm.D[i % 3];
-            } else if (i == j) {
-                v = qfree(c, k, i - 24) ? c.sig[32 + i - 24] + c.sig[38 + i - 24] : 1.0;
+                c.QuuD[9 * (i / 3) + 3 * (i % 3) + j % 3] = v;
+                vf = (float)v;
+            } else if (i < NF && (i / 12) == (j / 12) && (i % 3) == (j % 3)) {
+                // another corner of the same foot, same axis: symmetry-cost coupling
+                const float gam = gam_of(c, i / 12, k);
+                vf -= 2.f * prm.w_sym * 0.25f * gam * (2.f - gam);
             }
-            if (i == j) v += (double)reg;
-            v += (double)c.Bval[3 * i] * (double)c.G[c.Brow[3 * i] * GLD + j] + (double)c.Bval[3 * i + 1] * (double)c.G[c.Brow[3 * i + 1] * GLD + j]
-                 + (double)c.Bval[3 * i + 2] * (double)c.G[c.Brow[3 * i + 2] * GLD + j];
-            if (havep && i < NF) v += (double)c.G[(NS + i) * GLD + j];
-            c.QuuF[i * RLD + j] = (float)v;
-            if (i / 3 == j / 3) c.QuuD[9 * (i / 3) + 3 * (i % 3) + j % 3] = v;
+            c.QuuF[i * RLD + j] = vf;
         }
         for (int e = tid; e < (NPAN - 1) * NU; e += NT) {
             const int r = e / NU, i = e % NU;  // panel row r (column of [Qus | I]), entry i
@@ -576,19 +605,12 @@ __device__ int riccati_backward(const Ctx& c, const CmpcConsts& prm, int tid, bo
                 const int j = r;
                 v = c.G[c.Arow[3 * j] * GLD + i] * c.Aval[3 * j] + c.G[c.Arow[3 * j + 1] * GLD + i] * c.Aval[3 * j + 1]
                     + c.G[c.Arow[3 * j + 2] * GLD + i] * c.Aval[3 * j + 2];
-                if (use_exact && i < NF) {
-                    // S[f_cj, pos_c] = dt gam [lam_h]x ; S[f_cj, com] = -dt gam [lam_h]x
+                if (i < NF) {
+                    // S[f_cj, pos_c] = gam Sx ; S[f_cj, com] = -gam Sx   (Sx = dt [lam_h]x, zero diagonal)
                     const int ct = i / 12, a = i % 3;
-                    int b = -1;
-                    float sgn = 0.f;
-                    if (j < 3) { b = j; sgn = -1.f; }
-                    else if (j >= 9 + 3 * ct && j < 12 + 3 * ct) { b = j - 9 - 3 * ct; sgn = 1.f; }
-                    if (b >= 0 && b != a) {
-                        const int o = 3 - a - b;
-                        const float lv = (float)c.LAM[NS * (k + 1) + 6 + o];
-                        const float sk = ((b - a + 3) % 3 == 1) ? -lv : lv;
-                        v += sgn * prm.dt * gam_of(c, ct, k) * sk;
-                    }
+                    const int b = j < 3 ? j : j - 9 - 3 * ct;
+                    const float sgn = j < 3 ? -1.f : ((b >= 0 && b < 3) ? 1.f : 0.f);
+                    v += sgn * gam_of(c, ct, k) * c.arow[96 + 3 * a + ((b >= 0 && b < 3) ? b : 0)];
                 }
             } else {
                 v = (r - NS == i) ? 1.f : 0.f;
@@ -624,33 +646,49 @@ __device__ int riccati_backward(const Ctx& c, const CmpcConsts& prm, int tid, bo
         __syncthreads();
         PROF(2);
         // ---- phase 3: fused Cholesky + panel solve (waves 0 and 1; each repeats the factorisation) ----
-        if (tid < 128)
+        if (tid < 128) {
+            int fixedmask = 0;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) fixedmask |= qfree(c, k, q) ? 0 : (1 << q);
             stage_factor(c.QuuF, c.QuuD, c.Pan, c.Lf + (size_t)LP * k, c.Ws + (size_t)(NU * NS) * k, c.lqs + NU * k,
-                         prm.D[0], prm.D[1], prm.D[2], c.flag, tid);
+                         prm.D[0], prm.D[1], prm.D[2], c.flag, tid, fixedmask);
+        }
         __syncthreads();
         PROF(3);
         if (*c.flag) return 1;
         // ---- phase 4: P = [Qss 0; 0 D] - W^T W  (rows of the panel are W^T rows; p rows pre-scaled by -D) ----
         {
-            const int ntri = pk ? NTRI : NS * (NS + 1) / 2;
-            for (int e = tid; e < ntri; e += NT) {
-                const unsigned short ij = c.tri[e];
-                const int i = ij >> 8, j = ij & 255;
-                const float4* ri = reinterpret_cast<const float4*>(c.Pan + i * RLD);
-                const float4* rj = reinterpret_cast<const float4*>(c.Pan + j * RLD);
-                float acc = 0.f;
+            // 2x2 output tiles: thread <-> tile (bi, bj), bj <= bi, of the 39x39 (or 15x15) lower triangle
+            const int nb = pk ? 20 : 8;
+            if (tid < nb * (nb + 1) / 2) {
+                const unsigned short t = c.tri[tid];
+                const int bi = t >> 8, bj = t & 255;
+                const int i0 = 2 * bi, j0 = 2 * bj, ncol = pk ? NXA : NS;
+                const float4* ri0 = reinterpret_cast<const float4*>(c.Pan + i0 * RLD);
+                const float4* ri1 = reinterpret_cast<const float4*>(c.Pan + (i0 + 1) * RLD);
+                const float4* rj0 = reinterpret_cast<const float4*>(c.Pan + j0 * RLD);
+                const float4* rj1 = reinterpret_cast<const float4*>(c.Pan + (j0 + 1) * RLD);
+                float a00 = 0.f, a01 = 0.f, a10 = 0.f, a11 = 0.f;
 #pragma unroll
                 for (int q4 = 0; q4 < 8; ++q4) {
-                    const float4 x = ri[q4], y = rj[q4];
-                    acc += x.x * y.x + x.y * y.y;
-                    if (q4 < 7) acc += x.z * y.z + x.w * y.w;  // columns 30, 31 are padding
+                    const float4 x0 = ri0[q4], x1 = ri1[q4], y0 = rj0[q4], y1 = rj1[q4];
+                    a00 += x0.x * y0.x + x0.y * y0.y; a01 += x0.x * y1.x + x0.y * y1.y;
+                    a10 += x1.x * y0.x + x1.y * y0.y; a11 += x1.x * y1.x + x1.y * y1.y;
+                    if (q4 < 7) {  // columns 30, 31 are padding
+                        a00 += x0.z * y0.z + x0.w * y0.w; a01 += x0.z * y1.z + x0.w * y1.w;
+                        a10 += x1.z * y0.z + x1.w * y0.w; a11 += x1.z * y1.z + x1.w * y1.w;
+                    }
                 }
-                float base = 0.f;
-                if (i < NS) base = Pnew[i * PLD + j];
-                else if (i == j) base = prm.D[(i - NS) % 3];
-                const float r = base - acc;
-                Pnew[i * PLD + j] = r;
-                Pnew[j * PLD + i] = r;
+                auto put = [&](int i, int j, float acc) {
+                    if (j > i || i >= ncol) return;
+                    float base = 0.f;
+                    if (i < NS) base = Pnew[i * PLD + j];
+                    else if (i == j) base = prm.D[(i - NS) % 3];
+                    const float r = base - acc;
+                    Pnew[i * PLD + j] = r;
+                    Pnew[j * PLD + i] = r;
+                };
+                put(i0, j0, a00); put(i0, j0 + 1, a01); put(i0 + 1, j0, a10); put(i0 + 1, j0 + 1, a11);
             }
             // gradient of the value function (float64)
             const int ncol = pk ? NXA : NS;
@@ -690,48 +728,60 @@ __device__ void riccati_forward(const Ctx& c, const CmpcConsts& prm, int tid, bo
 {
     const int N = c.N;
     if (tid < 64) {
-        float ymax = 0.f;
+        // two lanes per row (lane i and lane i+32 each sum half of the terms, then one __shfl_xor)
+        const int half = tid >> 5, i = (tid & 31) < NU ? (tid & 31) : 0;
+        const bool row = (tid & 31) < NU;
+        const float D0 = prm.D[0], D1 = prm.D[1], D2 = prm.D[2];
         if (tid < NS) c.dS[tid] = 0.f;
         wave_lds_sync();
         for (int k = 0; k < N; ++k) {
             const float* Lf = c.Lf + (size_t)LP * k;
             const float* Ws = c.Ws + (size_t)(NU * NS) * k;
-            if (tid < NU) {
-                const int i = tid;
-                float v = c.lqs[NU * k + i];
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+            if (half == 0) {  // lq + Ws ds
+                s0 = c.lqs[NU * k + i];
 #pragma unroll
-                for (int a = 0; a < NS; ++a) v += Ws[i * NS + a] * c.dS[NS * k + a];
-                if (k > 0) {  // Wp dp = -Linv[:, :24] D dp   (loads past the row end are masked, not skipped)
-                    const float* dp = c.dU + NU * (k - 1);
-                    const float* Li = Lf + lpk(i, 0);
-                    const float D0 = prm.D[0], D1 = prm.D[1], D2 = prm.D[2];
-#pragma unroll
-                    for (int a = 0; a < NF; ++a) {
-                        const float l = Li[a];
-                        v -= (a <= i ? l : 0.f) * (a % 3 == 0 ? D0 : (a % 3 == 1 ? D1 : D2)) * dp[a];
-                    }
+                for (int a = 0; a < NS; a += 3) {
+                    s0 += Ws[i * NS + a] * c.dS[NS * k + a];
+                    s1 += Ws[i * NS + a + 1] * c.dS[NS * k + a + 1];
+                    s2 += Ws[i * NS + a + 2] * c.dS[NS * k + a + 2];
                 }
-                c.ybuf[i] = -v;
-                ymax = fmaxf(ymax, fabsf(v));
+            } else if (k > 0) {  // Wp dp = -Linv[:, :24] D dp  (loads past the row end are masked, not skipped)
+                const float* dp = c.dU + NU * (k - 1);
+                const float* Li = Lf + lpk(i, 0);
+#pragma unroll
+                for (int a = 0; a < NF; a += 3) {
+                    const float l0 = Li[a], l1 = Li[a + 1], l2 = Li[a + 2];
+                    s0 -= (a <= i ? l0 : 0.f) * D0 * dp[a];
+                    s1 -= (a + 1 <= i ? l1 : 0.f) * D1 * dp[a + 1];
+                    s2 -= (a + 2 <= i ? l2 : 0.f) * D2 * dp[a + 2];
+                }
             }
+            float v = s0 + s1 + s2;
+            v += __shfl_xor(v, 32);
+            if (tid < NU) c.ybuf[tid] = -v;
             wave_lds_sync();
-            if (tid < NU) {  // du = Linv^T y
-                float v = 0.f;
+            {   // du = Linv^T y : half 0 sums a = 0..14, half 1 a = 15..29
+                float t0 = 0.f, t1 = 0.f, t2 = 0.f;
+                const int a0 = 15 * half;
 #pragma unroll
-                for (int a = 0; a < NU; ++a) {
-                    const float l = Lf[lpk(a, 0) + (tid <= a ? tid : 0)];
-                    v += (a >= tid ? l : 0.f) * c.ybuf[a];
+                for (int aa = 0; aa < 15; aa += 3) {
+                    const int a = a0 + aa;
+                    const float l0 = Lf[lpk(a, 0) + (i <= a ? i : 0)], l1 = Lf[lpk(a + 1, 0) + (i <= a + 1 ? i : 0)],
+                                l2 = Lf[lpk(a + 2, 0) + (i <= a + 2 ? i : 0)];
+                    t0 += (a >= i ? l0 : 0.f) * c.ybuf[a];
+                    t1 += (a + 1 >= i ? l1 : 0.f) * c.ybuf[a + 1];
+                    t2 += (a + 2 >= i ? l2 : 0.f) * c.ybuf[a + 2];
                 }
-                c.dU[NU * k + tid] = v;
+                float w = t0 + t1 + t2;
+                w += __shfl_xor(w, 32);
+                if (tid < NU) c.dU[NU * k + tid] = w;
             }
             wave_lds_sync();
             if (tid < NS) c.dS[NS * (k + 1) + tid] = AB_step(c, prm, k, tid, c.dS + NS * k, c.dU + NU * k) + c.d[NS * k + tid];
             wave_lds_sync();
+            (void)row;
         }
-        // curvature-weighted size of the step: y = L^T du, |y|^2 = du^T Quu du
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) ymax = fmaxf(ymax, __shfl_xor(ymax, o));
-        if (tid == 0) c.red[4] = ymax;
     }
     __syncthreads();
     for (int e = tid; e < N * NI; e += NT) {
@@ -782,34 +832,51 @@ __device__ void riccati_delta(const Ctx& c, const CmpcConsts& prm, int tid)
                 c.ybuf[tid] = g + Bt_vec<float>(c, prm, k, tid, c.fpv);
             }
             wave_lds_sync();
-            if (tid < NU) {  // dl = Linv dq
-                float v = 0.f;
-                const float* Li = Lf + lpk(tid, 0);
+            {   // dl = Linv dq : two lanes per row
+                const int half = tid >> 5, i = (tid & 31) < NU ? (tid & 31) : 0;
+                const float* Li = Lf + lpk(i, 0);
+                float t0 = 0.f, t1 = 0.f, t2 = 0.f;
+                const int a0 = 15 * half;
 #pragma unroll
-                for (int a = 0; a < NU; ++a) {
-                    const float l = Li[a <= tid ? a : 0];
-                    v += (a <= tid ? l : 0.f) * c.ybuf[a];
+                for (int aa = 0; aa < 15; aa += 3) {
+                    const int a = a0 + aa;
+                    const float l0 = Li[a <= i ? a : 0], l1 = Li[a + 1 <= i ? a + 1 : 0], l2 = Li[a + 2 <= i ? a + 2 : 0];
+                    t0 += (a <= i ? l0 : 0.f) * c.ybuf[a];
+                    t1 += (a + 1 <= i ? l1 : 0.f) * c.ybuf[a + 1];
+                    t2 += (a + 2 <= i ? l2 : 0.f) * c.ybuf[a + 2];
                 }
-                c.ybuf[32 + tid] = v;
-                c.lqs[NU * k + tid] += v;
+                float v = t0 + t1 + t2;
+                v += __shfl_xor(v, 32);
+                if (tid < NU) {
+                    c.ybuf[32 + tid] = v;
+                    c.lqs[NU * k + tid] += v;
+                }
             }
             wave_lds_sync();
             if (tid < NXA) {
                 float v;
                 const float* dl = c.ybuf + 32;
                 if (tid < NS) {
-                    v = At_vec<float>(c, prm, k, tid, c.fpv);
+                    float t0 = At_vec<float>(c, prm, k, tid, c.fpv), t1 = 0.f, t2 = 0.f;
 #pragma unroll
-                    for (int a = 0; a < NU; ++a) v -= Ws[a * NS + tid] * dl[a];
+                    for (int a = 0; a < NU; a += 3) {
+                        t0 -= Ws[a * NS + tid] * dl[a];
+                        t1 -= Ws[(a + 1) * NS + tid] * dl[a + 1];
+                        t2 -= Ws[(a + 2) * NS + tid] * dl[a + 2];
+                    }
+                    v = t0 + t1 + t2;
                 } else if (pk) {
                     const int m = tid - NS;
-                    v = 0.f;
+                    float t0 = 0.f, t1 = 0.f, t2 = 0.f;
 #pragma unroll
-                    for (int a = 0; a < NU; ++a) {
-                        const float l = Lf[lpk(a, 0) + (m <= a ? m : 0)];
-                        v += (a >= m ? l : 0.f) * dl[a];
+                    for (int a = 0; a < NU; a += 3) {
+                        const float l0 = Lf[lpk(a, 0) + (m <= a ? m : 0)], l1 = Lf[lpk(a + 1, 0) + (m <= a + 1 ? m : 0)],
+                                    l2 = Lf[lpk(a + 2, 0) + (m <= a + 2 ? m : 0)];
+                        t0 += (a >= m ? l0 : 0.f) * dl[a];
+                        t1 += (a + 1 >= m ? l1 : 0.f) * dl[a + 1];
+                        t2 += (a + 2 >= m ? l2 : 0.f) * dl[a + 2];
                     }
-                    v *= prm.D[m % 3];
+                    v = (t0 + t1 + t2) * prm.D[m % 3];
                 } else v = 0.f;
                 c.fpn[tid] = v;
             }
@@ -905,7 +972,7 @@ __global__ __launch_bounds__(NT) void cmpc_solve_kernel(CmpcParams kp)
     constexpr int KBYTES = (sizeof(CmpcConsts) + 15) & ~15;
     const long long t_start = __builtin_amdgcn_s_memtime();
     Ctx c;
-    cmpc_layout_init(c.L, N);
+    c.L.N = N;
     c.N = N;
     // ---- carve LDS: doubles first, then 16-byte aligned float panels ----
     double* dp = reinterpret_cast<double*>(smem + KBYTES);
@@ -916,7 +983,7 @@ __global__ __launch_bounds__(NT) void cmpc_solve_kernel(CmpcParams kp)
     float* fp = reinterpret_cast<float*>(dp);
     c.QuuF = fp; fp += NU * RLD;
     c.Pan = fp; fp += NPAN * RLD;
-    float* spw = fp; fp += (c.L.np + 3) & ~3;
+    float* spw = fp; fp += (c.L.np() + 3) & ~3;
     c.sp = spw;
     c.S = fp; fp += NS * (N + 1); c.U = fp; fp += NU * N; c.T = fp; fp += NI * N; c.Z = fp; fp += NI * N;
     c.dS = fp; fp += NS * (N + 1); c.dU = fp; fp += NU * N; c.dT = fp; fp += NI * N; c.dZ = fp; fp += NI * N;
@@ -926,7 +993,7 @@ __global__ __launch_bounds__(NT) void cmpc_solve_kernel(CmpcParams kp)
     c.P0 = fp; fp += NXA * PLD; c.P1 = fp; fp += NXA * PLD;
     c.G = fp; fp += NXA * GLD; c.T1 = fp; fp += NS * NS;
     c.Bval = fp; fp += 3 * NU; c.Aval = fp; fp += 3 * NS + 3;
-    c.arow = fp; fp += 96; c.ybuf = fp; fp += 64; c.fpv = fp; fp += 40; c.fpn = fp; fp += 40; c.red = fp; fp += 8;
+    c.arow = fp; fp += 96 + 12; c.ybuf = fp; fp += 64; c.fpv = fp; fp += 40; c.fpn = fp; fp += 40; c.red = fp; fp += 8;
     c.Brow = reinterpret_cast<int*>(fp); fp += 3 * NU;
     c.Arow = reinterpret_cast<int*>(fp); fp += 3 * NS + 3;
     c.flag = reinterpret_cast<int*>(fp); fp += 4;
@@ -950,35 +1017,35 @@ __global__ __launch_bounds__(NT) void cmpc_solve_kernel(CmpcParams kp)
     for (int e = tid; e < NU * RLD; e += NT) c.QuuF[e] = 0.f;
     if (tid < 90) c.QuuD[tid] = 0.0;
     {
-        const float* gp = kp.P + (size_t)b * c.L.np;
-        for (int e = tid; e < c.L.np; e += NT) spw[e] = gp[e];
+        const float* gp = kp.P + (size_t)b * c.L.np();
+        for (int e = tid; e < c.L.np(); e += NT) spw[e] = gp[e];
     }
     __syncthreads();
     // ---- initial iterate from x0 ----
     {
-        const float* x0 = kp.X0 + (size_t)b * c.L.nx;
+        const float* x0 = kp.X0 + (size_t)b * c.L.nx();
         for (int e = tid; e < NS * (N + 1); e += NT) {
             const int k = e / NS, i = e % NS;
             float v;
             if (k == 0) {  // initial-condition rows of g hold exactly
-                if (i < 9) v = c.sp[c.L.p_com0 + i];
-                else v = c.sp[c.L.p_cur[(i - 9) / 3] + (i - 9) % 3];
-            } else if (i < 9) v = x0[c.L.o_com + 3 * (N + 1) * (i / 3) + 3 * k + i % 3];
-            else v = x0[c.L.o_pos[(i - 9) / 3] + 3 * k + (i - 9) % 3];
+                if (i < 9) v = c.sp[c.L.pCom0() + i];
+                else v = c.sp[c.L.pCur((i - 9) / 3) + (i - 9) % 3];
+            } else if (i < 9) v = x0[c.L.oCom() + 3 * (N + 1) * (i / 3) + 3 * k + i % 3];
+            else v = x0[c.L.oPos((i - 9) / 3) + 3 * k + (i - 9) % 3];
             c.S[e] = v;
             c.LAM[e] = 0.0;
         }
         for (int e = tid; e < NU * N; e += NT) {
             const int k = e / NU, m = e % NU;
             float v = 0.f;
-            if (m < NF) v = x0[c.L.o_f[m / 12][(m % 12) / 3] + 3 * k + m % 3];
+            if (m < NF) v = x0[c.L.oF(m / 12, (m % 12) / 3) + 3 * k + m % 3];
             else {
                 const int q = m - 24, ct = q / 3, i = q % 3;
                 if (qfree(c, k, q)) {
-                    const float* R = c.sp + c.L.p_R[ct] + 9 * k;
+                    const float* R = c.sp + c.L.pR(ct) + 9 * k;
                     const float lo = qlo(c, k, q), hi = qhi(c, k, q), push = 0.01f * (hi - lo);
                     for (int a = 0; a < 3; ++a)
-                        v += Rm(R, a, i) * (x0[c.L.o_pos[ct] + 3 * (k + 1) + a] - c.sp[c.L.p_nom[ct] + 3 * (k + 1) + a]);
+                        v += Rm(R, a, i) * (x0[c.L.oPos(ct) + 3 * (k + 1) + a] - c.sp[c.L.pNom(ct) + 3 * (k + 1) + a]);
                     v = fminf(fmaxf(v, lo + push), hi - push);
                 } else if (gam_of(c, ct, k) < 0.5f) v = qlo(c, k, q);
             }
@@ -1118,19 +1185,19 @@ __global__ __launch_bounds__(NT) void cmpc_solve_kernel(CmpcParams kp)
     }
     // ---- export x in the reference layout ----
     {
-        float* x = kp.X + (size_t)b * c.L.nx;
+        float* x = kp.X + (size_t)b * c.L.nx();
         for (int e = tid; e < NS * (N + 1); e += NT) {
             const int k = e / NS, i = e % NS;
-            if (i < 9) x[c.L.o_com + 3 * (N + 1) * (i / 3) + 3 * k + i % 3] = c.S[e];
-            else x[c.L.o_pos[(i - 9) / 3] + 3 * k + (i - 9) % 3] = c.S[e];
+            if (i < 9) x[c.L.oCom() + 3 * (N + 1) * (i / 3) + 3 * k + i % 3] = c.S[e];
+            else x[c.L.oPos((i - 9) / 3) + 3 * k + (i - 9) % 3] = c.S[e];
         }
         for (int e = tid; e < NU * N; e += NT) {
             const int k = e / NU, m = e % NU;
-            if (m < NF) x[c.L.o_f[m / 12][(m % 12) / 3] + 3 * k + m % 3] = c.U[e];
+            if (m < NF) x[c.L.oF(m / 12, (m % 12) / 3) + 3 * k + m % 3] = c.U[e];
             else {
                 const int q = m - 24, ct = q / 3, i = q % 3;
                 const float v = gam_of(c, ct, k) < 0.5f ? (c.S[NS * (k + 1) + 9 + q] - c.S[NS * k + 9 + q]) / prm.dt : 0.f;
-                x[c.L.o_vel[ct] + 3 * k + i] = v;
+                x[c.L.oVel(ct) + 3 * k + i] = v;
             }
         }
         if (kp.info && tid == 0) {
@@ -1152,7 +1219,7 @@ extern "C" size_t cmpc_solver_lds_bytes(int N, int factors_global)
     const size_t dbl = nlam + 90 + 40 + 40 + 16 + 40 + NI + NI + 8;
     const size_t flt = (size_t)NU * RLD + (size_t)NPAN * RLD + ((L.np + 3) & ~3)
                        + 2 * ((size_t)NS * (N + 1) + (size_t)NU * N + 2 * (size_t)NI * N) + (size_t)NS * N + (size_t)NU * N
-                       + (size_t)GEO * N + 2 * NXA * PLD + NXA * GLD + NS * NS + 3 * NU + 3 * NS + 3 + 96 + 64 + 40 + 40 + 8
+                       + (size_t)GEO * N + 2 * NXA * PLD + NXA * GLD + NS * NS + 3 * NU + 3 * NS + 3 + 96 + 12 + 64 + 40 + 40 + 8
                        + 3 * NU + 3 * NS + 3 + 4 + NTRI / 2 + (factors_global ? 0 : (size_t)LP * N + (size_t)NU * NS * N);
     return ((sizeof(CmpcConsts) + 15) & ~(size_t)15) + dbl * 8 + flt * 4;
 }
@@ -1171,6 +1238,9 @@ extern "C" int cmpc_launch_solver(const CmpcParams* prm, size_t lds_bytes, hipSt
 {
     constexpr int NT = 256;
     void (*kern)(CmpcParams) = nullptr;
+#ifdef CMPC_ONLY_N20  // developer builds: one instantiation
+    kern = cmpc_solve_kernel<NT, 20, false>;
+#else
     if (prm->scratch) {
         kern = cmpc_solve_kernel<NT, 0, true>;
     } else {
@@ -1181,6 +1251,7 @@ extern "C" int cmpc_launch_solver(const CmpcParams* prm, size_t lds_bytes, hipSt
             default: kern = cmpc_solve_kernel<NT, 0, false>; break;
         }
     }
+#endif
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(kern, dim3(prm->B), dim3(NT), lds_bytes, stream, *prm);
