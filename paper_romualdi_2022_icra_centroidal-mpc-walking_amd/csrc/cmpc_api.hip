@@ -120,7 +120,19 @@ int cmpc_create(const cmpc_config* cfg, int batch, int device, cmpc_handle* out)
     h->device = device;
     cmpc_layout_init(h->L, cfg->horizon);
     h->lds = cmpc_solver_lds_bytes(cfg->horizon, 0);
-    const bool fg = h->lds > 160 * 1024;
+    // factors in HBM scratch when the LDS image would not fit -- or, by choice, to halve the image so that
+    // two workgroups share a CU (CMPC_FACTORS=hbm|lds overrides; default: LDS whenever it fits)
+    bool fg = h->lds > 160 * 1024;
+    {
+        // more problems than CUs: the batch is throughput-bound, and two 67 KB workgroups per CU overlap
+        // each other's single-wave phases (measured 1.42x at B = 4096); at B <= #CU latency rules: LDS
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess && batch > prop.multiProcessorCount) fg = true;
+    }
+    if (const char* e = std::getenv("CMPC_FACTORS")) {
+        if (std::string(e) == "hbm") fg = true;
+        if (std::string(e) == "lds" && h->lds <= 160 * 1024) fg = false;
+    }
     if (fg) {
         h->lds = cmpc_solver_lds_bytes(cfg->horizon, 1);
         h->scratch_stride = (long long)(CMPC_LP + CMPC_NU * CMPC_NS) * cfg->horizon;

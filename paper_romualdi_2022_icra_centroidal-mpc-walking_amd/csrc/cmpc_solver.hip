@@ -356,31 +356,37 @@ __device__ inline double readlane_d(double x, int lane)
 // pivot was not positive (uniform across the wave).
 __device__ inline bool chol_solve_fused(float (&v)[NU], double (&dd)[3], int lane, int fixedmask)
 {
+    // Lanes < 30 enter with v[c] = Quu[lane][c] for c outside their own 3x3 diagonal block and 0 inside it; the
+    // diagonal block itself is in dd (float64).  Updates of a diagonal block by earlier columns are moderate
+    // numbers and accumulate in those zeroed float slots; they are folded into dd when the block becomes the
+    // pivot block.  Inside the pivot block everything is float64 (partners by v_readlane of compile-time lanes).
     bool bad = false;
     const int myblk = lane / 3;
 #pragma unroll
     for (int j = 0; j < NU; ++j) {
         const int b = j / 3, jm = j % 3;
+        const bool inblk = (myblk == b);
+        if (jm == 0 && inblk) {
+            dd[0] += (double)v[3 * b];
+            dd[1] += (double)v[3 * b + 1];
+            dd[2] += (double)v[3 * b + 2];
+        }
         if (j >= NF && ((fixedmask >> (j - NF)) & 1)) continue;  // identity row/column (fixed q): nothing to do
         double piv = readlane_d(dd[jm], j);
         if (!(piv > 0.0)) { bad = true; piv = 1.0; }
         double rinv = (double)rsqrtf((float)piv);
         rinv = rinv * (1.5 - 0.5 * piv * rinv * rinv);  // one Newton step in float64: ~1e-14 relative
         const float rinvf = (float)rinv;
-        const bool inblk = (myblk == b);
         const double ld = inblk ? dd[jm] * rinv : (double)(v[j] * rinvf);
         const float lf = (float)ld;
         v[j] = lf;
-        // own 3x3 diagonal block (float64).  Rows of the pivot's block need their partners' column entries in
-        // float64 (two compile-time lanes: v_readlane); rows of later blocks take float partners by ds_bpermute.
-        const double dA = jm < 2 ? readlane_d(ld, j + 1 < NU ? j + 1 : j) : 0.0;
-        const double dB = jm < 1 ? readlane_d(ld, j + 2 < NU ? j + 2 : j) : 0.0;
-#pragma unroll
-        for (int m = 0; m < 3; ++m) {
-            const int src = 3 * myblk + m;
-            const float of = __shfl(lf, src & 63);
-            const double od = inblk ? ((3 * b + m) == j + 1 ? dA : dB) : (double)of;
-            if (src > j && src <= lane) dd[m] -= ld * od;
+        if (jm < 2) {
+            const double dA = readlane_d(ld, j + 1);
+            if (inblk && lane > j) dd[jm + 1] -= ld * dA;
+            if (jm < 1) {
+                const double dB = readlane_d(ld, j + 2);
+                if (inblk && lane > j + 1) dd[2] -= ld * dB;
+            }
         }
         // everything else (float32): v[c] -= l_ij * l_cj
 #pragma unroll
@@ -400,8 +406,9 @@ __device__ inline void stage_factor(const float* QuuF, const double* QuuD, float
     const bool active = isL || prow < NPAN;
     float v[NU];
     double dd[3] = {0.0, 0.0, 0.0};
+    const bool idrow = !isL && prow >= NS && prow < NS + NU;
     {
-        const float* src = isL ? QuuF + lane * RLD : Pan + (active ? prow : 0) * RLD;
+        const float* src = isL ? QuuF + lane * RLD : Pan + ((active && !idrow) ? prow : 0) * RLD;
 #pragma unroll
         for (int q4 = 0; q4 < 8; ++q4) {
             const float4 t4 = *reinterpret_cast<const float4*>(src + 4 * q4);
@@ -409,6 +416,10 @@ __device__ inline void stage_factor(const float* QuuF, const double* QuuD, float
             if (4 * q4 + 1 < NU) v[4 * q4 + 1] = t4.y;
             if (4 * q4 + 2 < NU) v[4 * q4 + 2] = t4.z;
             if (4 * q4 + 3 < NU) v[4 * q4 + 3] = t4.w;
+        }
+        if (idrow) {
+#pragma unroll
+            for (int cc = 0; cc < NU; ++cc) v[cc] = (cc == prow - NS) ? 1.f : 0.f;
         }
         if (isL) {
             dd[0] = QuuD[9 * (lane / 3) + 3 * (lane % 3) + 0];
@@ -590,7 +601,7 @@ __device__ int riccati_backward(const Ctx& c, const CmpcConsts& prm, int tid, bo
                     v = fr ? v + c.sig[32 + i - 24] + c.sig[38 + i - 24] + (double)reg : 1.0;  // fixed q: exact identity row
                 }
                 c.QuuD[9 * (i / 3) + 3 * (i % 3) + j % 3] = v;
-                vf = (float)v;
+                vf = 0.f;  // the float copy of a diagonal block collects the updates by earlier columns
             } else if (i < NF && (i / 12) == (j / 12) && (i % 3) == (j % 3)) {
                 // another corner of the same foot, same axis: symmetry-cost coupling
                 const float gam = gam_of(c, i / 12, k);
@@ -598,10 +609,10 @@ __device__ int riccati_backward(const Ctx& c, const CmpcConsts& prm, int tid, bo
             }
             c.QuuF[i * RLD + j] = vf;
         }
-        for (int e = tid; e < (NPAN - 1) * NU; e += NT) {
-            const int r = e / NU, i = e % NU;  // panel row r (column of [Qus | I]), entry i
+        for (int e = tid; e < NS * NU; e += NT) {  // identity rows of the panel are made in registers (phase 3)
+            const int r = e / NU, i = e % NU;  // panel row r (column of Qus), entry i
             float v;
-            if (r < NS) {
+            {
                 const int j = r;
                 v = c.G[c.Arow[3 * j] * GLD + i] * c.Aval[3 * j] + c.G[c.Arow[3 * j + 1] * GLD + i] * c.Aval[3 * j + 1]
                     + c.G[c.Arow[3 * j + 2] * GLD + i] * c.Aval[3 * j + 2];
@@ -612,26 +623,25 @@ __device__ int riccati_backward(const Ctx& c, const CmpcConsts& prm, int tid, bo
                     const float sgn = j < 3 ? -1.f : ((b >= 0 && b < 3) ? 1.f : 0.f);
                     v += sgn * gam_of(c, ct, k) * c.arow[96 + 3 * a + ((b >= 0 && b < 3) ? b : 0)];
                 }
-            } else {
-                v = (r - NS == i) ? 1.f : 0.f;
             }
             c.Pan[r * RLD + i] = v;
         }
-        if (tid < NU) {  // qu (float64 -> float: it vanishes at convergence, so float keeps its relative accuracy)
+        if (tid >= 192 && tid < 192 + NU) {  // qu on wave 3 (float64 -> float: it vanishes at convergence, so float keeps its relative accuracy)
+            const int iq = tid - 192;
             double g;
-            if (tid < NF) {
-                g = grad_sym(c, prm, k, tid);
-                const int r0 = 4 * (tid / 3);
+            if (iq < NF) {
+                g = grad_sym(c, prm, k, iq);
+                const int r0 = 4 * (iq / 3);
 #pragma unroll
-                for (int f = 0; f < 4; ++f) g += c.gco[r0 + f] * (double)c.arow[3 * (r0 + f) + tid % 3];
-                if (pk) g += (double)prm.D[tid % 3] * ((double)u[tid] - (double)c.U[NU * (k - 1) + tid]);
-                if (havep) g += c.Pd[NS + tid];
+                for (int f = 0; f < 4; ++f) g += c.gco[r0 + f] * (double)c.arow[3 * (r0 + f) + iq % 3];
+                if (pk) g += (double)prm.D[iq % 3] * ((double)u[iq] - (double)c.U[NU * (k - 1) + iq]);
+                if (havep) g += c.Pd[NS + iq];
             } else {
-                const int q = tid - 24;
+                const int q = iq - 24;
                 g = qfree(c, k, q) ? c.gco[32 + q] - c.gco[38 + q] : 0.0;
             }
-            g += Bt_vec<double>(c, prm, k, tid, c.Pd);
-            c.Pan[(NPAN - 1) * RLD + tid] = (float)g;
+            g += Bt_vec<double>(c, prm, k, iq, c.Pd);
+            c.Pan[(NPAN - 1) * RLD + iq] = (float)g;
         } else if (tid >= 64 && tid < 64 + NS) {
             const int i = tid - 64;
             c.qs[i] = grad_track(c, prm, k, i) + At_vec<double>(c, prm, k, i, c.Pd);
@@ -692,8 +702,8 @@ __device__ int riccati_backward(const Ctx& c, const CmpcConsts& prm, int tid, bo
             }
             // gradient of the value function (float64)
             const int ncol = pk ? NXA : NS;
-            if (tid >= 192 && tid < 192 + NXA) {
-                const int i = tid - 192;
+            if (tid >= 216 && tid < 216 + NXA) {
+                const int i = tid - 216;
                 double v = 0.0;
                 if (i < ncol) {
                     const float* ri = c.Pan + i * RLD;
@@ -955,7 +965,7 @@ __device__ void costate_update(const Ctx& c, const CmpcConsts& prm, int tid, flo
 // FG: the per-stage factors (Linv, Ws: 915 floats per stage) live in global scratch instead of LDS
 // (horizons whose LDS image would exceed 160 KiB)
 template <int NT, int NC, bool FG>
-__global__ __launch_bounds__(NT) void cmpc_solve_kernel(CmpcParams kp)
+__global__ __launch_bounds__(NT, FG ? 2 : 1) void cmpc_solve_kernel(CmpcParams kp)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -1242,7 +1252,7 @@ extern "C" int cmpc_launch_solver(const CmpcParams* prm, size_t lds_bytes, hipSt
     kern = cmpc_solve_kernel<NT, 20, false>;
 #else
     if (prm->scratch) {
-        kern = cmpc_solve_kernel<NT, 0, true>;
+        kern = prm->N == 20 ? cmpc_solve_kernel<NT, 20, true> : cmpc_solve_kernel<NT, 0, true>;
     } else {
         switch (prm->N) {  // horizons of the shipped configurations get compile-time layouts
             case 10: kern = cmpc_solve_kernel<NT, 10, false>; break;
