@@ -702,14 +702,21 @@ __device__ int riccati_backward(const Ctx& c, const CmpcConsts& prm, int tid, bo
             }
             // gradient of the value function (float64)
             const int ncol = pk ? NXA : NS;
-            if (tid >= 216 && tid < 216 + NXA) {
+            if (tid >= 216 && tid < 216 + NXA) {  // threads beyond the 210 tile owners
                 const int i = tid - 216;
                 double v = 0.0;
                 if (i < ncol) {
-                    const float* ri = c.Pan + i * RLD;
-                    const float* rl = c.Pan + (NPAN - 1) * RLD;
+                    // W^T lq: lq vanishes at convergence, so the dot product itself is fine in float32
+                    const float4* ri = reinterpret_cast<const float4*>(c.Pan + i * RLD);
+                    const float4* rl = reinterpret_cast<const float4*>(c.Pan + (NPAN - 1) * RLD);
+                    float s0 = 0.f, s1 = 0.f;
 #pragma unroll
-                    for (int a = 0; a < NU; ++a) v += (double)ri[a] * (double)rl[a];
+                    for (int q4 = 0; q4 < 8; ++q4) {
+                        const float4 x = ri[q4], y = rl[q4];
+                        s0 += x.x * y.x + x.y * y.y;
+                        if (q4 < 7) s1 += x.z * y.z + x.w * y.w;
+                    }
+                    v = (double)(s0 + s1);
                     if (i < NS) v = c.qs[i] - v;
                     else {
                         const int m = i - NS;
