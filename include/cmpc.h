@@ -122,6 +122,20 @@ int cmpc_get_solution(cmpc_handle h, float* X, float* info);
  * index [2] (-1 if the contact does not land inside the horizon) */
 int cmpc_get_output(cmpc_handle h, float* forces0, float* pos0, float* next_pos, int* next_knot);
 
+/* ---- rows next to the solve ----
+ * 8f-3, CentroidalMPCBlock.cpp:525-577: planner trajectories (n_in knots every in_dt seconds, the first one t_offset
+ * seconds before "now"; com_in/h_in [B][n_in][3], h_in NOT yet divided by the mass) -> comRef/hRef at the N+1 MPC knots
+ * by linear interpolation; the CoM height is replaced by com_height unless it is NaN (the reference forces 0.7, :534). */
+int cmpc_set_reference_from_planner(cmpc_handle h, const float* com_in, const float* h_in, int n_in, double in_dt,
+                                    double t_offset, double robot_mass, double com_height);
+/* 8f-4, WholeBodyQPBlock.cpp:805-873, 1083-1084, 1150, 1259-1262: between two MPC ticks the plant integrates the
+ * centroidal dynamics under the first-knot corner forces of the active contacts + the external wrench of knot 0 (RK4,
+ * `substeps` steps of `step` seconds, forces held) and reports the desired ZMP (local ZMP clamped to +-zmp_half_x/y:
+ * 0.08 / 0.03 in the reference).  dStateIn/dStateOut [B][9] (com, dcom, h; may alias), dZmp [B][2] or NULL. Device
+ * pointers; asynchronous on `stream` (NULL: the handle's). */
+int cmpc_plant_step_device(cmpc_handle h, const float* dX, const float* dP, const float* dStateIn, float* dStateOut,
+                           float* dZmp, double step, int substeps, double zmp_half_x, double zmp_half_y, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

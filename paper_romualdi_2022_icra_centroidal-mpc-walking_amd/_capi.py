@@ -38,7 +38,7 @@ EXPORTS = [
     "cmpc_batch", "cmpc_stream", "cmpc_solve_device", "cmpc_solve", "cmpc_last_solve_ms",
     "cmpc_eval_nlp_device", "cmpc_nlp_sparsity", "cmpc_set_state", "cmpc_set_reference",
     "cmpc_set_contacts", "cmpc_set_initial_guess", "cmpc_advance", "cmpc_get_solution",
-    "cmpc_get_output",
+    "cmpc_get_output", "cmpc_set_reference_from_planner", "cmpc_plant_step_device",
 ]
 
 _lib = None
@@ -82,5 +82,7 @@ def lib():
         L.cmpc_advance.argtypes = [vp]
         L.cmpc_get_solution.argtypes = [vp, fp, fp]
         L.cmpc_get_output.argtypes = [vp, fp, fp, fp, vp]
+        L.cmpc_set_reference_from_planner.argtypes = [vp, fp, fp, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double]
+        L.cmpc_plant_step_device.argtypes = [vp, fp, fp, fp, fp, fp, C.c_double, C.c_int, C.c_double, C.c_double, vp]
         _lib = L
     return _lib

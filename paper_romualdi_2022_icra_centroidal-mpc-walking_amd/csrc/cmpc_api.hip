@@ -16,6 +16,9 @@ extern "C" int cmpc_launch_nlp_eval(const CmpcParams* prm, const float* dX, cons
                                     float lam_f, float* dF, float* dG, float* dGradF, float* dJac, float* dHess,
                                     hipStream_t stream);
 extern "C" int cmpc_launch_warm_shift(const CmpcParams* prm, const float* dXprev, float* dX0, hipStream_t stream);
+extern "C" int cmpc_launch_plant_step(int N, int B, float grav, const float* dCorners, const float* dX, const float* dP,
+                                      const float* dStateIn, float* dStateOut, float* dZmp, float h, int nsub, float zx, float zy,
+                                      hipStream_t stream);
 
 struct cmpc_handle_s {
     cmpc_config cfg;
@@ -448,6 +451,54 @@ int cmpc_eval_nlp_device(cmpc_handle h, const float* dX, const float* dP, const 
     fill_params(h, p);
     int rc = cmpc_launch_nlp_eval(&p, dX, dP, dLamG, lam_f, dF, dG, dGradF, dJac, dHess, stream ? (hipStream_t)stream : h->stream);
     if (rc != 0) return fail(h, CMPC_ERR_HIP, std::string("nlp eval launch: ") + hipGetErrorString((hipError_t)rc));
+    return CMPC_OK;
+}
+
+
+// ---- 8f-3: planner references -> MPC knots (CentroidalMPCBlock.cpp:525-577): angular momentum / mass, CoM height
+// override, linear spline from the planner's knots (period in_dt, first knot t_offset in the past) to the N+1 MPC
+// knots; clamped at both ends.  Host-side like the reference's LinearSpline; fills the handle's parameter staging. ----
+int cmpc_set_reference_from_planner(cmpc_handle h, const float* com_in, const float* h_in, int n_in, double in_dt, double t_offset,
+                                    double robot_mass, double com_height)
+{
+    if (!h || !com_in || !h_in || n_in < 2 || !(in_dt > 0) || !(robot_mass > 0))
+        return fail(h, CMPC_ERR_ARG, "cmpc_set_reference_from_planner: bad argument");
+    int rc = ensure_buffers(h);
+    if (rc) return rc;
+    const int N = h->cfg.horizon;
+    for (int b = 0; b < h->B; ++b) {
+        float* p = h->hP.data() + (size_t)b * h->L.np;
+        const float* ci = com_in + (size_t)b * n_in * 3;
+        const float* hi = h_in + (size_t)b * n_in * 3;
+        for (int k = 0; k <= N; ++k) {
+            double s = (t_offset + k * h->cfg.sampling_time) / in_dt;
+            if (s < 0) s = 0;
+            if (s > n_in - 1) s = n_in - 1;
+            int i0 = (int)s;
+            if (i0 > n_in - 2) i0 = n_in - 2;
+            const double w = s - i0;
+            for (int a = 0; a < 3; ++a) {
+                double cv = (1 - w) * ci[3 * i0 + a] + w * ci[3 * (i0 + 1) + a];
+                if (a == 2 && com_height == com_height) cv = com_height;  // the reference forces 0.7 (:534); NaN keeps the planner's
+                p[h->L.p_comref + 3 * k + a] = (float)cv;
+                p[h->L.p_href + 3 * k + a] = (float)(((1 - w) * hi[3 * i0 + a] + w * hi[3 * (i0 + 1) + a]) / robot_mass);
+            }
+        }
+    }
+    return CMPC_OK;
+}
+
+// ---- 8f-4: plant step on the device (see cmpc_plant_step_kernel) ----
+int cmpc_plant_step_device(cmpc_handle h, const float* dX, const float* dP, const float* dStateIn, float* dStateOut, float* dZmp,
+                           double step, int substeps, double zmp_half_x, double zmp_half_y, void* stream)
+{
+    if (!h || !dX || !dP || !dStateIn || !dStateOut || !(step > 0) || substeps < 1)
+        return fail(h, CMPC_ERR_ARG, "cmpc_plant_step_device: bad argument");
+    HIPCHK(h, hipSetDevice(h->device));
+    const float* corners = h->dConsts->corners;  // device pointer arithmetic only
+    int rc = cmpc_launch_plant_step(h->cfg.horizon, h->B, (float)h->cfg.gravity, corners, dX, dP, dStateIn, dStateOut, dZmp, (float)step,
+                                    substeps, (float)zmp_half_x, (float)zmp_half_y, stream ? (hipStream_t)stream : h->stream);
+    if (rc != 0) return fail(h, CMPC_ERR_HIP, std::string("plant step launch: ") + hipGetErrorString((hipError_t)rc));
     return CMPC_OK;
 }
 

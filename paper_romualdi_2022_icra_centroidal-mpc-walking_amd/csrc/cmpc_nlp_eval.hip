@@ -452,3 +452,101 @@ extern "C" int cmpc_launch_warm_shift(const CmpcParams* prm, const float* dXprev
     hipLaunchKernelGGL(cmpc_warm_shift_kernel, dim3(prm->B), dim3(256), 0, stream, prm->N, prm->B, dXprev, dX0);
     return (int)hipGetLastError();
 }
+
+// ---------------------------------------------------------------------------------------------
+// Closed-loop plant between two MPC ticks: what WholeBodyQPBlock does with the MPC
+// output -- centroidal dynamics driven by the first-knot corner forces of the active contacts plus
+// the external wrench, RK4 with the forces held (src/centroidal-mpc-walking/src/
+// WholeBodyQPBlock.cpp:1083-1084, 1150, 1259-1262), and the desired ZMP from the corner forces
+// (:805-873: per-foot local ZMP = (-tau_y, tau_x)/f_z clamped to the sole, f_z-weighted mean in the
+// world frame).  Everything mass-normalised like the MPC.  One thread per problem (a few hundred
+// flops): the kernel is HBM/launch bound and exists so that Monte-Carlo roll-outs never leave HBM.
+namespace {
+
+__global__ __launch_bounds__(256) void cmpc_plant_step_kernel(int N, int B, float grav, const float* __restrict__ corners,
+                                                              const float* __restrict__ X, const float* __restrict__ P,
+                                                              const float* __restrict__ state_in, float* __restrict__ state_out,
+                                                              float* __restrict__ zmp, float h, int nsub, float zx, float zy)
+{
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= B) return;
+    CmpcIdx L{N};
+    const float* x = X + (size_t)b * L.nx();
+    const float* p = P + (size_t)b * L.np();
+    double com[3], v[3], hm[3], fsum[3] = {0, 0, 0}, ext_t[3];
+    for (int i = 0; i < 3; ++i) {
+        com[i] = state_in[(size_t)b * 9 + i]; v[i] = state_in[(size_t)b * 9 + 3 + i]; hm[i] = state_in[(size_t)b * 9 + 6 + i];
+        ext_t[i] = p[L.pText() + i];
+    }
+    // contact points (world) and forces of the active contacts at knot 0
+    double cp[8][3], cf[8][3];
+    double zw[2] = {0, 0}, ztot = 0;
+    for (int c = 0; c < 2; ++c) {
+        const float* R = p + L.pR(c);  // col-major vec of knot 0
+        const bool on = p[L.pGam(c)] > 0.5f;
+        double F[3] = {0, 0, 0}, T[3] = {0, 0, 0};
+        for (int j = 0; j < 4; ++j) {
+            const float* cn = corners + 12 * c + 3 * j;
+            double fl[3];
+            for (int i = 0; i < 3; ++i) {
+                cp[4 * c + j][i] = (double)x[L.oPos(c) + i] + (double)R[i] * cn[0] + (double)R[3 + i] * cn[1] + (double)R[6 + i] * cn[2];
+                cf[4 * c + j][i] = on ? (double)x[L.oF(c, j) + i] : 0.0;
+                fsum[i] += cf[4 * c + j][i];
+            }
+            for (int i = 0; i < 3; ++i) fl[i] = (double)R[3 * i] * cf[4 * c + j][0] + (double)R[3 * i + 1] * cf[4 * c + j][1] + (double)R[3 * i + 2] * cf[4 * c + j][2];
+            for (int i = 0; i < 3; ++i) F[i] += cf[4 * c + j][i];
+            T[0] += cn[1] * fl[2] - cn[2] * fl[1];
+            T[1] += cn[2] * fl[0] - cn[0] * fl[2];
+            T[2] += cn[0] * fl[1] - cn[1] * fl[0];
+        }
+        if (F[2] > 0.001) {
+            double lx = fmin((double)zx, fmax(-(double)zx, -T[1] / F[2]));
+            double ly = fmin((double)zy, fmax(-(double)zy, T[0] / F[2]));
+            ztot += F[2];
+            zw[0] += F[2] * ((double)x[L.oPos(c)] + (double)R[0] * lx + (double)R[3] * ly);
+            zw[1] += F[2] * ((double)x[L.oPos(c) + 1] + (double)R[1] * lx + (double)R[4] * ly);
+        }
+    }
+    auto deriv = [&](const double* cm, const double* vv, double* dcm, double* dv, double* dh) {
+        for (int i = 0; i < 3; ++i) { dcm[i] = vv[i]; dv[i] = fsum[i] + (double)p[L.pFext() + i] - (i == 2 ? (double)grav : 0.0); dh[i] = ext_t[i]; }
+        for (int q = 0; q < 8; ++q) {
+            const double r0 = cp[q][0] - cm[0], r1 = cp[q][1] - cm[1], r2 = cp[q][2] - cm[2];
+            dh[0] += r1 * cf[q][2] - r2 * cf[q][1];
+            dh[1] += r2 * cf[q][0] - r0 * cf[q][2];
+            dh[2] += r0 * cf[q][1] - r1 * cf[q][0];
+        }
+    };
+    for (int s = 0; s < nsub; ++s) {
+        double k1c[3], k1v[3], k1h[3], k2c[3], k2v[3], k2h[3], k3c[3], k3v[3], k3h[3], k4c[3], k4v[3], k4h[3], tc[3], tv[3];
+        deriv(com, v, k1c, k1v, k1h);
+        for (int i = 0; i < 3; ++i) { tc[i] = com[i] + 0.5 * h * k1c[i]; tv[i] = v[i] + 0.5 * h * k1v[i]; }
+        deriv(tc, tv, k2c, k2v, k2h);
+        for (int i = 0; i < 3; ++i) { tc[i] = com[i] + 0.5 * h * k2c[i]; tv[i] = v[i] + 0.5 * h * k2v[i]; }
+        deriv(tc, tv, k3c, k3v, k3h);
+        for (int i = 0; i < 3; ++i) { tc[i] = com[i] + h * k3c[i]; tv[i] = v[i] + h * k3v[i]; }
+        deriv(tc, tv, k4c, k4v, k4h);
+        for (int i = 0; i < 3; ++i) {
+            com[i] += h / 6.0 * (k1c[i] + 2 * k2c[i] + 2 * k3c[i] + k4c[i]);
+            v[i] += h / 6.0 * (k1v[i] + 2 * k2v[i] + 2 * k3v[i] + k4v[i]);
+            hm[i] += h / 6.0 * (k1h[i] + 2 * k2h[i] + 2 * k3h[i] + k4h[i]);
+        }
+    }
+    for (int i = 0; i < 3; ++i) {
+        state_out[(size_t)b * 9 + i] = (float)com[i]; state_out[(size_t)b * 9 + 3 + i] = (float)v[i]; state_out[(size_t)b * 9 + 6 + i] = (float)hm[i];
+    }
+    if (zmp) {
+        zmp[(size_t)b * 2] = ztot > 0.001 ? (float)(zw[0] / ztot) : nanf("");
+        zmp[(size_t)b * 2 + 1] = ztot > 0.001 ? (float)(zw[1] / ztot) : nanf("");
+    }
+}
+
+}  // namespace
+
+extern "C" int cmpc_launch_plant_step(int N, int B, float grav, const float* dCorners, const float* dX, const float* dP,
+                                      const float* dStateIn, float* dStateOut, float* dZmp, float h, int nsub, float zx, float zy,
+                                      hipStream_t stream)
+{
+    hipLaunchKernelGGL(cmpc_plant_step_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, N, B, grav, dCorners, dX, dP, dStateIn,
+                       dStateOut, dZmp, h, nsub, zx, zy);
+    return (int)hipGetLastError();
+}

@@ -125,6 +125,27 @@ class BatchSolver:
     def last_solve_ms(self) -> float:
         return float(self._lib.cmpc_last_solve_ms(self._h))
 
+    def plant_step_device(self, dX, dP, dState, dStateOut=None, dZmp=None, step=0.01, substeps=6,
+                          zmp_half_x=0.08, zmp_half_y=0.03):
+        """Closed-loop plant between two MPC ticks (WholeBodyQPBlock.cpp:805-873, 1083-1084, 1150): RK4 of the
+        centroidal dynamics under the first-knot forces; torch CUDA tensors; returns (state[B,9], zmp[B,2])."""
+        import torch
+        if dStateOut is None:
+            dStateOut = torch.empty_like(dState)
+        if dZmp is None:
+            dZmp = torch.empty((self.batch, 2), dtype=torch.float32, device=dState.device)
+        if self._stream is None:
+            self._stream = torch.cuda.Stream(dState.device)
+        cur = torch.cuda.current_stream(dState.device)
+        self._stream.wait_stream(cur)
+        rc = self._lib.cmpc_plant_step_device(self._h, dX.data_ptr(), dP.data_ptr(), dState.data_ptr(), dStateOut.data_ptr(),
+                                              dZmp.data_ptr(), float(step), int(substeps), float(zmp_half_x), float(zmp_half_y),
+                                              self._stream.cuda_stream)
+        if rc != 0:
+            raise RuntimeError(f"cmpc_plant_step_device failed ({rc}): {self.last_error}")
+        cur.wait_stream(self._stream)
+        return dStateOut, dZmp
+
 
 class CentroidalMPCOutput:
     """What getOutput() exposes downstream (WholeBodyQPBlock.cpp:824-829, 1319-1335): per contact
@@ -201,6 +222,18 @@ class CentroidalMPC:
         c = np.ascontiguousarray(np.reshape(com, (B, N + 1, 3)), np.float32)
         h = np.ascontiguousarray(np.reshape(angular_momentum, (B, N + 1, 3)), np.float32)
         return self._ok(self._lib.cmpc_set_reference(self._h, c.ctypes.data, h.ctypes.data))
+
+    def set_reference_from_planner(self, com_in, h_in, in_dt: float, t_offset: float, robot_mass: float,
+                                   com_height: float = 0.7) -> bool:
+        """Planner trajectories [B,M,3] every in_dt seconds -> MPC knots (CentroidalMPCBlock.cpp:525-577): angular
+        momentum divided by the mass, CoM height forced to com_height (NaN keeps the planner's)."""
+        if not self._need_init():
+            return False
+        B = self._batch
+        c = np.ascontiguousarray(np.reshape(com_in, (B, -1, 3)), np.float32)
+        h = np.ascontiguousarray(np.reshape(h_in, (B, -1, 3)), np.float32)
+        return self._ok(self._lib.cmpc_set_reference_from_planner(self._h, c.ctypes.data, h.ctypes.data, c.shape[1], float(in_dt),
+                                                                  float(t_offset), float(robot_mass), float(com_height)))
 
     def set_contact_phase_list(self, lists, t0: float = 0.0) -> bool:
         """lists: one dict {contact_name: [PlannedContact,...]} for every problem of the batch (or a
