@@ -97,6 +97,7 @@ struct CmpcParams {
     const float* X0;             // [B][nx]
     float* X;                    // [B][nx]
     float* info;                 // [B][CMPC_INFO_N] or null
+    float mu_init, t_floor;      // starting barrier parameter and slack floor of this solve (cold: 0.1 / 1e-2)
     float* scratch;              // per-problem factor storage when it does not fit in LDS, else null
     long long scratch_stride;    // floats per problem
 };

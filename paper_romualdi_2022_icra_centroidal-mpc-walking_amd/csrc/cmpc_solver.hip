@@ -1074,8 +1074,8 @@ __global__ __launch_bounds__(NT, FG ? 2 : 1) void cmpc_solve_kernel(CmpcParams k
             float t = 1.f, z = 0.f;
             if (row_active(c, k, i)) {
                 t = -row_val(c, prm, k, i, c.U + NU * k);
-                if (i < 32) t = fmaxf(t, 1e-2f);
-                z = prm.mu_init / t;
+                if (i < 32) t = fmaxf(t, kp.t_floor);
+                z = kp.mu_init / t;
             }
             c.T[e] = t; c.Z[e] = z;
         }
@@ -1264,7 +1264,10 @@ extern "C" int cmpc_launch_solver(const CmpcParams* prm, size_t lds_bytes, hipSt
         switch (prm->N) {  // horizons of the shipped configurations get compile-time layouts
             case 10: kern = cmpc_solve_kernel<NT, 10, false>; break;
             case 12: kern = cmpc_solve_kernel<NT, 12, false>; break;
-            case 20: kern = cmpc_solve_kernel<NT, 20, false>; break;
+            case 13: kern = cmpc_solve_kernel<NT, 13, false>; break;  // ergoCubSN000
+            case 15: kern = cmpc_solve_kernel<NT, 15, false>; break;  // iCubGazeboV3
+            case 20: kern = cmpc_solve_kernel<NT, 20, false>; break;  // ergoCubGazeboV1
+            case 22: kern = cmpc_solve_kernel<NT, 22, false>; break;  // ergoCubSN001
             default: kern = cmpc_solve_kernel<NT, 0, false>; break;
         }
     }

@@ -85,3 +85,40 @@ def test_closed_loop_rollout_stays_upright():
     assert np.abs(st[:, 2] - 0.7).max() < 0.02 and np.abs(st[:, :2]).max() < 0.05
     z = zmp.cpu().numpy()
     assert (np.abs(z[:, 0]) <= 0.08 + 1e-6).all() and (np.abs(z[:, 1]) <= 0.08 + 0.01 + 1e-6).all()
+
+
+def test_warm_start_saves_iterations_in_receding_horizon():
+    """is_warm_start_enabled (ergoCubGazeboV1/centroidal_mpc.ini:9): ticks started from the previous solution shifted
+    by one knot, with the barrier started at 1e-2 instead of 0.1, need fewer iterations than cold ticks and reach the
+    same optimum."""
+    import torch
+    from cmpc_amd.synthetic import _standing_lists
+    from tests import parity
+    B = 32
+    cfg, P, X0 = cm.synthetic.config2_perturbed_com(B)
+    L, N = cm.Layout(cfg.N), cfg.N
+    its = {}
+    sols = {}
+    for mode in ("cold", "warm"):
+        mpc = cm.CentroidalMPC(batch=B)
+        assert mpc.initialize(cfg)
+        state = P[:, L.p_com0:L.p_com0 + 9].astype(np.float32).copy()
+        dP = torch.from_numpy(P.astype(np.float32)).cuda()
+        it = []
+        for tick in range(4):
+            assert mpc.set_state(state[:, 0:3], state[:, 3:6], state[:, 6:9])
+            assert mpc.set_reference_trajectory(P[:, L.p_comref:L.p_comref + 3 * (N + 1)], P[:, L.p_href:L.p_href + 3 * (N + 1)])
+            assert mpc.set_contact_phase_list(_standing_lists(cfg, 10.0))
+            if tick > 0 and mode == "warm":
+                assert mpc.set_initial_guess(None, shift_previous=True)
+            assert mpc.advance(), mpc.last_error
+            X, info = mpc.get_solution()
+            it.append(float(info[:, 0].mean()))
+            st, _ = mpc._solver.plant_step_device(torch.from_numpy(X).cuda(), dP, torch.from_numpy(state).cuda(), step=0.01, substeps=6)
+            torch.cuda.synchronize()
+            state = st.cpu().numpy()
+        its[mode], sols[mode] = it, X
+    assert np.mean(its["warm"][1:]) < np.mean(its["cold"][1:]) - 0.5, its
+    for b in range(B):  # same closed-loop trajectory either way
+        e = parity.errors(cfg.N, P[b], sols["warm"][b], sols["cold"][b])
+        assert e["com"] < 1e-4 and e["force0"] < 1e-4, e
