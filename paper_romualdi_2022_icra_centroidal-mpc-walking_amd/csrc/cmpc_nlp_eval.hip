@@ -63,30 +63,29 @@ __global__ __launch_bounds__(256) void cmpc_nlp_eval_kernel(CmpcParams kp, const
         int* dst = reinterpret_cast<int*>(smem);
         for (int e = tid; e < (int)(sizeof(CmpcConsts) / 4); e += NT) dst[e] = src[e];
     }
-    CmpcLayout L;
-    cmpc_layout_init(L, N);
+    const CmpcIdx L{N};
     GLay G;
     glay_init(G, N);
     float* x = reinterpret_cast<float*>(smem + ((sizeof(CmpcConsts) + 15) & ~15));
-    float* p = x + ((L.nx + 3) & ~3);
-    float* lam = p + ((L.np + 3) & ~3);
-    float* red = lam + ((L.ng + 3) & ~3);
-    for (int e = tid; e < L.nx; e += NT) x[e] = X[(size_t)b * L.nx + e];
-    for (int e = tid; e < L.np; e += NT) p[e] = P[(size_t)b * L.np + e];
-    if (LamG) for (int e = tid; e < L.ng; e += NT) lam[e] = LamG[(size_t)b * L.ng + e];
+    float* p = x + ((L.nx() + 3) & ~3);
+    float* lam = p + ((L.np() + 3) & ~3);
+    float* red = lam + ((L.ng() + 3) & ~3);
+    for (int e = tid; e < L.nx(); e += NT) x[e] = X[(size_t)b * L.nx() + e];
+    for (int e = tid; e < L.np(); e += NT) p[e] = P[(size_t)b * L.np() + e];
+    if (LamG) for (int e = tid; e < L.ng(); e += NT) lam[e] = LamG[(size_t)b * L.ng() + e];
     __syncthreads();
     const float dt = K.dt;
 
-    auto gam = [&](int c, int k) { return p[L.p_gam[c] + k]; };
+    auto gam = [&](int c, int k) { return p[L.pGam(c) + k]; };
     auto rvec = [&](int c, int j, int k, float* r) {
-        const float* R = p + L.p_R[c] + 9 * k;
+        const float* R = p + L.pR(c) + 9 * k;
         const float* cn = K.corners + 12 * c + 3 * j;
         for (int i = 0; i < 3; ++i)
-            r[i] = R[i] * cn[0] + R[3 + i] * cn[1] + R[6 + i] * cn[2] + x[L.o_pos[c] + 3 * k + i] - x[L.o_com + 3 * k + i];
+            r[i] = R[i] * cn[0] + R[3 + i] * cn[1] + R[6 + i] * cn[2] + x[L.oPos(c) + 3 * k + i] - x[L.oCom() + 3 * k + i];
     };
     auto fcsum = [&](int c, int k, float* Fc) {
         for (int i = 0; i < 3; ++i)
-            Fc[i] = x[L.o_f[c][0] + 3 * k + i] + x[L.o_f[c][1] + 3 * k + i] + x[L.o_f[c][2] + 3 * k + i] + x[L.o_f[c][3] + 3 * k + i];
+            Fc[i] = x[L.oF(c, 0) + 3 * k + i] + x[L.oF(c, 1) + 3 * k + i] + x[L.oF(c, 2) + 3 * k + i] + x[L.oF(c, 3) + 3 * k + i];
     };
 
     // ---------------- f ----------------
@@ -94,12 +93,12 @@ __global__ __launch_bounds__(256) void cmpc_nlp_eval_kernel(CmpcParams kp, const
         float acc = 0.f;
         for (int e = tid; e < 3 * (N + 1); e += NT) {
             const int k = e / 3, i = e % 3;
-            const float ec = x[L.o_com + e] - p[L.p_comref + e];
+            const float ec = x[L.oCom() + e] - p[L.pComref() + e];
             acc += (i == 0 ? K.w_com0 : (i == 1 ? K.w_com1 : 0.5f * K.wz2[k])) * ec * ec;
-            const float eh = x[L.o_h + e] - p[L.p_href + e];
+            const float eh = x[L.oH() + e] - p[L.pHref() + e];
             acc += K.w_h * eh * eh;
             for (int c = 0; c < 2; ++c) {
-                const float ep = x[L.o_pos[c] + e] - p[L.p_nom[c] + e];
+                const float ep = x[L.oPos(c) + e] - p[L.pNom(c) + e];
                 acc += K.w_pos * ep * ep;
             }
         }
@@ -107,13 +106,13 @@ __global__ __launch_bounds__(256) void cmpc_nlp_eval_kernel(CmpcParams kp, const
             const int c = e / (3 * N), k = (e % (3 * N)) / 3, i = e % 3;
             const float g = gam(c, k);
             float mean = 0.f;
-            for (int j = 0; j < 4; ++j) mean += 0.25f * x[L.o_f[c][j] + 3 * k + i];
+            for (int j = 0; j < 4; ++j) mean += 0.25f * x[L.oF(c, j) + 3 * k + i];
             for (int j = 0; j < 4; ++j) {
-                const float fv = x[L.o_f[c][j] + 3 * k + i];
+                const float fv = x[L.oF(c, j) + 3 * k + i];
                 const float es = fv - g * mean;
                 acc += K.w_sym * es * es;
                 if (k + 1 < N) {
-                    const float d = x[L.o_f[c][j] + 3 * (k + 1) + i] - fv;
+                    const float d = x[L.oF(c, j) + 3 * (k + 1) + i] - fv;
                     acc += 0.5f * K.D[i] * d * d;
                 }
             }
@@ -125,53 +124,53 @@ __global__ __launch_bounds__(256) void cmpc_nlp_eval_kernel(CmpcParams kp, const
     }
     // ---------------- g ----------------
     if (Gout) {
-        float* g = Gout + (size_t)b * L.ng;
-        for (int r = tid; r < L.ng; r += NT) {
+        float* g = Gout + (size_t)b * L.ng();
+        for (int r = tid; r < L.ng(); r += NT) {
             float v;
             if (r < 15) {
                 const int i = r % 3;
-                v = r < 3 ? x[L.o_com + i] : r < 6 ? x[L.o_dcom + i] : r < 9 ? x[L.o_h + i] : r < 12 ? x[L.o_pos[0] + i] : x[L.o_pos[1] + i];
+                v = r < 3 ? x[L.oCom() + i] : r < 6 ? x[L.oDcom() + i] : r < 9 ? x[L.oH() + i] : r < 12 ? x[L.oPos(0) + i] : x[L.oPos(1) + i];
             } else if (r < G.g_dcom) {
                 const int e = r - G.g_com, k = e / 3;
-                v = x[L.o_com + e + 3] - (x[L.o_com + e] + dt * x[L.o_dcom + e]);
+                v = x[L.oCom() + e + 3] - (x[L.oCom() + e] + dt * x[L.oDcom() + e]);
                 (void)k;
             } else if (r < G.g_h) {
                 const int e = r - G.g_dcom, k = e / 3, i = e % 3;
-                float acc = p[L.p_fext + e] - (i == 2 ? K.grav : 0.f);
+                float acc = p[L.pFext() + e] - (i == 2 ? K.grav : 0.f);
                 for (int c = 0; c < 2; ++c) {
                     float Fc[3];
                     fcsum(c, k, Fc);
                     acc += gam(c, k) * Fc[i];
                 }
-                v = x[L.o_dcom + e + 3] - (x[L.o_dcom + e] + dt * acc);
+                v = x[L.oDcom() + e + 3] - (x[L.oDcom() + e] + dt * acc);
             } else if (r < G.g_pos[0]) {
                 const int e = r - G.g_h, k = e / 3, i = e % 3, a1 = (i + 1) % 3, a2 = (i + 2) % 3;
-                float tor = p[L.p_text + e];
+                float tor = p[L.pText() + e];
                 for (int c = 0; c < 2; ++c) {
                     float t = 0.f;
                     for (int j = 0; j < 4; ++j) {
                         float rr[3];
                         rvec(c, j, k, rr);
-                        const float* f = x + L.o_f[c][j] + 3 * k;
+                        const float* f = x + L.oF(c, j) + 3 * k;
                         t += rr[a1] * f[a2] - rr[a2] * f[a1];
                     }
                     tor += gam(c, k) * t;
                 }
-                v = x[L.o_h + e + 3] - (x[L.o_h + e] + dt * tor);
+                v = x[L.oH() + e + 3] - (x[L.oH() + e] + dt * tor);
             } else if (r < G.g_bbox[0]) {
                 const int c = r < G.g_pos[1] ? 0 : 1, e = r - G.g_pos[c], k = e / 3;
-                v = x[L.o_pos[c] + e + 3] - (x[L.o_pos[c] + e] + dt * (1.f - gam(c, k)) * x[L.o_vel[c] + e]);
+                v = x[L.oPos(c) + e + 3] - (x[L.oPos(c) + e] + dt * (1.f - gam(c, k)) * x[L.oVel(c) + e]);
             } else {
                 const int c = r < G.g_bbox[1] ? 0 : 1;
                 if (r < G.g_fric[c]) {
                     const int e = r - G.g_bbox[c], k = e / 3, i = e % 3;
-                    const float* R = p + L.p_R[c] + 9 * k;
+                    const float* R = p + L.pR(c) + 9 * k;
                     v = 0.f;
-                    for (int a = 0; a < 3; ++a) v += R[3 * i + a] * (x[L.o_pos[c] + 3 * (k + 1) + a] - p[L.p_nom[c] + 3 * (k + 1) + a]);
+                    for (int a = 0; a < 3; ++a) v += R[3 * i + a] * (x[L.oPos(c) + 3 * (k + 1) + a] - p[L.pNom(c) + 3 * (k + 1) + a]);
                 } else {
                     const int e = r - G.g_fric[c], k = e / 16, j = (e % 16) / 4, face = e % 4;
-                    const float* R = p + L.p_R[c] + 9 * k;
-                    const float* f = x + L.o_f[c][j] + 3 * k;
+                    const float* R = p + L.pR(c) + 9 * k;
+                    const float* f = x + L.oF(c, j) + 3 * k;
                     const float sx = (face == 0 || face == 3) ? 1.f : -1.f, sy = face < 2 ? 1.f : -1.f;
                     float fl[3];
                     for (int m = 0; m < 3; ++m) fl[m] = R[3 * m] * f[0] + R[3 * m + 1] * f[1] + R[3 * m + 2] * f[2];
@@ -183,26 +182,26 @@ __global__ __launch_bounds__(256) void cmpc_nlp_eval_kernel(CmpcParams kp, const
     }
     // ---------------- grad f ----------------
     if (GradF) {
-        float* gf = GradF + (size_t)b * L.nx;
-        for (int e = tid; e < L.nx; e += NT) {
+        float* gf = GradF + (size_t)b * L.nx();
+        for (int e = tid; e < L.nx(); e += NT) {
             float v = 0.f;
-            if (e < L.o_dcom) {
+            if (e < L.oDcom()) {
                 const int k = e / 3, i = e % 3;
-                v = (i == 0 ? 2.f * K.w_com0 : (i == 1 ? 2.f * K.w_com1 : K.wz2[k])) * (x[e] - p[L.p_comref + e]);
-            } else if (e < L.o_h) {
+                v = (i == 0 ? 2.f * K.w_com0 : (i == 1 ? 2.f * K.w_com1 : K.wz2[k])) * (x[e] - p[L.pComref() + e]);
+            } else if (e < L.oH()) {
                 v = 0.f;
-            } else if (e < L.o_pos[0]) {
-                v = 2.f * K.w_h * (x[e] - p[L.p_href + e - L.o_h]);
+            } else if (e < L.oPos(0)) {
+                v = 2.f * K.w_h * (x[e] - p[L.pHref() + e - L.oH()]);
             } else {
-                const int c = e < L.o_pos[1] ? 0 : 1;
-                const int e2 = e - L.o_pos[c];
-                if (e2 < 3 * (N + 1)) v = 2.f * K.w_pos * (x[e] - p[L.p_nom[c] + e2]);
+                const int c = e < L.oPos(1) ? 0 : 1;
+                const int e2 = e - L.oPos(c);
+                if (e2 < 3 * (N + 1)) v = 2.f * K.w_pos * (x[e] - p[L.pNom(c) + e2]);
                 else if (e2 < 3 * (N + 1) + 3 * N) v = 0.f;
                 else {
                     const int e3 = e2 - 3 * (N + 1) - 3 * N, j = e3 / (3 * N), k = (e3 % (3 * N)) / 3, i = e3 % 3;
                     const float g = gam(c, k);
                     float mean = 0.f;
-                    for (int l = 0; l < 4; ++l) mean += 0.25f * x[L.o_f[c][l] + 3 * k + i];
+                    for (int l = 0; l < 4; ++l) mean += 0.25f * x[L.oF(c, l) + 3 * k + i];
                     const float es = x[e] - g * mean, esum = 4.f * mean * (1.f - g);
                     v = 2.f * K.w_sym * (es - 0.25f * g * esum);
                     if (k > 0) v += K.D[i] * (x[e] - x[e - 3]);
@@ -244,9 +243,9 @@ __global__ __launch_bounds__(256) void cmpc_nlp_eval_kernel(CmpcParams kp, const
                     v = -dt * skew(Fs, a, bb);
                 } break;
                 case J_POS_VEL: v = -dt * (1.f - gam(c, k)); break;
-                case J_BBOX: v = p[L.p_R[c] + 9 * k + 3 * a + bb]; break;  // a = bbox row i, bb = pos component
+                case J_BBOX: v = p[L.pR(c) + 9 * k + 3 * a + bb]; break;  // a = bbox row i, bb = pos component
                 default: {  // J_FRIC: bb = force component
-                    const float* R = p + L.p_R[c] + 9 * k;
+                    const float* R = p + L.pR(c) + 9 * k;
                     const float sx = (face == 0 || face == 3) ? 1.f : -1.f, sy = face < 2 ? 1.f : -1.f;
                     v = sx * R[bb] + sy * R[3 + bb] - K.mu_fr * R[6 + bb];
                 } break;

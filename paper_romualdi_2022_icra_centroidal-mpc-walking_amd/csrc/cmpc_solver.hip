@@ -48,9 +48,13 @@ __device__ long long g_prof[32];
 __device__ float g_trace[64 * 8];  // per iteration of workgroup 0: mu, ep, ec, step, ap, ad, sigma, mu_t
 #define PROF_DECL long long pt_ = __builtin_amdgcn_s_memtime()
 #define PROF(slot) do { long long n_ = __builtin_amdgcn_s_memtime(); if (threadIdx.x == 0 && blockIdx.x == 0) g_prof[slot] += n_ - pt_; pt_ = n_; } while (0)
+#define PROF2_DECL long long pt2_ = __builtin_amdgcn_s_memtime()
+#define PROF2(slot) do { long long n_ = __builtin_amdgcn_s_memtime(); if (threadIdx.x == 0 && blockIdx.x == 0) g_prof[slot] += n_ - pt2_; pt2_ = n_; } while (0)
 #else
 #define PROF_DECL
 #define PROF(slot)
+#define PROF2_DECL
+#define PROF2(slot)
 #endif
 
 struct Ctx {
@@ -63,7 +67,7 @@ struct Ctx {
     float *Lf, *Ws, *lqs;  // per-stage factors: L^{-1} (packed lower), Ws = L^{-1} Qus, lq = L^{-1} qu
     float *geoA;           // N x GEO
     float *P0, *P1, *G, *T1, *QuuF, *Pan, *Bval, *Aval, *arow, *ybuf, *fpv, *fpn;
-    int *Brow, *Arow;
+    int *Brow, *Arow, *qmask;
     unsigned short* tri;
     double *QuuD, *pv, *pn, *qs, *Pd, *sig, *gco, *redd;
     float* red;
@@ -76,12 +80,15 @@ __device__ inline float gam_of(const Ctx& c, int ct, int k) { return c.sp[c.L.pG
 // reference stores vec(R) column-major: R(r,cc) = R[3*cc + r]
 __device__ inline float Rm(const float* R, int r, int cc) { return R[3 * cc + r]; }
 
-__device__ inline bool qfree(const Ctx& c, int k, int m)
+// a landing-offset component is a free variable in a swing stage whose box row is not an equality;
+// the 6-bit mask per stage is computed once per solve (the schedule is data)
+__device__ inline bool qfree_compute(const Ctx& c, int k, int m)
 {
     const int ct = m / 3, i = m % 3;
     const float lo = c.sp[c.L.pLo(ct) + 3 * k + i], hi = c.sp[c.L.pUp(ct) + 3 * k + i];
     return gam_of(c, ct, k) < 0.5f && (hi - lo) > 1e-9f;
 }
+__device__ inline bool qfree(const Ctx& c, int k, int m) { return (c.qmask[k] >> m) & 1; }
 __device__ inline float qlo(const Ctx& c, int k, int m) { return c.sp[c.L.pLo(m / 3) + 3 * k + m % 3]; }
 __device__ inline float qhi(const Ctx& c, int k, int m) { return c.sp[c.L.pUp(m / 3) + 3 * k + m % 3]; }
 
@@ -450,7 +457,7 @@ __device__ inline void stage_factor(const float* QuuF, const double* QuuD, float
 // ---- Riccati backward sweep (matrices + right-hand side of the affine step).
 // Returns (uniformly) 0 ok, 1 non-positive pivot. ----
 template <int NT>
-__device__ int riccati_backward(const Ctx& c, const CmpcConsts& prm, int tid, bool use_exact, float reg)
+__device__ int riccati_backward(const Ctx& c, const CmpcConsts& prm, int tid, bool use_exact, float reg, float cmu)
 {
     const int N = c.N;
     float* Pcur = c.P0;  // value function of stage k+1
@@ -517,7 +524,7 @@ __device__ int riccati_backward(const Ctx& c, const CmpcConsts& prm, int tid, bo
                 const double t = c.T[NI * k + i], z = c.Z[NI * k + i];
                 const double r = (double)row_val(c, prm, k, i, u) + t;
                 sg = z / t;
-                gc = sg * r;  // affine step: complementarity target 0
+                gc = (double)cmu / t + sg * r;  // complementarity target cmu (0: affine-scaling predictor)
             }
             c.sig[i] = sg; c.gco[i] = gc;
             if (i < 32) {
@@ -657,9 +664,7 @@ __device__ int riccati_backward(const Ctx& c, const CmpcConsts& prm, int tid, bo
         PROF(2);
         // ---- phase 3: fused Cholesky + panel solve (waves 0 and 1; each repeats the factorisation) ----
         if (tid < 128) {
-            int fixedmask = 0;
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) fixedmask |= qfree(c, k, q) ? 0 : (1 << q);
+            const int fixedmask = (~c.qmask[k]) & 63;
             stage_factor(c.QuuF, c.QuuD, c.Pan, c.Lf + (size_t)LP * k, c.Ws + (size_t)(NU * NS) * k, c.lqs + NU * k,
                          prm.D[0], prm.D[1], prm.D[2], c.flag, tid, fixedmask);
         }
@@ -751,10 +756,12 @@ __device__ void riccati_forward(const Ctx& c, const CmpcConsts& prm, int tid, bo
         const float D0 = prm.D[0], D1 = prm.D[1], D2 = prm.D[2];
         if (tid < NS) c.dS[tid] = 0.f;
         wave_lds_sync();
+        PROF2_DECL;
         for (int k = 0; k < N; ++k) {
             const float* Lf = c.Lf + (size_t)LP * k;
             const float* Ws = c.Ws + (size_t)(NU * NS) * k;
             float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+            PROF2(20);
             if (half == 0) {  // lq + Ws ds
                 s0 = c.lqs[NU * k + i];
 #pragma unroll
@@ -778,6 +785,7 @@ __device__ void riccati_forward(const Ctx& c, const CmpcConsts& prm, int tid, bo
             v += __shfl_xor(v, 32);
             if (tid < NU) c.ybuf[tid] = -v;
             wave_lds_sync();
+            PROF2(21);
             {   // du = Linv^T y : half 0 sums a = 0..14, half 1 a = 15..29
                 float t0 = 0.f, t1 = 0.f, t2 = 0.f;
                 const int a0 = 15 * half;
@@ -795,8 +803,10 @@ __device__ void riccati_forward(const Ctx& c, const CmpcConsts& prm, int tid, bo
                 if (tid < NU) c.dU[NU * k + tid] = w;
             }
             wave_lds_sync();
+            PROF2(22);
             if (tid < NS) c.dS[NS * (k + 1) + tid] = AB_step(c, prm, k, tid, c.dS + NS * k, c.dU + NU * k) + c.d[NS * k + tid];
             wave_lds_sync();
+            PROF2(23);
             (void)row;
         }
     }
@@ -825,10 +835,12 @@ __device__ void riccati_delta(const Ctx& c, const CmpcConsts& prm, int tid)
         bool havep = false;
         if (tid < NXA) c.fpv[tid] = 0.f;
         wave_lds_sync();
+        PROF2_DECL;
         for (int k = N - 1; k >= 0; --k) {
             const bool pk = k > 0;
             const float* Lf = c.Lf + (size_t)LP * k;
             const float* Ws = c.Ws + (size_t)(NU * NS) * k;
+            PROF2(24);
             if (tid < NU) {
                 float g;
                 if (tid < NF) {
@@ -849,6 +861,7 @@ __device__ void riccati_delta(const Ctx& c, const CmpcConsts& prm, int tid)
                 c.ybuf[tid] = g + Bt_vec<float>(c, prm, k, tid, c.fpv);
             }
             wave_lds_sync();
+            PROF2(25);
             {   // dl = Linv dq : two lanes per row
                 const int half = tid >> 5, i = (tid & 31) < NU ? (tid & 31) : 0;
                 const float* Li = Lf + lpk(i, 0);
@@ -870,6 +883,7 @@ __device__ void riccati_delta(const Ctx& c, const CmpcConsts& prm, int tid)
                 }
             }
             wave_lds_sync();
+            PROF2(26);
             if (tid < NXA) {
                 float v;
                 const float* dl = c.ybuf + 32;
@@ -901,6 +915,7 @@ __device__ void riccati_delta(const Ctx& c, const CmpcConsts& prm, int tid)
             if (tid < NXA) c.fpv[tid] = c.fpn[tid];
             havep = pk;
             wave_lds_sync();
+            PROF2(27);
         }
     }
     __syncthreads();
@@ -1014,6 +1029,7 @@ __global__ __launch_bounds__(NT, FG ? 2 : 1) void cmpc_solve_kernel(CmpcParams k
     c.Brow = reinterpret_cast<int*>(fp); fp += 3 * NU;
     c.Arow = reinterpret_cast<int*>(fp); fp += 3 * NS + 3;
     c.flag = reinterpret_cast<int*>(fp); fp += 4;
+    c.qmask = reinterpret_cast<int*>(fp); fp += CMPC_NMAX;
     c.tri = reinterpret_cast<unsigned short*>(fp); fp += NTRI / 2;
     if (FG) {
         c.Lf = kp.scratch + (size_t)b * kp.scratch_stride;
@@ -1036,6 +1052,13 @@ __global__ __launch_bounds__(NT, FG ? 2 : 1) void cmpc_solve_kernel(CmpcParams k
     {
         const float* gp = kp.P + (size_t)b * c.L.np();
         for (int e = tid; e < c.L.np(); e += NT) spw[e] = gp[e];
+    }
+    __syncthreads();
+    if (tid < N) {
+        int m = 0;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) m |= qfree_compute(c, tid, q) ? (1 << q) : 0;
+        c.qmask[tid] = m;
     }
     __syncthreads();
     // ---- initial iterate from x0 ----
@@ -1116,11 +1139,14 @@ __global__ __launch_bounds__(NT, FG ? 2 : 1) void cmpc_solve_kernel(CmpcParams k
         PROF(10);
         // ---- predictor (affine scaling): factorise; on a non-positive pivot fall back to the
         // Gauss-Newton Hessian, then to a larger Levenberg shift ----
+        // once the complementarity products sit at the barrier floor the predictor has nothing to predict
+        // (sigma ~ 0, second-order term ~ 0): take plain centring Newton steps, one sweep pair instead of three
+        const bool centring = !finishing && mu_cur <= 1.5f * prm.mu_min && ec <= 4.f * prm.mu_min;
         bool exact = prm.exact_hessian != 0;
         float reg = prm.reg;
         int fail = 1;
         for (int attempt = 0; attempt < 4; ++attempt) {
-            fail = riccati_backward<NT>(c, prm, tid, exact, reg);
+            fail = riccati_backward<NT>(c, prm, tid, exact, reg, centring ? prm.mu_min : 0.f);
             if (!fail) break;
             __syncthreads();
             ++gn; exact = false;
@@ -1128,9 +1154,15 @@ __global__ __launch_bounds__(NT, FG ? 2 : 1) void cmpc_solve_kernel(CmpcParams k
         }
         if (fail) { status = 2; break; }
         PROF(11);
+        float ap, ad, sigma = 0.f, mu_t = prm.mu_min;
+        if (centring) {
+            for (int e = tid; e < NI * N; e += NT) c.dZ[e] = row_active(c, e / NI, e % NI) ? prm.mu_min : 0.f;
+            __syncthreads();
+            riccati_forward<NT>(c, prm, tid, false);
+            PROF(15);
+        } else {
         riccati_forward<NT>(c, prm, tid, true);
         PROF(12);
-        float ap, ad;
         if (finishing) {
             // last step: affine-scaling extrapolation of the central path to mu = 0 (primal only)
             step_lengths<NT>(c, tid, 0.999f, ap, ad);
@@ -1145,9 +1177,9 @@ __global__ __launch_bounds__(NT, FG ? 2 : 1) void cmpc_solve_kernel(CmpcParams k
         for (int e = tid; e < NI * N; e += NT)
             if (row_active(c, e / NI, e % NI)) l_aff += (double)(c.T[e] + ap * c.dT[e]) * (double)(c.Z[e] + ad * c.dZ[e]);
         const float mu_aff = (float)(block_sum<NT>(l_aff, c.redd, tid) / (double)nrow);
-        float sigma = mu_aff / mu_cur;
+        sigma = mu_aff / mu_cur;
         sigma = sigma * sigma * sigma;
-        const float mu_t = fmaxf(sigma * mu_cur, prm.mu_min);
+        mu_t = fmaxf(sigma * mu_cur, prm.mu_min);
         // ---- corrector ----
         for (int e = tid; e < NI * N; e += NT)
             c.dZ[e] = row_active(c, e / NI, e % NI) ? mu_t - c.dT[e] * c.dZ[e] : 0.f;  // complementarity target
@@ -1157,6 +1189,7 @@ __global__ __launch_bounds__(NT, FG ? 2 : 1) void cmpc_solve_kernel(CmpcParams k
         PROF(14);
         riccati_forward<NT>(c, prm, tid, false);
         PROF(15);
+        }
         step_lengths<NT>(c, tid, fmaxf(0.99f, 1.f - mu_t), ap, ad);
         // ---- costates, then the iterate ----
         costate_update(c, prm, tid, ap, exact);
@@ -1237,7 +1270,7 @@ extern "C" size_t cmpc_solver_lds_bytes(int N, int factors_global)
     const size_t flt = (size_t)NU * RLD + (size_t)NPAN * RLD + ((L.np + 3) & ~3)
                        + 2 * ((size_t)NS * (N + 1) + (size_t)NU * N + 2 * (size_t)NI * N) + (size_t)NS * N + (size_t)NU * N
                        + (size_t)GEO * N + 2 * NXA * PLD + NXA * GLD + NS * NS + 3 * NU + 3 * NS + 3 + 96 + 12 + 64 + 40 + 40 + 8
-                       + 3 * NU + 3 * NS + 3 + 4 + NTRI / 2 + (factors_global ? 0 : (size_t)LP * N + (size_t)NU * NS * N);
+                       + 3 * NU + 3 * NS + 3 + 4 + CMPC_NMAX + NTRI / 2 + (factors_global ? 0 : (size_t)LP * N + (size_t)NU * NS * N);
     return ((sizeof(CmpcConsts) + 15) & ~(size_t)15) + dbl * 8 + flt * 4;
 }
 
