@@ -140,7 +140,7 @@ int cmpc_create(const cmpc_config* cfg, int batch, int device, cmpc_handle* out)
     }
     if (fg) {
         h->lds = cmpc_solver_lds_bytes(cfg->horizon, 1);
-        h->scratch_stride = (long long)(CMPC_LP + CMPC_NU * CMPC_NS) * cfg->horizon;
+        h->scratch_stride = (long long)CMPC_REC_N * cfg->horizon;
     }
     if (h->lds > 160 * 1024) {
         const int n = cfg->horizon;
@@ -148,7 +148,11 @@ int cmpc_create(const cmpc_config* cfg, int batch, int device, cmpc_handle* out)
         return fail(nullptr, CMPC_ERR_ARG, "cmpc_create: horizon " + std::to_string(n) + " needs more than 160 KiB of LDS per problem");
     }
     HIPCHK(h, hipSetDevice(device));
-    if (fg) HIPCHK(h, hipMalloc(&h->dScratch, sizeof(float) * (size_t)h->scratch_stride * (size_t)batch));
+    if (fg) {
+        // the factor records rely on never-written zero blocks (layout: cmpc_solver.hip): zero once
+        HIPCHK(h, hipMalloc(&h->dScratch, sizeof(float) * (size_t)h->scratch_stride * (size_t)batch));
+        HIPCHK(h, hipMemset(h->dScratch, 0, sizeof(float) * (size_t)h->scratch_stride * (size_t)batch));
+    }
     HIPCHK(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     HIPCHK(h, hipEventCreate(&h->ev0));
     HIPCHK(h, hipEventCreate(&h->ev1));
@@ -204,6 +208,17 @@ static void fill_consts(cmpc_handle h, CmpcConsts& q)
         for (int i = 1; i < 3; ++i) dmin = std::min(dmin, 2.0 * c.force_rate_of_change_weight[i]);
         q.reg = (float)std::max(1e-5, 5e-5 * dmin);
         if (const char* e = std::getenv("CMPC_REG")) q.reg = (float)std::atof(e);  // developer knob
+    }
+    // Mehrotra's sigma = (mu_aff/mu)^3 can ask for a 1000-fold barrier decrease in one step; the linearisation
+    // does not hold that far and the blocked step costs the problem 3-6 extra iterations.  A floor of 0.03
+    // costs +0.3 iterations on the mean of config 2 and removes the tail (max 11 -> 8 of 4096 problems; config 3:
+    // mean 8.60 -> 8.49, max 14 -> 12), and a batch is as slow as its slowest problem.
+    q.sigma_min = 0.03f;
+    if (const char* e = std::getenv("CMPC_SIGMA_MIN")) q.sigma_min = (float)std::atof(e);  // developer knob
+    for (int i = 0; i < 4; ++i) {
+        q.dev[i] = 0.f;
+        const std::string nm = "CMPC_DEV" + std::to_string(i);
+        if (const char* e = std::getenv(nm.c_str())) q.dev[i] = (float)std::atof(e);
     }
 }
 

@@ -9,6 +9,7 @@
 #define CMPC_NXA 39  // NS + NF: the previous force rides along as state (force-rate cost)
 #define CMPC_NI 44   // inequality rows per stage: 32 friction + 6 q upper + 6 q lower
 #define CMPC_LP 465  // packed lower triangle of a 30x30
+#define CMPC_REC_N 1056  // floats of one stage's factor record (layout: cmpc_solver.hip)
 #define CMPC_NMAX 40 // largest horizon the kernels are built for
 #define CMPC_INFO_N 8
 
@@ -56,8 +57,10 @@ struct CmpcConsts {
     float D[3];                  // 2 * force_rate_of_change_weight
     float tol, step_tol, mu_init, mu_min;
     float reg;                   // Levenberg shift on the diagonal of every stage Hessian Quu
+    float sigma_min;             // lower bound of Mehrotra's centring parameter (caps the barrier decrease per iteration)
     float corners[24];           // [c][j][3]
     float wz2[CMPC_NMAX + 1];    // 2 w_z(k)^2, w_z(k) = (w_cz/2)(1+exp(-k))
+    float dev[4];                // developer knobs (env CMPC_DEV0..3), 0 in production
 };
 
 // The same layout as closed-form index functions.  Device code uses these: indexing the offset arrays

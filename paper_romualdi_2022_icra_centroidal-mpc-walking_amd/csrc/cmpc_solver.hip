@@ -39,6 +39,17 @@
 #define NPAN 46    // panel rows: 15 (Qus^T) + 30 (I) + 1 (qu)
 #define GEO 36     // floats of stage geometry: r[24] | Fc[6] | Fsum[3] | pad
 #define NTRI 780   // lower-triangular entries of a 39x39
+// Per-stage factor record (floats), in LDS or -- FG kernels -- in HBM scratch:
+//   [REC_LB, +576)  L^{-1}, lower triangle in 4x4 blocks: block-row I (rows 4I..4I+3) stores its I+1 blocks row by
+//                   row, so row r is 4(I+1) contiguous floats on a 16-byte boundary and column walks stay inside
+//                   one bank sweep.  Entries above the diagonal inside a diagonal block, and rows 30, 31, are zero
+//                   and never written: row 31 doubles as the zero block (REC_ZERO) that out-of-triangle reads hit.
+//   [REC_WS, +480)  30 rows x 16: Ws[a][0..14] = (L^{-1} Qus)[a][:], slot 15 = lq[a] = (L^{-1} qu)[a]; the
+//                   float4 index of a row is XOR-swizzled with (a >> 2) & 3 (conflict-free 16-byte row reads)
+#define REC_LB 0
+#define REC_WS 576
+#define REC_ZERO 544
+#define REC_N CMPC_REC_N
 
 namespace {
 
@@ -64,7 +75,7 @@ struct Ctx {
     float *S, *U, *T, *Z;
     double* LAM;
     float *dS, *dU, *dT, *dZ, *d;
-    float *Lf, *Ws, *lqs;  // per-stage factors: L^{-1} (packed lower), Ws = L^{-1} Qus, lq = L^{-1} qu
+    float *Lf;             // per-stage factor records (REC_N floats each)
     float *geoA;           // N x GEO
     float *P0, *P1, *G, *T1, *QuuF, *Pan, *Bval, *Aval, *arow, *ybuf, *fpv, *fpn;
     int *Brow, *Arow, *qmask;
@@ -74,7 +85,62 @@ struct Ctx {
     int* flag;
 };
 
-__device__ inline void wave_lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+// LDS operations of one wave execute in issue order, so a write followed by reads of other lanes of the
+// SAME wave needs no wait, only a fence for the compiler
+__device__ inline void wave_lds_sync() { asm volatile("" ::: "memory"); }
+
+// carve the workgroup's LDS image (constants first, then doubles, then 16-byte aligned float panels).
+// Pure address arithmetic: every phase function rebuilds it instead of receiving it, so that the
+// out-of-line phases have a register allocation of their own.
+template <bool FG>
+__device__ inline void make_ctx(Ctx& c, char* smem, int N, float* fg_base)
+{
+    constexpr int KBYTES = (sizeof(CmpcConsts) + 15) & ~15;
+    c.L.N = N;
+    c.N = N;
+    double* dp = reinterpret_cast<double*>(smem + KBYTES);
+    c.LAM = dp; dp += NS * (N + 1) + ((NS * (N + 1)) & 1);
+    c.QuuD = dp; dp += 90;
+    c.pv = dp; dp += 40; c.pn = dp; dp += 40; c.qs = dp; dp += 16; c.Pd = dp; dp += 40;
+    c.sig = dp; dp += NI; c.gco = dp; dp += NI; c.redd = dp; dp += 8;
+    float* fp = reinterpret_cast<float*>(dp);
+    c.QuuF = fp; fp += NU * RLD;
+    c.Pan = fp; fp += NPAN * RLD;
+    c.ybuf = fp; fp += 96;          // 16-byte aligned vector staging of the sweeps
+    if (!FG) { c.Lf = fp; fp += (size_t)REC_N * N; } else c.Lf = fg_base;
+    c.sp = fp; fp += (c.L.np() + 3) & ~3;
+    c.S = fp; fp += NS * (N + 1); c.U = fp; fp += NU * N; c.T = fp; fp += NI * N; c.Z = fp; fp += NI * N;
+    c.dS = fp; fp += NS * (N + 1); c.dU = fp; fp += NU * N; c.dT = fp; fp += NI * N; c.dZ = fp; fp += NI * N;
+    c.d = fp; fp += NS * N;
+    c.geoA = fp; fp += GEO * N;
+    c.P0 = fp; fp += NXA * PLD; c.P1 = fp; fp += NXA * PLD;
+    c.G = fp; fp += NXA * GLD; c.T1 = fp; fp += NS * NS;
+    c.Bval = fp; fp += 3 * NU; c.Aval = fp; fp += 3 * NS + 3;
+    c.arow = fp; fp += 96 + 12; c.fpv = fp; fp += 40; c.fpn = fp; fp += 40; c.red = fp; fp += 8;
+    c.Brow = reinterpret_cast<int*>(fp); fp += 3 * NU;
+    c.Arow = reinterpret_cast<int*>(fp); fp += 3 * NS + 3;
+    c.flag = reinterpret_cast<int*>(fp); fp += 4;
+    c.qmask = reinterpret_cast<int*>(fp); fp += CMPC_NMAX;
+    c.tri = reinterpret_cast<unsigned short*>(fp); fp += NTRI / 2;
+}
+
+__device__ inline int lb_row(int r) { const int I = r >> 2; return REC_LB + 8 * I * (I + 1) + (r & 3) * 4 * (I + 1); }
+__device__ inline int ws_idx(int a, int j) { return REC_WS + 16 * a + 4 * ((j >> 2) ^ ((a >> 2) & 3)) + (j & 3); }
+// sum of the two 32-lane halves of a wave, in every lane (gfx950 v_permlane32_swap)
+__device__ inline float half_sum(float v)
+{
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+// sum over aligned groups of 8 lanes, in every lane of the group (DPP, no LDS)
+__device__ inline float oct_sum(float v)
+{
+    v += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+    v += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+    v += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x141, 0xF, 0xF, true));  // row_half_mirror
+    return v;
+}
+__device__ inline float dot4(const float4& a, const float4& b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
 
 __device__ inline float gam_of(const Ctx& c, int ct, int k) { return c.sp[c.L.pGam(ct) + k]; }
 // reference stores vec(R) column-major: R(r,cc) = R[3*cc + r]
@@ -404,7 +470,7 @@ __device__ inline bool chol_solve_fused(float (&v)[NU], double (&dd)[3], int lan
 
 // phase 3 of a backward stage, kept out of line so that its ~40 VGPRs of matrix rows and its
 // stream of v_readlane broadcasts get a register allocation of their own
-__device__ inline void stage_factor(const float* QuuF, const double* QuuD, float* Pan, float* Lf, float* Ws, float* lq,
+__device__ inline void stage_factor(const float* QuuF, const double* QuuD, float* Pan, float* rec,
                                           float D0, float D1, float D2, int* flag, int tid, int fixedmask)
 {
     const int lane = tid & 63, wv = tid >> 6;
@@ -439,24 +505,24 @@ __device__ inline void stage_factor(const float* QuuF, const double* QuuD, float
     if (!isL && active) {
         if (prow < NS) {
 #pragma unroll
-            for (int a = 0; a < NU; ++a) { Ws[a * NS + prow] = v[a]; Pan[prow * RLD + a] = v[a]; }
+            for (int a = 0; a < NU; ++a) { rec[ws_idx(a, prow)] = v[a]; Pan[prow * RLD + a] = v[a]; }
         } else if (prow < NS + NU) {
             const int m = prow - NS;
             const float dm = (m % 3 == 0) ? D0 : ((m % 3 == 1) ? D1 : D2);
             const float sc = m < NF ? -dm : 0.f;
 #pragma unroll
             for (int a = 0; a < NU; ++a)
-                if (a >= m) { Lf[lpk(a, m)] = v[a]; Pan[prow * RLD + a] = sc * v[a]; }
+                if (a >= m) { rec[lb_row(a) + m] = v[a]; Pan[prow * RLD + a] = sc * v[a]; }
         } else {
 #pragma unroll
-            for (int a = 0; a < NU; ++a) { lq[a] = v[a]; Pan[prow * RLD + a] = v[a]; }
+            for (int a = 0; a < NU; ++a) { rec[ws_idx(a, 15)] = v[a]; Pan[prow * RLD + a] = v[a]; }
         }
     }
 }
 
 // ---- Riccati backward sweep (matrices + right-hand side of the affine step).
 // Returns (uniformly) 0 ok, 1 non-positive pivot. ----
-template <int NT>
+template <int NT, int NC, bool FG>
 __device__ int riccati_backward(const Ctx& c, const CmpcConsts& prm, int tid, bool use_exact, float reg, float cmu)
 {
     const int N = c.N;
@@ -665,8 +731,7 @@ __device__ int riccati_backward(const Ctx& c, const CmpcConsts& prm, int tid, bo
         // ---- phase 3: fused Cholesky + panel solve (waves 0 and 1; each repeats the factorisation) ----
         if (tid < 128) {
             const int fixedmask = (~c.qmask[k]) & 63;
-            stage_factor(c.QuuF, c.QuuD, c.Pan, c.Lf + (size_t)LP * k, c.Ws + (size_t)(NU * NS) * k, c.lqs + NU * k,
-                         prm.D[0], prm.D[1], prm.D[2], c.flag, tid, fixedmask);
+            stage_factor(c.QuuF, c.QuuD, c.Pan, c.Lf + (size_t)REC_N * k, prm.D[0], prm.D[1], prm.D[2], c.flag, tid, fixedmask);
         }
         __syncthreads();
         PROF(3);
@@ -744,70 +809,118 @@ __device__ int riccati_backward(const Ctx& c, const CmpcConsts& prm, int tid, bo
 }
 
 // ---- forward sweep on wave 0: dS, dU.  All threads then compute dT, dZ (dZ holds the per-row
-// complementarity target on entry unless affine). ----
+// complementarity target on entry unless affine).
+// Per stage:  y = [Ws lq | -L^{-1}[:, :24] D] [ds; 1; du_prev]   (two lanes per row, 16-byte reads)
+//             du = -L^{-T} y                                      (two lanes per column)
+//             ds+ = A ds + B du + d                               (9 + 6 lanes, corner sums by DPP)
+// Matrix operands do not depend on the recursion: they are read at the top of the stage. ----
 template <int NT>
 __device__ void riccati_forward(const Ctx& c, const CmpcConsts& prm, int tid, bool affine)
 {
     const int N = c.N;
     if (tid < 64) {
-        // two lanes per row (lane i and lane i+32 each sum half of the terms, then one __shfl_xor)
-        const int half = tid >> 5, i = (tid & 31) < NU ? (tid & 31) : 0;
-        const bool row = (tid & 31) < NU;
-        const float D0 = prm.D[0], D1 = prm.D[1], D2 = prm.D[2];
+        const int r = tid & 31, half = tid >> 5, blk = r >> 2;
+        float* xb = c.ybuf;       // [ds (15), 1, -D du_prev (24)]
+        float* yb = c.ybuf + 40;  // y (32)
+        // per-lane offsets inside a stage record (loop invariant)
+        int moff[5], xoff[5], coff[16];
+#pragma unroll
+        for (int t = 0; t < 5; ++t) {
+            int mo, xo;
+            if (half == 0) {
+                mo = t < 4 ? REC_WS + 16 * r + 4 * (t ^ (blk & 3)) : lb_row(r);
+                xo = 4 * t;
+            } else {
+                const int q4 = t + 1;
+                mo = q4 <= blk ? lb_row(r) + 4 * q4 : REC_ZERO;
+                xo = 16 + 4 * q4;
+            }
+            moff[t] = r < NU ? mo : REC_ZERO;
+            xoff[t] = xo;
+        }
+#pragma unroll
+        for (int aa = 0; aa < 16; ++aa) {
+            const int a = 16 * half + aa;
+            coff[aa] = blk <= (a >> 2) ? lb_row(a) + r : REC_ZERO;
+        }
+        // roles in the dynamics step
+        const int ga = tid >> 3, cj = tid & 7;              // lanes 0..23: axis ga of corner cj
+        const int ga1 = (ga + 1) % 3, ga2 = (ga + 2) % 3;
+        const int qb = tid - 24, qct = qb >= 3 ? 1 : 0, qa = qb - 3 * qct;  // lanes 24..29: position row 9 + qb
+        const float Dm = prm.D[r % 3];
+        if (tid < 40) xb[tid] = tid == 15 ? 1.f : 0.f;
         if (tid < NS) c.dS[tid] = 0.f;
         wave_lds_sync();
         PROF2_DECL;
         for (int k = 0; k < N; ++k) {
-            const float* Lf = c.Lf + (size_t)LP * k;
-            const float* Ws = c.Ws + (size_t)(NU * NS) * k;
-            float s0 = 0.f, s1 = 0.f, s2 = 0.f;
-            PROF2(20);
-            if (half == 0) {  // lq + Ws ds
-                s0 = c.lqs[NU * k + i];
+            const float* rec = c.Lf + (size_t)REC_N * k;
+            float4 m[5];
+            float cl[16];
 #pragma unroll
-                for (int a = 0; a < NS; a += 3) {
-                    s0 += Ws[i * NS + a] * c.dS[NS * k + a];
-                    s1 += Ws[i * NS + a + 1] * c.dS[NS * k + a + 1];
-                    s2 += Ws[i * NS + a + 2] * c.dS[NS * k + a + 2];
-                }
-            } else if (k > 0) {  // Wp dp = -Linv[:, :24] D dp  (loads past the row end are masked, not skipped)
-                const float* dp = c.dU + NU * (k - 1);
-                const float* Li = Lf + lpk(i, 0);
+            for (int t = 0; t < 5; ++t) m[t] = *reinterpret_cast<const float4*>(rec + moff[t]);
 #pragma unroll
-                for (int a = 0; a < NF; a += 3) {
-                    const float l0 = Li[a], l1 = Li[a + 1], l2 = Li[a + 2];
-                    s0 -= (a <= i ? l0 : 0.f) * D0 * dp[a];
-                    s1 -= (a + 1 <= i ? l1 : 0.f) * D1 * dp[a + 1];
-                    s2 -= (a + 2 <= i ? l2 : 0.f) * D2 * dp[a + 2];
-                }
+            for (int aa = 0; aa < 16; ++aa) cl[aa] = rec[coff[aa]];
+            // stage data of the dynamics step (independent of the recursion as well)
+            const float* geo = c.geoA + GEO * k;
+            const float gam0 = gam_of(c, 0, k), gam1 = gam_of(c, 1, k);
+            float g_r1 = 0.f, g_r2 = 0.f, g_dt = 0.f, dk = 0.f;
+            if (tid < 24) {
+                g_r1 = geo[3 * cj + ga1]; g_r2 = geo[3 * cj + ga2];
+                g_dt = prm.dt * (cj < 4 ? gam0 : gam1);
             }
-            float v = s0 + s1 + s2;
-            v += __shfl_xor(v, 32);
-            if (tid < NU) c.ybuf[tid] = -v;
+            PROF2(20);
+            float4 xv[5];
+#pragma unroll
+            for (int t = 0; t < 5; ++t) xv[t] = *reinterpret_cast<const float4*>(xb + xoff[t]);
+            const float y = half_sum((dot4(m[0], xv[0]) + dot4(m[1], xv[1])) + (dot4(m[2], xv[2]) + dot4(m[3], xv[3])) + dot4(m[4], xv[4]));
+            if (tid < 32) yb[r] = y;
             wave_lds_sync();
             PROF2(21);
-            {   // du = Linv^T y : half 0 sums a = 0..14, half 1 a = 15..29
-                float t0 = 0.f, t1 = 0.f, t2 = 0.f;
-                const int a0 = 15 * half;
+            float w = 0.f;
 #pragma unroll
-                for (int aa = 0; aa < 15; aa += 3) {
-                    const int a = a0 + aa;
-                    const float l0 = Lf[lpk(a, 0) + (i <= a ? i : 0)], l1 = Lf[lpk(a + 1, 0) + (i <= a + 1 ? i : 0)],
-                                l2 = Lf[lpk(a + 2, 0) + (i <= a + 2 ? i : 0)];
-                    t0 += (a >= i ? l0 : 0.f) * c.ybuf[a];
-                    t1 += (a + 1 >= i ? l1 : 0.f) * c.ybuf[a + 1];
-                    t2 += (a + 2 >= i ? l2 : 0.f) * c.ybuf[a + 2];
-                }
-                float w = t0 + t1 + t2;
-                w += __shfl_xor(w, 32);
-                if (tid < NU) c.dU[NU * k + tid] = w;
+            for (int q = 0; q < 4; ++q) {
+                const float4 yv = *reinterpret_cast<const float4*>(yb + 16 * half + 4 * q);
+                w += cl[4 * q] * yv.x + cl[4 * q + 1] * yv.y + cl[4 * q + 2] * yv.z + cl[4 * q + 3] * yv.w;
             }
+            const float du = -half_sum(w);
+            if (tid < NU) c.dU[NU * k + tid] = du;
             wave_lds_sync();
             PROF2(22);
-            if (tid < NS) c.dS[NS * (k + 1) + tid] = AB_step(c, prm, k, tid, c.dS + NS * k, c.dU + NU * k) + c.d[NS * k + tid];
+            // ---- ds+ = A ds + B du + d ----
+            float tD = 0.f, tH = 0.f;
+            const float* duk = c.dU + NU * k;
+            if (tid < 24) {
+                tD = g_dt * duk[3 * cj + ga];
+                tH = g_dt * (g_r1 * duk[3 * cj + ga2] - g_r2 * duk[3 * cj + ga1]);
+            }
+            tD = oct_sum(tD);
+            tH = oct_sum(tH);
+            float out = 0.f;
+            int row = -1;
+            if (tid < 24) {
+                if (cj == 0) { row = ga; out = xb[ga] + prm.dt * xb[3 + ga]; }
+                else if (cj == 1) { row = 3 + ga; out = xb[3 + ga] + tD; }
+                else if (cj == 2) {
+                    row = 6 + ga;
+                    const float* F0 = geo + 24;
+                    const float* F1 = geo + 27;
+                    const float e01 = xb[9 + ga1] - xb[ga1], e02 = xb[9 + ga2] - xb[ga2];
+                    const float e11 = xb[12 + ga1] - xb[ga1], e12 = xb[12 + ga2] - xb[ga2];
+                    out = xb[6 + ga] + tH + prm.dt * (gam0 * (e01 * F0[ga2] - e02 * F0[ga1]) + gam1 * (e11 * F1[ga2] - e12 * F1[ga1]));
+                }
+            } else if (tid < 30) {
+                const float* R = c.sp + c.L.pR(qct) + 9 * k;
+                const float gam = qct ? gam1 : gam0;
+                row = 9 + qb;
+                out = gam * xb[9 + qb]
+                      + (1.f - gam) * (Rm(R, qa, 0) * duk[24 + 3 * qct] + Rm(R, qa, 1) * duk[25 + 3 * qct] + Rm(R, qa, 2) * duk[26 + 3 * qct]);
+            }
+            if (row >= 0) dk = c.d[NS * k + row];
+            wave_lds_sync();
+            if (row >= 0) { out += dk; c.dS[NS * (k + 1) + row] = out; xb[row] = out; }
+            if (tid < NF) xb[16 + tid] = -Dm * du;
             wave_lds_sync();
             PROF2(23);
-            (void)row;
         }
     }
     __syncthreads();
@@ -826,94 +939,104 @@ __device__ void riccati_forward(const Ctx& c, const CmpcConsts& prm, int tid, bo
     __syncthreads();
 }
 
-// ---- corrector right-hand side on wave 0: the row coefficients change by CMU/t (dZ holds CMU);
-// updates lq in place through the stored factors ----
+// ---- corrector right-hand side on wave 0: the row coefficients change by w = CMU / t.  On entry dT
+// holds w (0 on inactive rows).  Updates lq (slot 15 of the Ws rows) in place through the stored factors.
+// Per stage:  g = C^T w + fp_p + B^T fp_s ;  dl = L^{-1} g ;  lq += dl ;
+//             fp_s <- A^T fp_s - Ws^T dl ;  fp_p <- D L^{-T} dl ----
 __device__ void riccati_delta(const Ctx& c, const CmpcConsts& prm, int tid)
 {
     const int N = c.N;
     if (tid < 64) {
-        bool havep = false;
+        const int r = tid & 31, half = tid >> 5, blk = r >> 2;
+        float* gb = c.ybuf;        // g (32)
+        float* lb = c.ybuf + 32;   // dl (32)
+        int moff[4], doff[32];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int q4 = 4 * half + t;
+            moff[t] = (r < NU && q4 <= blk) ? lb_row(r) + 4 * q4 : REC_ZERO;
+        }
+        // lanes 0..31: column r of L^{-1} (outputs fp_p);  lanes 32..47: column r of [Ws | lq] (outputs fp_s)
+#pragma unroll
+        for (int a = 0; a < 32; ++a)
+            doff[a] = half == 0 ? (blk <= (a >> 2) ? lb_row(a) + r : REC_ZERO) : ((a < NU && r < 16) ? ws_idx(a, r) : REC_ZERO);
+        // A^T row roles of lanes 32..46 (state index j = r): out = s v[j] + ce v[je] + cg (v[6+a1] F[a2] - v[6+a2] F[a1])
+        const int j = r;
+        const int ja = j < 3 ? j : (j >= 9 ? (j - 9) % 3 : 0), ja1 = (ja + 1) % 3, ja2 = (ja + 2) % 3;
+        const int jct = j >= 12 ? 1 : 0;
+        const int foff = j < 3 ? 30 : 24 + 3 * jct;   // Fsum or Fc of the foot (geometry record)
+        const int je = (j >= 3 && j < 6) ? j - 3 : 0;
+        // B^T roles of lanes 0..29
+        const int fa = tid % 3, fa1 = (fa + 1) % 3, fa2 = (fa + 2) % 3, fcj = tid / 3;   // force component tid < 24
+        const int qq = tid - 24, qct = qq >= 3 ? 1 : 0, qa = qq - 3 * qct;               // offset component 24 <= tid < 30
+        const float Dm = prm.D[r % 3];
         if (tid < NXA) c.fpv[tid] = 0.f;
+        if (tid < 32) { gb[tid] = 0.f; }
         wave_lds_sync();
         PROF2_DECL;
         for (int k = N - 1; k >= 0; --k) {
-            const bool pk = k > 0;
-            const float* Lf = c.Lf + (size_t)LP * k;
-            const float* Ws = c.Ws + (size_t)(NU * NS) * k;
-            PROF2(24);
-            if (tid < NU) {
-                float g;
-                if (tid < NF) {
-                    const int r0 = 4 * (tid / 3);
-                    g = 0.f;
+            float* rec = c.Lf + (size_t)REC_N * k;
+            float4 m[4];
 #pragma unroll
-                    for (int f = 0; f < 4; ++f) {
-                        float a0, a1, a2;
-                        fric_row(c, prm, k, r0 + f, a0, a1, a2);
-                        const float av = (tid % 3 == 0) ? a0 : ((tid % 3 == 1) ? a1 : a2);
-                        g += c.dZ[NI * k + r0 + f] / c.T[NI * k + r0 + f] * av;
-                    }
-                    if (havep) g += c.fpv[NS + tid];
-                } else {
-                    const int q = tid - 24;
-                    g = qfree(c, k, q) ? c.dZ[NI * k + 32 + q] / c.T[NI * k + 32 + q] - c.dZ[NI * k + 38 + q] / c.T[NI * k + 38 + q] : 0.f;
-                }
-                c.ybuf[tid] = g + Bt_vec<float>(c, prm, k, tid, c.fpv);
+            for (int t = 0; t < 4; ++t) m[t] = *reinterpret_cast<const float4*>(rec + moff[t]);
+            float cd[32];
+#pragma unroll
+            for (int a = 0; a < 32; ++a) cd[a] = rec[doff[a]];
+            const float* geo = c.geoA + GEO * k;
+            const float* wk = c.dT + NI * k;
+            const float gam0 = gam_of(c, 0, k), gam1 = gam_of(c, 1, k);
+            PROF2(24);
+            // ---- g ----
+            if (tid < NF) {
+                const float* R = c.sp + c.L.pR(fcj >> 2) + 9 * k;
+                const float w0 = wk[4 * fcj], w1 = wk[4 * fcj + 1], w2 = wk[4 * fcj + 2], w3 = wk[4 * fcj + 3];
+                // sum_f w_f R (sx_f, sy_f, -mu)^T,  (sx, sy) = (+,+), (-,+), (-,-), (+,-)
+                const float wx = w0 - w1 - w2 + w3, wy = w0 + w1 - w2 - w3, ws = w0 + w1 + w2 + w3;
+                float g = Rm(R, fa, 0) * wx + Rm(R, fa, 1) * wy - prm.mu_fr * Rm(R, fa, 2) * ws;
+                const float* rr = geo + 3 * fcj;
+                const float* v = c.fpv;
+                g += v[NS + tid] + prm.dt * (fcj < 4 ? gam0 : gam1) * (v[3 + fa] + v[6 + fa1] * rr[fa2] - v[6 + fa2] * rr[fa1]);
+                gb[tid] = g;
+            } else if (tid < NU) {
+                const float* R = c.sp + c.L.pR(qct) + 9 * k;
+                const float* v = c.fpv + 9 + 3 * qct;
+                float g = wk[32 + qq] - wk[38 + qq];
+                if (qfree(c, k, qq)) g += (1.f - (qct ? gam1 : gam0)) * (Rm(R, 0, qa) * v[0] + Rm(R, 1, qa) * v[1] + Rm(R, 2, qa) * v[2]);
+                gb[tid] = g;
             }
             wave_lds_sync();
             PROF2(25);
-            {   // dl = Linv dq : two lanes per row
-                const int half = tid >> 5, i = (tid & 31) < NU ? (tid & 31) : 0;
-                const float* Li = Lf + lpk(i, 0);
-                float t0 = 0.f, t1 = 0.f, t2 = 0.f;
-                const int a0 = 15 * half;
+            // ---- dl = L^{-1} g ----
+            float4 gv[4];
 #pragma unroll
-                for (int aa = 0; aa < 15; aa += 3) {
-                    const int a = a0 + aa;
-                    const float l0 = Li[a <= i ? a : 0], l1 = Li[a + 1 <= i ? a + 1 : 0], l2 = Li[a + 2 <= i ? a + 2 : 0];
-                    t0 += (a <= i ? l0 : 0.f) * c.ybuf[a];
-                    t1 += (a + 1 <= i ? l1 : 0.f) * c.ybuf[a + 1];
-                    t2 += (a + 2 <= i ? l2 : 0.f) * c.ybuf[a + 2];
-                }
-                float v = t0 + t1 + t2;
-                v += __shfl_xor(v, 32);
-                if (tid < NU) {
-                    c.ybuf[32 + tid] = v;
-                    c.lqs[NU * k + tid] += v;
-                }
-            }
+            for (int t = 0; t < 4; ++t) gv[t] = *reinterpret_cast<const float4*>(gb + 16 * half + 4 * t);
+            const float dl = half_sum((dot4(m[0], gv[0]) + dot4(m[1], gv[1])) + (dot4(m[2], gv[2]) + dot4(m[3], gv[3])));
+            if (tid < 32) lb[r] = dl;
+            if (tid < NU) rec[ws_idx(tid, 15)] += dl;
             wave_lds_sync();
             PROF2(26);
-            if (tid < NXA) {
-                float v;
-                const float* dl = c.ybuf + 32;
-                if (tid < NS) {
-                    float t0 = At_vec<float>(c, prm, k, tid, c.fpv), t1 = 0.f, t2 = 0.f;
+            // ---- fp ----
+            float s0 = 0.f, s1 = 0.f;
 #pragma unroll
-                    for (int a = 0; a < NU; a += 3) {
-                        t0 -= Ws[a * NS + tid] * dl[a];
-                        t1 -= Ws[(a + 1) * NS + tid] * dl[a + 1];
-                        t2 -= Ws[(a + 2) * NS + tid] * dl[a + 2];
-                    }
-                    v = t0 + t1 + t2;
-                } else if (pk) {
-                    const int m = tid - NS;
-                    float t0 = 0.f, t1 = 0.f, t2 = 0.f;
-#pragma unroll
-                    for (int a = 0; a < NU; a += 3) {
-                        const float l0 = Lf[lpk(a, 0) + (m <= a ? m : 0)], l1 = Lf[lpk(a + 1, 0) + (m <= a + 1 ? m : 0)],
-                                    l2 = Lf[lpk(a + 2, 0) + (m <= a + 2 ? m : 0)];
-                        t0 += (a >= m ? l0 : 0.f) * dl[a];
-                        t1 += (a + 1 >= m ? l1 : 0.f) * dl[a + 1];
-                        t2 += (a + 2 >= m ? l2 : 0.f) * dl[a + 2];
-                    }
-                    v = (t0 + t1 + t2) * prm.D[m % 3];
-                } else v = 0.f;
-                c.fpn[tid] = v;
+            for (int q = 0; q < 8; ++q) {
+                const float4 dv = *reinterpret_cast<const float4*>(lb + 4 * q);
+                s0 += cd[4 * q] * dv.x + cd[4 * q + 2] * dv.z;
+                s1 += cd[4 * q + 1] * dv.y + cd[4 * q + 3] * dv.w;
+            }
+            const float s = s0 + s1;
+            float out = 0.f;
+            if (half == 0) out = k > 0 ? Dm * s : 0.f;
+            else if (j < NS) {
+                const float* v = c.fpv;
+                const float* F = geo + foff;
+                const float sj = j >= 9 ? (jct ? gam1 : gam0) : 1.f;
+                const float ce = (j >= 3 && j < 6) ? prm.dt : 0.f;
+                const float cg = j < 3 ? prm.dt : (j >= 9 ? -prm.dt * sj : 0.f);
+                out = sj * v[j] + ce * v[je] + cg * (v[6 + ja1] * F[ja2] - v[6 + ja2] * F[ja1]) - s;
             }
             wave_lds_sync();
-            if (tid < NXA) c.fpv[tid] = c.fpn[tid];
-            havep = pk;
+            if (half == 0) { if (tid < NF) c.fpv[NS + tid] = out; }
+            else if (j < NS) c.fpv[j] = out;
             wave_lds_sync();
             PROF2(27);
         }
@@ -983,6 +1106,40 @@ __device__ void costate_update(const Ctx& c, const CmpcConsts& prm, int tid, flo
     __syncthreads();
 }
 
+// ---- out-of-line entry points of the sweeps: each rebuilds the LDS map from the dynamic LDS base ----
+#define CMPC_PHASE_PROLOGUE                                                            \
+    extern __shared__ __attribute__((aligned(16))) char smem[];                        \
+    const int N = NC > 0 ? NC : Nrt;                                                   \
+    Ctx c;                                                                             \
+    make_ctx<FG>(c, smem, N, fg_base);                                                 \
+    const CmpcConsts& prm = *reinterpret_cast<const CmpcConsts*>(smem);                \
+    const int tid = threadIdx.x
+
+template <int NT, int NC, bool FG>
+__device__ __attribute__((noinline)) void phase_forward(int Nrt, float* fg_base, bool affine)
+{
+    CMPC_PHASE_PROLOGUE;
+    riccati_forward<NT>(c, prm, tid, affine);
+}
+template <int NT, int NC, bool FG>
+__device__ __attribute__((noinline)) void phase_delta(int Nrt, float* fg_base)
+{
+    CMPC_PHASE_PROLOGUE;
+    riccati_delta(c, prm, tid);
+}
+template <int NT, int NC, bool FG>
+__device__ __attribute__((noinline)) void phase_costate(int Nrt, float* fg_base, float ap, bool use_exact)
+{
+    CMPC_PHASE_PROLOGUE;
+    costate_update(c, prm, tid, ap, use_exact);
+}
+template <int NT, int NC, bool FG>
+__device__ __attribute__((noinline)) int phase_backward(int Nrt, float* fg_base, bool use_exact, float reg, float cmu)
+{
+    CMPC_PHASE_PROLOGUE;
+    return riccati_backward<NT, NC, FG>(c, prm, tid, use_exact, reg, cmu);
+}
+
 // NC > 0: horizon known at compile time (every LDS offset becomes an immediate); NC == 0: runtime N
 // FG: the per-stage factors (Linv, Ws: 915 floats per stage) live in global scratch instead of LDS
 // (horizons whose LDS image would exceed 160 KiB)
@@ -1001,43 +1158,11 @@ __global__ __launch_bounds__(NT, FG ? 2 : 1) void cmpc_solve_kernel(CmpcParams k
         for (int e = tid; e < (int)(sizeof(CmpcConsts) / 4); e += NT) dst[e] = src[e];
     }
     const CmpcConsts& prm = prmw;
-    constexpr int KBYTES = (sizeof(CmpcConsts) + 15) & ~15;
     const long long t_start = __builtin_amdgcn_s_memtime();
     Ctx c;
-    c.L.N = N;
-    c.N = N;
-    // ---- carve LDS: doubles first, then 16-byte aligned float panels ----
-    double* dp = reinterpret_cast<double*>(smem + KBYTES);
-    c.LAM = dp; dp += NS * (N + 1) + ((NS * (N + 1)) & 1);
-    c.QuuD = dp; dp += 90;
-    c.pv = dp; dp += 40; c.pn = dp; dp += 40; c.qs = dp; dp += 16; c.Pd = dp; dp += 40;
-    c.sig = dp; dp += NI; c.gco = dp; dp += NI; c.redd = dp; dp += 8;
-    float* fp = reinterpret_cast<float*>(dp);
-    c.QuuF = fp; fp += NU * RLD;
-    c.Pan = fp; fp += NPAN * RLD;
-    float* spw = fp; fp += (c.L.np() + 3) & ~3;
-    c.sp = spw;
-    c.S = fp; fp += NS * (N + 1); c.U = fp; fp += NU * N; c.T = fp; fp += NI * N; c.Z = fp; fp += NI * N;
-    c.dS = fp; fp += NS * (N + 1); c.dU = fp; fp += NU * N; c.dT = fp; fp += NI * N; c.dZ = fp; fp += NI * N;
-    c.d = fp; fp += NS * N;
-    c.lqs = fp; fp += NU * N;
-    c.geoA = fp; fp += GEO * N;
-    c.P0 = fp; fp += NXA * PLD; c.P1 = fp; fp += NXA * PLD;
-    c.G = fp; fp += NXA * GLD; c.T1 = fp; fp += NS * NS;
-    c.Bval = fp; fp += 3 * NU; c.Aval = fp; fp += 3 * NS + 3;
-    c.arow = fp; fp += 96 + 12; c.ybuf = fp; fp += 64; c.fpv = fp; fp += 40; c.fpn = fp; fp += 40; c.red = fp; fp += 8;
-    c.Brow = reinterpret_cast<int*>(fp); fp += 3 * NU;
-    c.Arow = reinterpret_cast<int*>(fp); fp += 3 * NS + 3;
-    c.flag = reinterpret_cast<int*>(fp); fp += 4;
-    c.qmask = reinterpret_cast<int*>(fp); fp += CMPC_NMAX;
-    c.tri = reinterpret_cast<unsigned short*>(fp); fp += NTRI / 2;
-    if (FG) {
-        c.Lf = kp.scratch + (size_t)b * kp.scratch_stride;
-        c.Ws = c.Lf + (size_t)LP * N;
-    } else {
-        c.Lf = fp; fp += (size_t)LP * N;
-        c.Ws = fp; fp += (size_t)(NU * NS) * N;
-    }
+    float* const fg_base = FG ? kp.scratch + (size_t)b * kp.scratch_stride : nullptr;
+    make_ctx<FG>(c, smem, N, fg_base);
+    float* spw = const_cast<float*>(c.sp);
 
     // ---- one-off tables, parameter vector (coalesced) ----
     for (int e = tid; e < NTRI; e += NT) {
@@ -1046,6 +1171,8 @@ __global__ __launch_bounds__(NT, FG ? 2 : 1) void cmpc_solve_kernel(CmpcParams k
         while (i * (i + 1) / 2 > e) --i;
         c.tri[e] = (unsigned short)((i << 8) | (e - i * (i + 1) / 2));
     }
+    if (!FG)  // zero blocks of the factor records (HBM scratch is zeroed once, at cmpc_create)
+        for (int e = tid; e < REC_N * N; e += NT) c.Lf[e] = 0.f;
     for (int e = tid; e < NPAN * RLD; e += NT) c.Pan[e] = 0.f;
     for (int e = tid; e < NU * RLD; e += NT) c.QuuF[e] = 0.f;
     if (tid < 90) c.QuuD[tid] = 0.0;
@@ -1146,7 +1273,7 @@ __global__ __launch_bounds__(NT, FG ? 2 : 1) void cmpc_solve_kernel(CmpcParams k
         float reg = prm.reg;
         int fail = 1;
         for (int attempt = 0; attempt < 4; ++attempt) {
-            fail = riccati_backward<NT>(c, prm, tid, exact, reg, centring ? prm.mu_min : 0.f);
+            fail = phase_backward<NT, NC, FG>(N, fg_base, exact, reg, centring ? prm.mu_min : 0.f);
             if (!fail) break;
             __syncthreads();
             ++gn; exact = false;
@@ -1158,10 +1285,10 @@ __global__ __launch_bounds__(NT, FG ? 2 : 1) void cmpc_solve_kernel(CmpcParams k
         if (centring) {
             for (int e = tid; e < NI * N; e += NT) c.dZ[e] = row_active(c, e / NI, e % NI) ? prm.mu_min : 0.f;
             __syncthreads();
-            riccati_forward<NT>(c, prm, tid, false);
+            phase_forward<NT, NC, FG>(N, fg_base, false);
             PROF(15);
         } else {
-        riccati_forward<NT>(c, prm, tid, true);
+        phase_forward<NT, NC, FG>(N, fg_base, true);
         PROF(12);
         if (finishing) {
             // last step: affine-scaling extrapolation of the central path to mu = 0 (primal only)
@@ -1179,24 +1306,33 @@ __global__ __launch_bounds__(NT, FG ? 2 : 1) void cmpc_solve_kernel(CmpcParams k
         const float mu_aff = (float)(block_sum<NT>(l_aff, c.redd, tid) / (double)nrow);
         sigma = mu_aff / mu_cur;
         sigma = sigma * sigma * sigma;
-        mu_t = fmaxf(sigma * mu_cur, prm.mu_min);
+        mu_t = fmaxf(fmaxf(sigma, prm.sigma_min) * mu_cur, prm.mu_min);
+        const float so = prm.dev[0] > 0.5f ? ap * ad : 1.f;
         // ---- corrector ----
-        for (int e = tid; e < NI * N; e += NT)
-            c.dZ[e] = row_active(c, e / NI, e % NI) ? mu_t - c.dT[e] * c.dZ[e] : 0.f;  // complementarity target
+        for (int e = tid; e < NI * N; e += NT) {
+            const float cmu = row_active(c, e / NI, e % NI) ? mu_t - so * c.dT[e] * c.dZ[e] : 0.f;  // complementarity target
+            c.dZ[e] = cmu;
+            c.dT[e] = cmu / c.T[e];   // row coefficient change, read by the corrector sweep (dT is rebuilt by the forward sweep)
+        }
         __syncthreads();
         PROF(13);
-        riccati_delta(c, prm, tid);
+        phase_delta<NT, NC, FG>(N, fg_base);
         PROF(14);
-        riccati_forward<NT>(c, prm, tid, false);
+        phase_forward<NT, NC, FG>(N, fg_base, false);
         PROF(15);
         }
         step_lengths<NT>(c, tid, fmaxf(0.99f, 1.f - mu_t), ap, ad);
         // ---- costates, then the iterate ----
-        costate_update(c, prm, tid, ap, exact);
+        phase_costate<NT, NC, FG>(N, fg_base, ap, exact);
         PROF(16);
         for (int e = tid; e < NS * (N + 1); e += NT) c.S[e] += ap * c.dS[e];
         for (int e = tid; e < NU * N; e += NT) c.U[e] += ap * c.dU[e];
-        for (int e = tid; e < NI * N; e += NT) { c.T[e] += ap * c.dT[e]; c.Z[e] += ad * c.dZ[e]; }
+        for (int e = tid; e < NI * N; e += NT) {
+            const float tn = c.T[e] + ap * c.dT[e];
+            float zn = c.Z[e] + ad * c.dZ[e];
+            if (prm.dev[2] > 0.f && row_active(c, e / NI, e % NI)) zn = fminf(fmaxf(zn, mu_t / (prm.dev[2] * tn)), prm.dev[2] * mu_t / tn);
+            c.T[e] = tn; c.Z[e] = zn;
+        }
         // ---- convergence: the Newton step itself is the error estimate.  Flat directions of the cost
         // (e.g. the internal force along the line joining the feet) are kept quiet by the Levenberg
         // shift `reg`.  The stationarity residual of a float32-stored iterate cannot go below ~1e-3
@@ -1267,10 +1403,10 @@ extern "C" size_t cmpc_solver_lds_bytes(int N, int factors_global)
     cmpc_layout_init(L, N);
     const size_t nlam = (size_t)NS * (N + 1) + (((size_t)NS * (N + 1)) & 1);
     const size_t dbl = nlam + 90 + 40 + 40 + 16 + 40 + NI + NI + 8;
-    const size_t flt = (size_t)NU * RLD + (size_t)NPAN * RLD + ((L.np + 3) & ~3)
-                       + 2 * ((size_t)NS * (N + 1) + (size_t)NU * N + 2 * (size_t)NI * N) + (size_t)NS * N + (size_t)NU * N
-                       + (size_t)GEO * N + 2 * NXA * PLD + NXA * GLD + NS * NS + 3 * NU + 3 * NS + 3 + 96 + 12 + 64 + 40 + 40 + 8
-                       + 3 * NU + 3 * NS + 3 + 4 + CMPC_NMAX + NTRI / 2 + (factors_global ? 0 : (size_t)LP * N + (size_t)NU * NS * N);
+    const size_t flt = (size_t)NU * RLD + (size_t)NPAN * RLD + 96 + ((L.np + 3) & ~3)
+                       + 2 * ((size_t)NS * (N + 1) + (size_t)NU * N + 2 * (size_t)NI * N) + (size_t)NS * N
+                       + (size_t)GEO * N + 2 * NXA * PLD + NXA * GLD + NS * NS + 3 * NU + 3 * NS + 3 + 96 + 12 + 40 + 40 + 8
+                       + 3 * NU + 3 * NS + 3 + 4 + CMPC_NMAX + NTRI / 2 + (factors_global ? 0 : (size_t)REC_N * N);
     return ((sizeof(CmpcConsts) + 15) & ~(size_t)15) + dbl * 8 + flt * 4;
 }
 
