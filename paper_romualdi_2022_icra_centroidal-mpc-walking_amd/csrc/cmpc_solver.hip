@@ -39,16 +39,18 @@
 #define NPAN 46    // panel rows: 15 (Qus^T) + 30 (I) + 1 (qu)
 #define GEO 36     // floats of stage geometry: r[24] | Fc[6] | Fsum[3] | pad
 #define NTRI 780   // lower-triangular entries of a 39x39
-// Per-stage factor record (floats), in LDS or -- FG kernels -- in HBM scratch:
-//   [REC_LB, +576)  L^{-1}, lower triangle in 4x4 blocks: block-row I (rows 4I..4I+3) stores its I+1 blocks row by
-//                   row, so row r is 4(I+1) contiguous floats on a 16-byte boundary and column walks stay inside
-//                   one bank sweep.  Entries above the diagonal inside a diagonal block, and rows 30, 31, are zero
-//                   and never written: row 31 doubles as the zero block (REC_ZERO) that out-of-triangle reads hit.
-//   [REC_WS, +480)  30 rows x 16: Ws[a][0..14] = (L^{-1} Qus)[a][:], slot 15 = lq[a] = (L^{-1} qu)[a]; the
-//                   float4 index of a row is XOR-swizzled with (a >> 2) & 3 (conflict-free 16-byte row reads)
-#define REC_LB 0
-#define REC_WS 576
-#define REC_ZERO 544
+// Per-stage factor record (floats), in LDS or -- FG kernels -- in HBM scratch.  Phase 3 leaves column m of
+// L^{-1} and column j of Ws = L^{-1} Qus in the registers of one lane, so both are stored transposed, one
+// 16-byte-aligned row per lane:
+//   [REC_UB, +576)  U = L^{-T}, upper triangle in 4x4 blocks: row m (block-row I = m / 4) holds columns 4I..31,
+//                   4 (8 - I) contiguous floats.  Entries below the diagonal inside a diagonal block, columns
+//                   30, 31 and rows 30, 31 are zero; row 31 is the zero block (REC_ZERO) that out-of-triangle
+//                   reads are pointed at.
+//   [REC_WT, +512)  16 rows x 32: row j < 15 = Ws[:, j], row 15 = lq = L^{-1} qu; the float4 index inside a row
+//                   is XOR-swizzled with j & 7 (row reads of 16 consecutive j stay 2-way conflict-free)
+#define REC_UB 0
+#define REC_WT 576
+#define REC_ZERO 572
 #define REC_N CMPC_REC_N
 
 namespace {
@@ -124,8 +126,9 @@ __device__ inline void make_ctx(Ctx& c, char* smem, int N, float* fg_base)
     c.tri = reinterpret_cast<unsigned short*>(fp); fp += NTRI / 2;
 }
 
-__device__ inline int lb_row(int r) { const int I = r >> 2; return REC_LB + 8 * I * (I + 1) + (r & 3) * 4 * (I + 1); }
-__device__ inline int ws_idx(int a, int j) { return REC_WS + 16 * a + 4 * ((j >> 2) ^ ((a >> 2) & 3)) + (j & 3); }
+// U[m][a] (a >= 4 (m / 4)) lives at ub_row(m) + a - 4 (m / 4)
+__device__ inline int ub_row(int m) { const int I = m >> 2; return REC_UB + 16 * (8 * I - I * (I - 1) / 2) + (m & 3) * 4 * (8 - I); }
+__device__ inline int wt_idx(int j, int a) { return REC_WT + 32 * j + 4 * ((a >> 2) ^ (j & 7)) + (a & 3); }
 // sum of the two 32-lane halves of a wave, in every lane (gfx950 v_permlane32_swap)
 __device__ inline float half_sum(float v)
 {
@@ -479,6 +482,7 @@ __device__ inline void stage_factor(const float* QuuF, const double* QuuD, float
     const bool active = isL || prow < NPAN;
     float v[NU];
     double dd[3] = {0.0, 0.0, 0.0};
+    PROF2_DECL;
     const bool idrow = !isL && prow >= NS && prow < NS + NU;
     {
         const float* src = isL ? QuuF + lane * RLD : Pan + ((active && !idrow) ? prow : 0) * RLD;
@@ -500,24 +504,32 @@ __device__ inline void stage_factor(const float* QuuF, const double* QuuD, float
             dd[2] = QuuD[9 * (lane / 3) + 3 * (lane % 3) + 2];
         }
     }
+    PROF2(28);
     const bool bad = chol_solve_fused(v, dd, lane, fixedmask);
+    PROF2(29);
     if (bad && tid == 0) *flag = 1;
     if (!isL && active) {
-        if (prow < NS) {
+        // one row per lane, 16-byte stores: the panel row for phase 4 and the record row for the sweeps
+        const int m = prow - NS;                       // identity rows: column m of L^{-1}
+        const bool isId = prow >= NS && prow < NS + NU;
+        float sc = 1.f;
+        if (isId) sc = m < NF ? -((m % 3 == 0) ? D0 : ((m % 3 == 1) ? D1 : D2)) : 0.f;
+        const int jw = prow < NS ? prow : 15;          // Ws column j, or the lq row
+        const int I = isId ? (m >> 2) : 0;
+        float* prow_p = Pan + prow * RLD;
+        float* rrow = rec + (isId ? ub_row(m) - 4 * I : REC_WT + 32 * jw);
 #pragma unroll
-            for (int a = 0; a < NU; ++a) { rec[ws_idx(a, prow)] = v[a]; Pan[prow * RLD + a] = v[a]; }
-        } else if (prow < NS + NU) {
-            const int m = prow - NS;
-            const float dm = (m % 3 == 0) ? D0 : ((m % 3 == 1) ? D1 : D2);
-            const float sc = m < NF ? -dm : 0.f;
-#pragma unroll
-            for (int a = 0; a < NU; ++a)
-                if (a >= m) { rec[lb_row(a) + m] = v[a]; Pan[prow * RLD + a] = sc * v[a]; }
-        } else {
-#pragma unroll
-            for (int a = 0; a < NU; ++a) { rec[ws_idx(a, 15)] = v[a]; Pan[prow * RLD + a] = v[a]; }
+        for (int q = 0; q < 8; ++q) {
+            float4 w;
+            w.x = v[4 * q]; w.y = v[4 * q + 1];
+            w.z = 4 * q + 2 < NU ? v[(4 * q + 2) % NU] : 0.f;
+            w.w = 4 * q + 3 < NU ? v[(4 * q + 3) % NU] : 0.f;
+            *reinterpret_cast<float4*>(prow_p + 4 * q) = make_float4(sc * w.x, sc * w.y, sc * w.z, sc * w.w);
+            if (isId) { if (q >= I) *reinterpret_cast<float4*>(rrow + 4 * q) = w; }
+            else *reinterpret_cast<float4*>(rrow + 4 * (q ^ (jw & 7))) = w;
         }
     }
+    PROF2(30);
 }
 
 // ---- Riccati backward sweep (matrices + right-hand side of the affine step).
@@ -823,25 +835,20 @@ __device__ void riccati_forward(const Ctx& c, const CmpcConsts& prm, int tid, bo
         float* xb = c.ybuf;       // [ds (15), 1, -D du_prev (24)]
         float* yb = c.ybuf + 40;  // y (32)
         // per-lane offsets inside a stage record (loop invariant)
-        int moff[5], xoff[5], coff[16];
+        // y-step: column r of [WT; U[0..23]] against x, 20 terms per half;  du-step: row r of U against y
+        int yoff[20], uoff[4];
 #pragma unroll
-        for (int t = 0; t < 5; ++t) {
-            int mo, xo;
-            if (half == 0) {
-                mo = t < 4 ? REC_WS + 16 * r + 4 * (t ^ (blk & 3)) : lb_row(r);
-                xo = 4 * t;
-            } else {
-                const int q4 = t + 1;
-                mo = q4 <= blk ? lb_row(r) + 4 * q4 : REC_ZERO;
-                xo = 16 + 4 * q4;
+        for (int t = 0; t < 20; ++t) {
+            if (half == 0) yoff[t] = t < 16 ? wt_idx(t, r) : ub_row(t - 16) + r;
+            else {
+                const int m = 4 + t;
+                yoff[t] = blk >= (m >> 2) ? ub_row(m) + r - 4 * (m >> 2) : REC_ZERO;
             }
-            moff[t] = r < NU ? mo : REC_ZERO;
-            xoff[t] = xo;
         }
 #pragma unroll
-        for (int aa = 0; aa < 16; ++aa) {
-            const int a = 16 * half + aa;
-            coff[aa] = blk <= (a >> 2) ? lb_row(a) + r : REC_ZERO;
+        for (int t = 0; t < 4; ++t) {
+            const int q4 = 4 * half + t;
+            uoff[t] = q4 >= blk ? ub_row(r) + 4 * (q4 - blk) : REC_ZERO;
         }
         // roles in the dynamics step
         const int ga = tid >> 3, cj = tid & 7;              // lanes 0..23: axis ga of corner cj
@@ -854,12 +861,12 @@ __device__ void riccati_forward(const Ctx& c, const CmpcConsts& prm, int tid, bo
         PROF2_DECL;
         for (int k = 0; k < N; ++k) {
             const float* rec = c.Lf + (size_t)REC_N * k;
-            float4 m[5];
-            float cl[16];
+            float ym[20];
+            float4 um[4];
 #pragma unroll
-            for (int t = 0; t < 5; ++t) m[t] = *reinterpret_cast<const float4*>(rec + moff[t]);
+            for (int t = 0; t < 20; ++t) ym[t] = rec[yoff[t]];
 #pragma unroll
-            for (int aa = 0; aa < 16; ++aa) cl[aa] = rec[coff[aa]];
+            for (int t = 0; t < 4; ++t) um[t] = *reinterpret_cast<const float4*>(rec + uoff[t]);
             // stage data of the dynamics step (independent of the recursion as well)
             const float* geo = c.geoA + GEO * k;
             const float gam0 = gam_of(c, 0, k), gam1 = gam_of(c, 1, k);
@@ -871,17 +878,21 @@ __device__ void riccati_forward(const Ctx& c, const CmpcConsts& prm, int tid, bo
             PROF2(20);
             float4 xv[5];
 #pragma unroll
-            for (int t = 0; t < 5; ++t) xv[t] = *reinterpret_cast<const float4*>(xb + xoff[t]);
-            const float y = half_sum((dot4(m[0], xv[0]) + dot4(m[1], xv[1])) + (dot4(m[2], xv[2]) + dot4(m[3], xv[3])) + dot4(m[4], xv[4]));
+            for (int t = 0; t < 5; ++t) xv[t] = *reinterpret_cast<const float4*>(xb + 20 * half + 4 * t);
+            float ya = 0.f, yc = 0.f;
+#pragma unroll
+            for (int t = 0; t < 5; ++t) {
+                ya += ym[4 * t] * xv[t].x + ym[4 * t + 2] * xv[t].z;
+                yc += ym[4 * t + 1] * xv[t].y + ym[4 * t + 3] * xv[t].w;
+            }
+            const float y = half_sum(ya + yc);
             if (tid < 32) yb[r] = y;
             wave_lds_sync();
             PROF2(21);
-            float w = 0.f;
+            float4 yv[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float4 yv = *reinterpret_cast<const float4*>(yb + 16 * half + 4 * q);
-                w += cl[4 * q] * yv.x + cl[4 * q + 1] * yv.y + cl[4 * q + 2] * yv.z + cl[4 * q + 3] * yv.w;
-            }
+            for (int q = 0; q < 4; ++q) yv[q] = *reinterpret_cast<const float4*>(yb + 16 * half + 4 * q);
+            const float w = (dot4(um[0], yv[0]) + dot4(um[1], yv[1])) + (dot4(um[2], yv[2]) + dot4(um[3], yv[3]));
             const float du = -half_sum(w);
             if (tid < NU) c.dU[NU * k + tid] = du;
             wave_lds_sync();
@@ -950,21 +961,22 @@ __device__ void riccati_delta(const Ctx& c, const CmpcConsts& prm, int tid)
         const int r = tid & 31, half = tid >> 5, blk = r >> 2;
         float* gb = c.ybuf;        // g (32)
         float* lb = c.ybuf + 32;   // dl (32)
-        int moff[4], doff[32];
+        // dl-step: column r of U against g, 16 terms per half;  fp-step: row r of U (lanes 0..31) or row r of WT
+        // (lanes 32..47) against dl
+        int loff[16], foff[8];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int q4 = 4 * half + t;
-            moff[t] = (r < NU && q4 <= blk) ? lb_row(r) + 4 * q4 : REC_ZERO;
+        for (int t = 0; t < 16; ++t) {
+            const int m = 16 * half + t;
+            loff[t] = blk >= (m >> 2) ? ub_row(m) + r - 4 * (m >> 2) : REC_ZERO;
         }
-        // lanes 0..31: column r of L^{-1} (outputs fp_p);  lanes 32..47: column r of [Ws | lq] (outputs fp_s)
 #pragma unroll
-        for (int a = 0; a < 32; ++a)
-            doff[a] = half == 0 ? (blk <= (a >> 2) ? lb_row(a) + r : REC_ZERO) : ((a < NU && r < 16) ? ws_idx(a, r) : REC_ZERO);
+        for (int q = 0; q < 8; ++q)
+            foff[q] = half == 0 ? (q >= blk ? ub_row(r) + 4 * (q - blk) : REC_ZERO) : (r < 16 ? REC_WT + 32 * r + 4 * (q ^ (r & 7)) : REC_ZERO);
         // A^T row roles of lanes 32..46 (state index j = r): out = s v[j] + ce v[je] + cg (v[6+a1] F[a2] - v[6+a2] F[a1])
         const int j = r;
         const int ja = j < 3 ? j : (j >= 9 ? (j - 9) % 3 : 0), ja1 = (ja + 1) % 3, ja2 = (ja + 2) % 3;
         const int jct = j >= 12 ? 1 : 0;
-        const int foff = j < 3 ? 30 : 24 + 3 * jct;   // Fsum or Fc of the foot (geometry record)
+        const int gfo = j < 3 ? 30 : 24 + 3 * jct;    // Fsum or Fc of the foot (geometry record)
         const int je = (j >= 3 && j < 6) ? j - 3 : 0;
         // B^T roles of lanes 0..29
         const int fa = tid % 3, fa1 = (fa + 1) % 3, fa2 = (fa + 2) % 3, fcj = tid / 3;   // force component tid < 24
@@ -976,12 +988,12 @@ __device__ void riccati_delta(const Ctx& c, const CmpcConsts& prm, int tid)
         PROF2_DECL;
         for (int k = N - 1; k >= 0; --k) {
             float* rec = c.Lf + (size_t)REC_N * k;
-            float4 m[4];
+            float lm[16];
+            float4 fm[8];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) m[t] = *reinterpret_cast<const float4*>(rec + moff[t]);
-            float cd[32];
+            for (int t = 0; t < 16; ++t) lm[t] = rec[loff[t]];
 #pragma unroll
-            for (int a = 0; a < 32; ++a) cd[a] = rec[doff[a]];
+            for (int q = 0; q < 8; ++q) fm[q] = *reinterpret_cast<const float4*>(rec + foff[q]);
             const float* geo = c.geoA + GEO * k;
             const float* wk = c.dT + NI * k;
             const float gam0 = gam_of(c, 0, k), gam1 = gam_of(c, 1, k);
@@ -1010,25 +1022,28 @@ __device__ void riccati_delta(const Ctx& c, const CmpcConsts& prm, int tid)
             float4 gv[4];
 #pragma unroll
             for (int t = 0; t < 4; ++t) gv[t] = *reinterpret_cast<const float4*>(gb + 16 * half + 4 * t);
-            const float dl = half_sum((dot4(m[0], gv[0]) + dot4(m[1], gv[1])) + (dot4(m[2], gv[2]) + dot4(m[3], gv[3])));
+            float la = 0.f, lc = 0.f;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                la += lm[4 * t] * gv[t].x + lm[4 * t + 2] * gv[t].z;
+                lc += lm[4 * t + 1] * gv[t].y + lm[4 * t + 3] * gv[t].w;
+            }
+            const float dl = half_sum(la + lc);
             if (tid < 32) lb[r] = dl;
-            if (tid < NU) rec[ws_idx(tid, 15)] += dl;
+            if (tid < NU) rec[wt_idx(15, tid)] += dl;
             wave_lds_sync();
             PROF2(26);
             // ---- fp ----
-            float s0 = 0.f, s1 = 0.f;
+            float4 dv[8];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const float4 dv = *reinterpret_cast<const float4*>(lb + 4 * q);
-                s0 += cd[4 * q] * dv.x + cd[4 * q + 2] * dv.z;
-                s1 += cd[4 * q + 1] * dv.y + cd[4 * q + 3] * dv.w;
-            }
-            const float s = s0 + s1;
+            for (int q = 0; q < 8; ++q) dv[q] = *reinterpret_cast<const float4*>(lb + 4 * q);
+            const float s = ((dot4(fm[0], dv[0]) + dot4(fm[1], dv[1])) + (dot4(fm[2], dv[2]) + dot4(fm[3], dv[3])))
+                            + ((dot4(fm[4], dv[4]) + dot4(fm[5], dv[5])) + (dot4(fm[6], dv[6]) + dot4(fm[7], dv[7])));
             float out = 0.f;
             if (half == 0) out = k > 0 ? Dm * s : 0.f;
             else if (j < NS) {
                 const float* v = c.fpv;
-                const float* F = geo + foff;
+                const float* F = geo + gfo;
                 const float sj = j >= 9 ? (jct ? gam1 : gam0) : 1.f;
                 const float ce = (j >= 3 && j < 6) ? prm.dt : 0.f;
                 const float cg = j < 3 ? prm.dt : (j >= 9 ? -prm.dt * sj : 0.f);

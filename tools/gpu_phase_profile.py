@@ -20,9 +20,9 @@ print("iters block0", info[0, 0], "total cycles (sum of phases) %.3g" % tot, "ke
 for n, x in zip(names, v):
     print("%-22s %12.0f  %5.1f%%  per stage-iter %8.0f" % (n, x, 100 * x / tot, x / (info[0, 0] * cfg.N)))
 
-sub = np.array(out[20:28], float)
+sub = np.array(out[20:31], float)
 for n, x in zip(["fwd: loop head", "fwd: y = lq + Ws ds + Wp dp", "fwd: du = -Linv^T y", "fwd: AB_step",
-                 "delta: loop head", "delta: rhs g + B^T fp", "delta: dl = Linv dq", "delta: fp update"], sub):
+                 "delta: loop head", "delta: rhs g + B^T fp", "delta: dl = Linv dq", "delta: fp update", "ph3: load rows", "ph3: cholesky+solve", "ph3: store"], sub):
     print("  %-30s %12.0f  per stage-sweep %8.0f" % (n, x, x / (info[0, 0] * cfg.N)))
 tr = (C.c_float * 512)()
 cm._capi.lib().cmpc_trace_read(tr)
