@@ -425,48 +425,72 @@ __device__ inline double readlane_d(double x, int lane)
     return __hiloint2double(hi, lo);
 }
 
-// ---- fused Cholesky + panel solve, one wave, rows in registers ----
+// ---- fused Cholesky + panel solve, one wave, rows in registers, 3x3 pivot blocks ----
 // lanes 0..29: row `lane` of the symmetric matrix (v[c], c <= lane, float; its own 3x3 diagonal
 // block in dd[], float64).  Lanes >= 30: a row of the panel [Qus | I | qu]^T (30 floats).
 // On exit v[] holds the row of L (lanes < 30) or of (L^{-1} [Qus | I | qu])^T.  Returns true if a
 // pivot was not positive (uniform across the wave).
+//
+// Lanes < 30 enter with v[c] = Quu[lane][c] for c outside their own 3x3 diagonal block and 0 inside it; the
+// diagonal block itself is in dd (float64).  Updates of a diagonal block by earlier blocks are moderate
+// numbers and accumulate in those zeroed float slots; they are folded into dd when the block becomes the
+// pivot block.  The pivot block is broadcast (v_readlane), factorised in float64 by every lane, and applied:
+// three columns of L per step, then one rank-3 update of the trailing columns.
+__device__ inline double rsqrt_d(double x)
+{
+    double r = (double)rsqrtf((float)x);
+    return r * (1.5 - 0.5 * x * r * r);  // one Newton step in float64: ~1e-14 relative
+}
 __device__ inline bool chol_solve_fused(float (&v)[NU], double (&dd)[3], int lane, int fixedmask)
 {
-    // Lanes < 30 enter with v[c] = Quu[lane][c] for c outside their own 3x3 diagonal block and 0 inside it; the
-    // diagonal block itself is in dd (float64).  Updates of a diagonal block by earlier columns are moderate
-    // numbers and accumulate in those zeroed float slots; they are folded into dd when the block becomes the
-    // pivot block.  Inside the pivot block everything is float64 (partners by v_readlane of compile-time lanes).
     bool bad = false;
-    const int myblk = lane / 3;
+    const int myblk = lane / 3, jm = lane - 3 * myblk;
 #pragma unroll
-    for (int j = 0; j < NU; ++j) {
-        const int b = j / 3, jm = j % 3;
-        const bool inblk = (myblk == b);
-        if (jm == 0 && inblk) {
-            dd[0] += (double)v[3 * b];
-            dd[1] += (double)v[3 * b + 1];
-            dd[2] += (double)v[3 * b + 2];
+    for (int b = 0; b < NU / 3; ++b) {
+        const int j0 = 3 * b;
+        // (opaque copies: the lane predicates are recomputed per block instead of living in hoisted, spilled SGPR pairs)
+        int myb = myblk, jmo = jm;
+        asm volatile("" : "+v"(myb), "+v"(jmo));
+        const bool inblk = (myb == b);
+        if (inblk) {
+            dd[0] += (double)v[j0];
+            dd[1] += (double)v[j0 + 1];
+            dd[2] += (double)v[j0 + 2];
         }
-        if (j >= NF && ((fixedmask >> (j - NF)) & 1)) continue;  // identity row/column (fixed q): nothing to do
-        double piv = readlane_d(dd[jm], j);
-        if (!(piv > 0.0)) { bad = true; piv = 1.0; }
-        double rinv = (double)rsqrtf((float)piv);
-        rinv = rinv * (1.5 - 0.5 * piv * rinv * rinv);  // one Newton step in float64: ~1e-14 relative
-        const float rinvf = (float)rinv;
-        const double ld = inblk ? dd[jm] * rinv : (double)(v[j] * rinvf);
-        const float lf = (float)ld;
-        v[j] = lf;
-        if (jm < 2) {
-            const double dA = readlane_d(ld, j + 1);
-            if (inblk && lane > j) dd[jm + 1] -= ld * dA;
-            if (jm < 1) {
-                const double dB = readlane_d(ld, j + 2);
-                if (inblk && lane > j + 1) dd[2] -= ld * dB;
-            }
+        // a stance foot's landing offsets are identity rows and columns: nothing to do
+        if (j0 >= NF && ((fixedmask >> (j0 - NF)) & 7) == 7) continue;
+        const double d00 = readlane_d(dd[0], j0);
+        const double d10 = readlane_d(dd[0], j0 + 1), d11 = readlane_d(dd[1], j0 + 1);
+        const double d20 = readlane_d(dd[0], j0 + 2), d21 = readlane_d(dd[1], j0 + 2), d22 = readlane_d(dd[2], j0 + 2);
+        double p0 = d00;
+        if (!(p0 > 0.0)) { bad = true; p0 = 1.0; }
+        const double r00 = rsqrt_d(p0);
+        const double l00 = p0 * r00, l10 = d10 * r00, l20 = d20 * r00;
+        double p1 = d11 - l10 * l10;
+        if (!(p1 > 0.0)) { bad = true; p1 = 1.0; }
+        const double r11 = rsqrt_d(p1);
+        const double l11 = p1 * r11, l21 = (d21 - l20 * l10) * r11;
+        double p2 = d22 - l20 * l20 - l21 * l21;
+        if (!(p2 > 0.0)) { bad = true; p2 = 1.0; }
+        const double r22 = rsqrt_d(p2);
+        const double l22 = p2 * r22;
+        // rows below the block and panel rows: x = v[j0..j0+2] L_bb^{-T}
+        float x0 = v[j0] * (float)r00;
+        float x1 = (v[j0 + 1] - x0 * (float)l10) * (float)r11;
+        float x2 = (v[j0 + 2] - x0 * (float)l20 - x1 * (float)l21) * (float)r22;
+        if (inblk) {  // the block's own rows of L, from the float64 factor
+            x0 = (float)(jmo == 0 ? l00 : (jmo == 1 ? l10 : l20));
+            x1 = jmo == 0 ? 0.f : (float)(jmo == 1 ? l11 : l21);
+            x2 = jmo == 2 ? (float)l22 : 0.f;
         }
-        // everything else (float32): v[c] -= l_ij * l_cj
+        v[j0] = x0; v[j0 + 1] = x1; v[j0 + 2] = x2;
 #pragma unroll
-        for (int cc = j + 1; cc < NU; ++cc) v[cc] -= lf * readlane_f(lf, cc);
+        for (int cc = j0 + 3; cc < NU; ++cc) {
+            v[cc] = fmaf(-x2, readlane_f(x2, cc), fmaf(-x1, readlane_f(x1, cc), fmaf(-x0, readlane_f(x0, cc), v[cc])));
+            // pin the update here: left alone, the optimiser sinks the FMAs to the block that next reads v[cc] and the
+            // broadcast scalars (81 per block) wait for them in SGPRs spilled to VGPR lanes
+            asm volatile("" : "+v"(v[cc]));
+        }
     }
     return bad;
 }
@@ -534,6 +558,19 @@ __device__ inline void stage_factor(const float* QuuF, const double* QuuD, float
 
 // ---- Riccati backward sweep (matrices + right-hand side of the affine step).
 // Returns (uniformly) 0 ok, 1 non-positive pivot. ----
+// phase 3 out of line: its long stream of v_readlane broadcasts wants the SGPR file to itself
+template <int NC, bool FG>
+__device__ __attribute__((noinline)) void phase_factor(int Nrt, float* fg_base, int k)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int N = NC > 0 ? NC : Nrt;
+    Ctx c;
+    make_ctx<FG>(c, smem, N, fg_base);
+    const CmpcConsts& prm = *reinterpret_cast<const CmpcConsts*>(smem);
+    const int fixedmask = (~c.qmask[k]) & 63;
+    stage_factor(c.QuuF, c.QuuD, c.Pan, c.Lf + (size_t)REC_N * k, prm.D[0], prm.D[1], prm.D[2], c.flag, threadIdx.x, fixedmask);
+}
+
 template <int NT, int NC, bool FG>
 __device__ int riccati_backward(const Ctx& c, const CmpcConsts& prm, int tid, bool use_exact, float reg, float cmu)
 {
@@ -741,10 +778,7 @@ __device__ int riccati_backward(const Ctx& c, const CmpcConsts& prm, int tid, bo
         __syncthreads();
         PROF(2);
         // ---- phase 3: fused Cholesky + panel solve (waves 0 and 1; each repeats the factorisation) ----
-        if (tid < 128) {
-            const int fixedmask = (~c.qmask[k]) & 63;
-            stage_factor(c.QuuF, c.QuuD, c.Pan, c.Lf + (size_t)REC_N * k, prm.D[0], prm.D[1], prm.D[2], c.flag, tid, fixedmask);
-        }
+        if (tid < 128) phase_factor<NC, FG>(N, FG ? c.Lf : nullptr, k);
         __syncthreads();
         PROF(3);
         if (*c.flag) return 1;
