@@ -62,12 +62,14 @@ __device__ float g_trace[64 * 8];  // per iteration of workgroup 0: mu, ep, ec, 
 #define PROF_DECL long long pt_ = __builtin_amdgcn_s_memtime()
 #define PROF(slot) do { long long n_ = __builtin_amdgcn_s_memtime(); if (threadIdx.x == 0 && blockIdx.x == 0) g_prof[slot] += n_ - pt_; pt_ = n_; } while (0)
 #define PROF2_DECL long long pt2_ = __builtin_amdgcn_s_memtime()
+#define PROF3(slot) do { long long n_ = __builtin_amdgcn_s_memtime(); if (threadIdx.x == 192 && blockIdx.x == 0) g_prof[slot] += n_ - pt2_; pt2_ = n_; } while (0)
 #define PROF2(slot) do { long long n_ = __builtin_amdgcn_s_memtime(); if (threadIdx.x == 0 && blockIdx.x == 0) g_prof[slot] += n_ - pt2_; pt2_ = n_; } while (0)
 #else
 #define PROF_DECL
 #define PROF(slot)
 #define PROF2_DECL
 #define PROF2(slot)
+#define PROF3(slot)
 #endif
 
 struct Ctx {
@@ -668,8 +670,7 @@ __device__ int riccati_backward(const Ctx& c, const CmpcConsts& prm, int tid, bo
         }
         __syncthreads();
         PROF(0);
-        // ---- phase 1: G = P [B;E] (39 x 30), T1 = Pss A (15 x 15): thread <-> column, its three non-zeros in
-        // registers, rows strided over 8 (G) / all 15 (T1) ----
+        // ---- phase 1: G = P [B;E] (39 x 30): thread <-> column, its three non-zeros in registers, rows strided over 8 ----
         {
             const int nrow = havep ? NXA : NS;
             if (tid < 8 * NU) {
@@ -688,67 +689,83 @@ __device__ int riccati_backward(const Ctx& c, const CmpcConsts& prm, int tid, bo
                     }
                 }
             }
-            if (tid < NS * NS) {
-                const int i = tid / NS, j = tid % NS;
-                const float* Pr = Pcur + i * PLD;
-                c.T1[tid] = Pr[c.Arow[3 * j]] * c.Aval[3 * j] + Pr[c.Arow[3 * j + 1]] * c.Aval[3 * j + 1] + Pr[c.Arow[3 * j + 2]] * c.Aval[3 * j + 2];
-            }
         }
         __syncthreads();
         PROF(1);
-        // ---- phase 2: Quu (lower triangle; float, its 3x3 diagonal blocks in float64), panel [Qus | I | qu]^T,
-        // Qss, qs ----
-        for (int e = tid; e < LP; e += NT) {
-            const unsigned short ij = c.tri[e];
-            const int i = ij >> 8, j = ij & 255;
+        // ---- phase 2: what the factorisation needs.  Waves 0, 1: the float32 entries -- the 405 entries of Quu outside
+        // its 3x3 diagonal blocks and the 450 of the panel rows Qus^T.  Wave 2: the diagonal blocks of Quu in float64
+        // (cost, barrier and Levenberg terms).  Wave 3: qu in float64. ----
+        PROF2_DECL;
+        if (tid < 128) {
+            // seven items per thread: all values first, stores last (the loads of one item do not wait for another's store)
+            float val[7];
+            int adr[7];
+#pragma unroll
+            for (int it = 0; it < 7; ++it) {
+                const int e = tid + 128 * it;
+                float vf = 0.f;
+                int ad = -1;
+                if (e < 405) {
+                    // block pair (bi > bj) number e / 9 of the strict lower block triangle, entry e % 9 inside it
+                    const unsigned short ij = c.tri[e / 9];
+                    const int w = e % 9;
+                    const int i = 3 * ((ij >> 8) + 1) + w / 3, j = 3 * (ij & 255) + w % 3;
+                    const int b0 = c.Brow[3 * i], b1 = c.Brow[3 * i + 1], b2 = c.Brow[3 * i + 2];
+                    // [B;E]^T P [B;E]
+                    vf = c.Bval[3 * i] * c.G[b0 * GLD + j] + c.Bval[3 * i + 1] * c.G[b1 * GLD + j] + c.Bval[3 * i + 2] * c.G[b2 * GLD + j];
+                    if (havep && i < NF) vf += c.G[(NS + i) * GLD + j];
+                    if (i < NF && (i / 12) == (j / 12) && (i % 3) == (j % 3)) {
+                        // another corner of the same foot, same axis: symmetry-cost coupling
+                        const float gam = gam_of(c, i / 12, k);
+                        vf -= 2.f * prm.w_sym * 0.25f * gam * (2.f - gam);
+                    }
+                    ad = (int)(c.QuuF - c.Pan) + i * RLD + j;
+                } else if (e < 405 + NS * NU) {  // identity rows of the panel are made in registers (phase 3)
+                    const int e2 = e - 405, j = e2 / NU, i = e2 % NU;  // panel row j (column of Qus), entry i
+                    vf = c.G[c.Arow[3 * j] * GLD + i] * c.Aval[3 * j] + c.G[c.Arow[3 * j + 1] * GLD + i] * c.Aval[3 * j + 1]
+                         + c.G[c.Arow[3 * j + 2] * GLD + i] * c.Aval[3 * j + 2];
+                    if (i < NF) {
+                        // S[f_cj, pos_c] = gam Sx ; S[f_cj, com] = -gam Sx   (Sx = dt [lam_h]x, zero diagonal)
+                        const int ct = i / 12, a = i % 3;
+                        const int b = j < 3 ? j : j - 9 - 3 * ct;
+                        const float sgn = j < 3 ? -1.f : ((b >= 0 && b < 3) ? 1.f : 0.f);
+                        vf += sgn * gam_of(c, ct, k) * c.arow[96 + 3 * a + ((b >= 0 && b < 3) ? b : 0)];
+                    }
+                    ad = j * RLD + i;
+                }
+                val[it] = vf; adr[it] = ad;
+            }
+#pragma unroll
+            for (int it = 0; it < 7; ++it)
+                if (it < 6 || adr[it] != -1) c.Pan[adr[it]] = val[it];   // QuuF sits NU * RLD floats below Pan
+        } else if (tid < 128 + 60) {
+            // lower entry w of diagonal block tid' / 6: (row, col) = (0,0) (1,0) (1,1) (2,0) (2,1) (2,2)
+            const int t = tid - 128, b = t / 6, w = t - 6 * b;
+            const int rr = w >= 3 ? 2 : (w >= 1 ? 1 : 0), cc = w - rr * (rr + 1) / 2;
+            const int i = 3 * b + rr, j = 3 * b + cc;
             const int b0 = c.Brow[3 * i], b1 = c.Brow[3 * i + 1], b2 = c.Brow[3 * i + 2];
-            // [B;E]^T P [B;E]
             float vf = c.Bval[3 * i] * c.G[b0 * GLD + j] + c.Bval[3 * i + 1] * c.G[b1 * GLD + j] + c.Bval[3 * i + 2] * c.G[b2 * GLD + j];
             if (havep && i < NF) vf += c.G[(NS + i) * GLD + j];
-            if (i / 3 == j / 3) {  // diagonal block: cost + barrier terms in float64
-                double v = (double)vf;
-                if (i < NF) {
-                    if ((i % 3) == (j % 3)) {  // same corner, same axis => i == j here
-                        const double gam = gam_of(c, i / 12, k);
-                        v += 2.0 * prm.w_sym * (1.0 - 0.25 * gam * (2.0 - gam));
-                        if (pk) v += (double)prm.D[i % 3];
-                    }
-                    const int r0 = 4 * (i / 3);
+            double v = (double)vf;
+            if (i < NF) {
+                if (i == j) {
+                    const double gam = gam_of(c, i / 12, k);
+                    v += 2.0 * prm.w_sym * (1.0 - 0.25 * gam * (2.0 - gam));
+                    if (pk) v += (double)prm.D[i % 3];
+                    v += (double)reg;
+                }
+                const int r0 = 4 * b;
 #pragma unroll
-                    for (int f = 0; f < 4; ++f)
-                        v += c.sig[r0 + f] * (double)c.arow[3 * (r0 + f) + i % 3] * (double)c.arow[3 * (r0 + f) + j % 3];
-                    if (i == j) v += (double)reg;
-                } else if (i == j) {
-                    const bool fr = qfree(c, k, i - 24);
-                    v = fr ? v + c.sig[32 + i - 24] + c.sig[38 + i - 24] + (double)reg : 1.0;  // fixed q: exact identity row
-                }
-                c.QuuD[9 * (i / 3) + 3 * (i % 3) + j % 3] = v;
-                vf = 0.f;  // the float copy of a diagonal block collects the updates by earlier columns
-            } else if (i < NF && (i / 12) == (j / 12) && (i % 3) == (j % 3)) {
-                // another corner of the same foot, same axis: symmetry-cost coupling
-                const float gam = gam_of(c, i / 12, k);
-                vf -= 2.f * prm.w_sym * 0.25f * gam * (2.f - gam);
+                for (int f = 0; f < 4; ++f)
+                    v += c.sig[r0 + f] * (double)c.arow[3 * (r0 + f) + rr] * (double)c.arow[3 * (r0 + f) + cc];
+            } else if (i == j) {
+                const bool fr = qfree(c, k, i - 24);
+                v = fr ? v + c.sig[32 + i - 24] + c.sig[38 + i - 24] + (double)reg : 1.0;  // fixed q: exact identity row
             }
-            c.QuuF[i * RLD + j] = vf;
-        }
-        for (int e = tid; e < NS * NU; e += NT) {  // identity rows of the panel are made in registers (phase 3)
-            const int r = e / NU, i = e % NU;  // panel row r (column of Qus), entry i
-            float v;
-            {
-                const int j = r;
-                v = c.G[c.Arow[3 * j] * GLD + i] * c.Aval[3 * j] + c.G[c.Arow[3 * j + 1] * GLD + i] * c.Aval[3 * j + 1]
-                    + c.G[c.Arow[3 * j + 2] * GLD + i] * c.Aval[3 * j + 2];
-                if (i < NF) {
-                    // S[f_cj, pos_c] = gam Sx ; S[f_cj, com] = -gam Sx   (Sx = dt [lam_h]x, zero diagonal)
-                    const int ct = i / 12, a = i % 3;
-                    const int b = j < 3 ? j : j - 9 - 3 * ct;
-                    const float sgn = j < 3 ? -1.f : ((b >= 0 && b < 3) ? 1.f : 0.f);
-                    v += sgn * gam_of(c, ct, k) * c.arow[96 + 3 * a + ((b >= 0 && b < 3) ? b : 0)];
-                }
-            }
-            c.Pan[r * RLD + i] = v;
-        }
-        if (tid >= 192 && tid < 192 + NU) {  // qu on wave 3 (float64 -> float: it vanishes at convergence, so float keeps its relative accuracy)
+            c.QuuD[9 * b + 3 * rr + cc] = v;
+            c.QuuF[i * RLD + j] = 0.f;  // the float copy of a diagonal block collects the updates by earlier blocks
+        } else if (tid >= 192 && tid < 192 + NU) {
+            // qu (float64 -> float: it vanishes at convergence, so float keeps its relative accuracy)
             const int iq = tid - 192;
             double g;
             if (iq < NF) {
@@ -764,21 +781,31 @@ __device__ int riccati_backward(const Ctx& c, const CmpcConsts& prm, int tid, bo
             }
             g += Bt_vec<double>(c, prm, k, iq, c.Pd);
             c.Pan[(NPAN - 1) * RLD + iq] = (float)g;
-        } else if (tid >= 64 && tid < 64 + NS) {
-            const int i = tid - 64;
-            c.qs[i] = grad_track(c, prm, k, i) + At_vec<double>(c, prm, k, i, c.Pd);
-        }
-        for (int e = tid + 128; e < 128 + NS * NS; e += NT) {  // Qss = A^T T1 + Q
-            const int e2 = e - 128, i = e2 / NS, j = e2 % NS;
-            float v = (i == j) ? qdiag(prm, k, i) : 0.f;
-            v += c.Aval[3 * i] * c.T1[c.Arow[3 * i] * NS + j] + c.Aval[3 * i + 1] * c.T1[c.Arow[3 * i + 1] * NS + j]
-                 + c.Aval[3 * i + 2] * c.T1[c.Arow[3 * i + 2] * NS + j];
-            Pnew[i * PLD + j] = v;
         }
         __syncthreads();
         PROF(2);
-        // ---- phase 3: fused Cholesky + panel solve (waves 0 and 1; each repeats the factorisation) ----
+        // ---- phase 3: fused Cholesky + panel solve on waves 0 and 1 (each repeats the factorisation).  Waves 2, 3
+        // meanwhile build what only phase 4 reads: Qss = A^T Pss A + Q (lower triangle, nine products per entry
+        // straight from the column descriptors) and qs ----
         if (tid < 128) phase_factor<NC, FG>(N, FG ? c.Lf : nullptr, k);
+        else {
+            const int t = tid - 128;
+            if (t < 120) {
+                const unsigned short ij = c.tri[t];
+                const int i = ij >> 8, j = ij & 255;
+                const float ai0 = c.Aval[3 * i], ai1 = c.Aval[3 * i + 1], ai2 = c.Aval[3 * i + 2];
+                const float aj0 = c.Aval[3 * j], aj1 = c.Aval[3 * j + 1], aj2 = c.Aval[3 * j + 2];
+                const float* P0r = Pcur + c.Arow[3 * i] * PLD;
+                const float* P1r = Pcur + c.Arow[3 * i + 1] * PLD;
+                const float* P2r = Pcur + c.Arow[3 * i + 2] * PLD;
+                const int c0 = c.Arow[3 * j], c1 = c.Arow[3 * j + 1], c2 = c.Arow[3 * j + 2];
+                float v = (i == j) ? qdiag(prm, k, i) : 0.f;
+                v += ai0 * (aj0 * P0r[c0] + aj1 * P0r[c1] + aj2 * P0r[c2]) + ai1 * (aj0 * P1r[c0] + aj1 * P1r[c1] + aj2 * P1r[c2])
+                     + ai2 * (aj0 * P2r[c0] + aj1 * P2r[c1] + aj2 * P2r[c2]);
+                Pnew[i * PLD + j] = v;
+            }
+            if (t < NS) c.qs[t] = grad_track(c, prm, k, t) + At_vec<double>(c, prm, k, t, c.Pd);
+        }
         __syncthreads();
         PROF(3);
         if (*c.flag) return 1;
@@ -884,10 +911,17 @@ __device__ void riccati_forward(const Ctx& c, const CmpcConsts& prm, int tid, bo
             const int q4 = 4 * half + t;
             uoff[t] = q4 >= blk ? ub_row(r) + 4 * (q4 - blk) : REC_ZERO;
         }
-        // roles in the dynamics step
-        const int ga = tid >> 3, cj = tid & 7;              // lanes 0..23: axis ga of corner cj
+        // roles in the dynamics step: lanes 0..23 form the corner terms (axis ga of corner cj), lanes 0..14 then
+        // evaluate one row each of  ds+ = A ds + B du + d  with per-lane coefficients, branch-free:
+        //   out = sj ds_j + ce ds_je + cD sumD_a + cH (sumH_a + dt sum_ct gam_ct (e_ct x Fc_ct)_a) + cp (R_ct dq_ct)_a + d_j
+        const int ga = tid >> 3, cj = tid & 7;
         const int ga1 = (ga + 1) % 3, ga2 = (ga + 2) % 3;
-        const int qb = tid - 24, qct = qb >= 3 ? 1 : 0, qa = qb - 3 * qct;  // lanes 24..29: position row 9 + qb
+        const int j = tid < NS ? tid : 0;
+        const int ja = j % 3, ja1 = (ja + 1) % 3, ja2 = (ja + 2) % 3, jct = j >= 12 ? 1 : 0;
+        const int je = j < 3 ? j + 3 : 0;
+        const float ce = j < 3 ? prm.dt : 0.f;
+        const float cD = (j >= 3 && j < 6) ? 1.f : 0.f, cH = (j >= 6 && j < 9) ? 1.f : 0.f;
+        const bool isPos = j >= 9;
         const float Dm = prm.D[r % 3];
         if (tid < 40) xb[tid] = tid == 15 ? 1.f : 0.f;
         if (tid < NS) c.dS[tid] = 0.f;
@@ -904,11 +938,13 @@ __device__ void riccati_forward(const Ctx& c, const CmpcConsts& prm, int tid, bo
             // stage data of the dynamics step (independent of the recursion as well)
             const float* geo = c.geoA + GEO * k;
             const float gam0 = gam_of(c, 0, k), gam1 = gam_of(c, 1, k);
-            float g_r1 = 0.f, g_r2 = 0.f, g_dt = 0.f, dk = 0.f;
-            if (tid < 24) {
-                g_r1 = geo[3 * cj + ga1]; g_r2 = geo[3 * cj + ga2];
-                g_dt = prm.dt * (cj < 4 ? gam0 : gam1);
-            }
+            const float g_r1 = tid < 24 ? geo[3 * cj + ga1] : 0.f, g_r2 = tid < 24 ? geo[3 * cj + ga2] : 0.f;
+            const float g_dt = tid < 24 ? prm.dt * (cj < 4 ? gam0 : gam1) : 0.f;
+            const float F01 = geo[24 + ja1], F02 = geo[24 + ja2], F11 = geo[27 + ja1], F12 = geo[27 + ja2];
+            const float* Rj = c.sp + c.L.pR(jct) + 9 * k;
+            const float R0 = Rm(Rj, ja, 0), R1 = Rm(Rj, ja, 1), R2 = Rm(Rj, ja, 2);
+            const float dk = c.d[NS * k + j];
+            const float gamj = jct ? gam1 : gam0;
             PROF2(20);
             float4 xv[5];
 #pragma unroll
@@ -932,37 +968,23 @@ __device__ void riccati_forward(const Ctx& c, const CmpcConsts& prm, int tid, bo
             wave_lds_sync();
             PROF2(22);
             // ---- ds+ = A ds + B du + d ----
-            float tD = 0.f, tH = 0.f;
             const float* duk = c.dU + NU * k;
-            if (tid < 24) {
-                tD = g_dt * duk[3 * cj + ga];
-                tH = g_dt * (g_r1 * duk[3 * cj + ga2] - g_r2 * duk[3 * cj + ga1]);
-            }
-            tD = oct_sum(tD);
-            tH = oct_sum(tH);
-            float out = 0.f;
-            int row = -1;
-            if (tid < 24) {
-                if (cj == 0) { row = ga; out = xb[ga] + prm.dt * xb[3 + ga]; }
-                else if (cj == 1) { row = 3 + ga; out = xb[3 + ga] + tD; }
-                else if (cj == 2) {
-                    row = 6 + ga;
-                    const float* F0 = geo + 24;
-                    const float* F1 = geo + 27;
-                    const float e01 = xb[9 + ga1] - xb[ga1], e02 = xb[9 + ga2] - xb[ga2];
-                    const float e11 = xb[12 + ga1] - xb[ga1], e12 = xb[12 + ga2] - xb[ga2];
-                    out = xb[6 + ga] + tH + prm.dt * (gam0 * (e01 * F0[ga2] - e02 * F0[ga1]) + gam1 * (e11 * F1[ga2] - e12 * F1[ga1]));
-                }
-            } else if (tid < 30) {
-                const float* R = c.sp + c.L.pR(qct) + 9 * k;
-                const float gam = qct ? gam1 : gam0;
-                row = 9 + qb;
-                out = gam * xb[9 + qb]
-                      + (1.f - gam) * (Rm(R, qa, 0) * duk[24 + 3 * qct] + Rm(R, qa, 1) * duk[25 + 3 * qct] + Rm(R, qa, 2) * duk[26 + 3 * qct]);
-            }
-            if (row >= 0) dk = c.d[NS * k + row];
+            const int cb = tid < 24 ? 3 * cj : 0;
+            const float u0 = duk[cb + ga], u1 = duk[cb + ga1], u2 = duk[cb + ga2];
+            const float xs = xb[j], xe = xb[je];
+            const float c1 = xb[ja1], c2 = xb[ja2];
+            const float p01 = xb[9 + ja1], p02 = xb[9 + ja2], p11 = xb[12 + ja1], p12 = xb[12 + ja2];
+            const float q0 = duk[24 + 3 * jct], q1 = duk[25 + 3 * jct], q2 = duk[26 + 3 * jct];
+            const float tD = oct_sum(g_dt * u0);
+            const float tH = oct_sum(g_dt * (g_r1 * u2 - g_r2 * u1));
+            const float sD = ja == 0 ? readlane_f(tD, 0) : (ja == 1 ? readlane_f(tD, 8) : readlane_f(tD, 16));
+            const float sH = ja == 0 ? readlane_f(tH, 0) : (ja == 1 ? readlane_f(tH, 8) : readlane_f(tH, 16));
+            const float cross = gam0 * ((p01 - c1) * F02 - (p02 - c2) * F01) + gam1 * ((p11 - c1) * F12 - (p12 - c2) * F11);
+            const float land = R0 * q0 + R1 * q1 + R2 * q2;
+            float out = (isPos ? gamj : 1.f) * xs + ce * xe + cD * sD + cH * (sH + prm.dt * cross) + dk;
+            if (isPos) out += (1.f - gamj) * land;
             wave_lds_sync();
-            if (row >= 0) { out += dk; c.dS[NS * (k + 1) + row] = out; xb[row] = out; }
+            if (tid < NS) { c.dS[NS * (k + 1) + tid] = out; xb[tid] = out; }
             if (tid < NF) xb[16 + tid] = -Dm * du;
             wave_lds_sync();
             PROF2(23);
@@ -1112,42 +1134,60 @@ __device__ void step_lengths(const Ctx& c, int tid, float tau, float& ap, float&
 __device__ void costate_update(const Ctx& c, const CmpcConsts& prm, int tid, float ap, bool use_exact)
 {
     const int N = c.N;
+    // gam-weighted sums of the force step per foot and in total (the defect array is free until the next
+    // iteration's residual pass): d[NS k + 3 ct + a], d[NS k + 6 + a]
+    for (int e = tid; e < 9 * N; e += blockDim.x) {
+        const int k = e / 9, t = e - 9 * k;
+        const float* du = c.dU + NU * k;
+        const int a = t % 3;
+        const float s0 = gam_of(c, 0, k) * (du[a] + du[3 + a] + du[6 + a] + du[9 + a]);
+        const float s1 = gam_of(c, 1, k) * (du[12 + a] + du[15 + a] + du[18 + a] + du[21 + a]);
+        c.d[NS * k + t] = t < 3 ? s0 : (t < 6 ? s1 : s0 + s1);
+    }
+    __syncthreads();
     if (tid < 64) {
+        // lane j < 15 owns costate component j.  Everything below is one formula with per-lane coefficients:
+        //   lam_j = w (s_j - ref_j + ds_j) + sj pv_j + ce pv_je + cg (pv_{6+a1} F_a2 - pv_{6+a2} F_a1)
+        //           + eg (dF_a1 lamh_a2 - dF_a2 lamh_a1)                       (exact Hessian only)
+        const int j = tid < NS ? tid : 0;
+        const int ja = j < 3 ? j : (j >= 9 ? (j - 9) % 3 : 0), ja1 = (ja + 1) % 3, ja2 = (ja + 2) % 3;
+        const int jct = j >= 12 ? 1 : 0;
+        const int roff = j < 3 ? c.L.pComref() + j : (j < 6 ? c.L.pComref() : (j < 9 ? c.L.pHref() + j - 6 : c.L.pNom(jct) + ja));
+        const double wc = j == 0 ? 2.0 * prm.w_com0 : (j == 1 ? 2.0 * prm.w_com1 : (j < 6 ? 0.0 : (j < 9 ? 2.0 * prm.w_h : 2.0 * prm.w_pos)));
+        const int gfo = j < 3 ? 30 : 24 + 3 * jct;       // Fsum or Fc of the foot (geometry record)
+        const int dfo = j < 3 ? 6 : 3 * jct;             // total or per-foot force-step sum
+        const int je = (j >= 3 && j < 6) ? j - 3 : 0;
+        const double ce = (j >= 3 && j < 6) ? (double)prm.dt : 0.0;
+        const double eg = !use_exact ? 0.0 : (j < 3 ? -(double)prm.dt : (j >= 9 ? (double)prm.dt : 0.0));
         if (tid < 3) c.qs[tid] = c.LAM[NS * N + 6 + tid];  // lam_h,N the Hessian used
-        if (tid < NS) c.pv[tid] = grad_track(c, prm, N, tid) + (double)qdiag(prm, N, tid) * (double)c.dS[NS * N + tid];
+        if (tid < NS) {
+            const double w = j == 2 ? (double)prm.wz2[N] : wc;
+            c.pv[tid] = w * (((double)c.S[NS * N + j] - (double)c.sp[roff + 3 * N]) + (double)c.dS[NS * N + j]);
+        }
         wave_lds_sync();
         if (tid < NS) c.LAM[NS * N + tid] += (double)ap * (c.pv[tid] - c.LAM[NS * N + tid]);
         for (int k = N - 1; k >= 1; --k) {
+            double v = 0.0, lold = 0.0;
             if (tid < NS) {
-                double v = grad_track(c, prm, k, tid) + (double)qdiag(prm, k, tid) * (double)c.dS[NS * k + tid] + At_vec<double>(c, prm, k, tid, c.pv);
-                if (use_exact && (tid < 3 || tid >= 9)) {
-                    const double* lh = c.qs;  // old lam_h of stage k+1
-                    const int i = tid < 3 ? tid : (tid - 9) % 3;
-                    const int a1 = (i + 1) % 3, a2 = (i + 2) % 3;
-                    const float* du = c.dU + NU * k;
-                    const double g0 = gam_of(c, 0, k), g1 = gam_of(c, 1, k);
-                    double F1, F2;  // components a1, a2 of the gam-weighted force-step sum
-                    if (tid < 3) {
-                        F1 = g0 * ((double)du[a1] + du[3 + a1] + du[6 + a1] + du[9 + a1]) + g1 * ((double)du[12 + a1] + du[15 + a1] + du[18 + a1] + du[21 + a1]);
-                        F2 = g0 * ((double)du[a2] + du[3 + a2] + du[6 + a2] + du[9 + a2]) + g1 * ((double)du[12 + a2] + du[15 + a2] + du[18 + a2] + du[21 + a2]);
-                    } else {
-                        const int ct = (tid - 9) / 3;
-                        const float* df = du + 12 * ct;
-                        const double g = ct ? g1 : g0;
-                        F1 = g * ((double)df[a1] + df[3 + a1] + df[6 + a1] + df[9 + a1]);
-                        F2 = g * ((double)df[a2] + df[3 + a2] + df[6 + a2] + df[9 + a2]);
-                    }
-                    // (S^T du) = dt (F x lam_h) on pos rows, minus that on com rows
-                    const double sxtf = (double)prm.dt * (F1 * lh[a2] - F2 * lh[a1]);
-                    v += (tid < 3) ? -sxtf : sxtf;
-                }
-                c.pn[tid] = v;
+                const float* geo = c.geoA + GEO * k;
+                const float* F = geo + gfo;
+                const float* dF = c.d + NS * k + dfo;
+                const double gam = jct ? gam_of(c, 1, k) : gam_of(c, 0, k);
+                const double sj = j >= 9 ? gam : 1.0;
+                const double cg = j < 3 ? (double)prm.dt : (j >= 9 ? -(double)prm.dt * gam : 0.0);
+                const double w = j == 2 ? (double)prm.wz2[k] : wc;
+                const double* pv = c.pv;
+                const double* lh = c.qs;  // lam_h of stage k+1 as the Hessian used it
+                lold = c.LAM[NS * k + j];
+                v = w * (((double)c.S[NS * k + j] - (double)c.sp[roff + 3 * k]) + (double)c.dS[NS * k + j])
+                    + sj * pv[j] + ce * pv[je] + cg * (pv[6 + ja1] * (double)F[ja2] - pv[6 + ja2] * (double)F[ja1])
+                    + eg * ((double)dF[ja1] * lh[ja2] - (double)dF[ja2] * lh[ja1]);
             }
             wave_lds_sync();
             if (tid < NS) {
-                c.pv[tid] = c.pn[tid];
-                if (tid >= 6 && tid < 9) c.qs[tid - 6] = c.LAM[NS * k + tid];
-                c.LAM[NS * k + tid] += (double)ap * (c.pn[tid] - c.LAM[NS * k + tid]);
+                c.pv[j] = v;
+                if (j >= 6 && j < 9) c.qs[j - 6] = lold;
+                c.LAM[NS * k + j] = lold + (double)ap * (v - lold);
             }
             wave_lds_sync();
         }

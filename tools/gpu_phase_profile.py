@@ -7,7 +7,7 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: F401  (same HIP runtime)
 import cmpc_amd as cm
 cm._capi.LIB_PATH = os.path.join(os.path.dirname(cm._capi.LIB_PATH), "libcmpc_hip_prof.so")
-names = ["ph0 desc+rows+Pd", "ph1 G,T1", "ph2 Quu,panel,Qss", "ph3 fused chol+solve", "ph4 P update", "-", "-", "-", "-", "-",
+names = ["ph0 desc+rows+Pd", "ph1 G,T1", "ph2 Quu,panel,Qss", "ph3 fused chol+solve", "ph4 P update", "ph2/w0: Quu", "ph2/w0: Qus", "ph2/w3: Quu", "ph2/w3: Qus", "ph2/w3: qu+Qss",
          "residuals", "backward(total)", "fwd1", "steps+muaff", "delta", "fwd2", "steplen+costate", "update+conv"]
 cfg, P, X0 = cm.synthetic.config2_perturbed_com(256)
 s = cm.BatchSolver(cfg, 256)
@@ -15,7 +15,7 @@ X, info, rc = s.solve_host(P, X0)
 out = (C.c_longlong * 32)()
 cm._capi.lib().cmpc_profile_read(out, 1)
 v = np.array(out[:18], float)
-tot = v[10:].sum()
+tot = v[10:18].sum()
 print("iters block0", info[0, 0], "total cycles (sum of phases) %.3g" % tot, "kernel cycles %.3g" % info[0, 6])
 for n, x in zip(names, v):
     print("%-22s %12.0f  %5.1f%%  per stage-iter %8.0f" % (n, x, 100 * x / tot, x / (info[0, 0] * cfg.N)))
