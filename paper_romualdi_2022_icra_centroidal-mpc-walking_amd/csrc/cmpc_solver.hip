@@ -63,6 +63,7 @@ __device__ float g_trace[64 * 8];  // per iteration of workgroup 0: mu, ep, ec, 
 #define PROF(slot) do { long long n_ = __builtin_amdgcn_s_memtime(); if (threadIdx.x == 0 && blockIdx.x == 0) g_prof[slot] += n_ - pt_; pt_ = n_; } while (0)
 #define PROF2_DECL long long pt2_ = __builtin_amdgcn_s_memtime()
 #define PROF3(slot) do { long long n_ = __builtin_amdgcn_s_memtime(); if (threadIdx.x == 192 && blockIdx.x == 0) g_prof[slot] += n_ - pt2_; pt2_ = n_; } while (0)
+#define PROF4(slot) do { long long n_ = __builtin_amdgcn_s_memtime(); if (threadIdx.x == 128 && blockIdx.x == 0) g_prof[slot] += n_ - pt2_; pt2_ = n_; } while (0)
 #define PROF2(slot) do { long long n_ = __builtin_amdgcn_s_memtime(); if (threadIdx.x == 0 && blockIdx.x == 0) g_prof[slot] += n_ - pt2_; pt2_ = n_; } while (0)
 #else
 #define PROF_DECL
@@ -70,6 +71,7 @@ __device__ float g_trace[64 * 8];  // per iteration of workgroup 0: mu, ep, ec, 
 #define PROF2_DECL
 #define PROF2(slot)
 #define PROF3(slot)
+#define PROF4(slot)
 #endif
 
 struct Ctx {
@@ -560,39 +562,18 @@ __device__ inline void stage_factor(const float* QuuF, const double* QuuD, float
 
 // ---- Riccati backward sweep (matrices + right-hand side of the affine step).
 // Returns (uniformly) 0 ok, 1 non-positive pivot. ----
-// phase 3 out of line: its long stream of v_readlane broadcasts wants the SGPR file to itself
-template <int NC, bool FG>
-__device__ __attribute__((noinline)) void phase_factor(int Nrt, float* fg_base, int k)
-{
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int N = NC > 0 ? NC : Nrt;
-    Ctx c;
-    make_ctx<FG>(c, smem, N, fg_base);
-    const CmpcConsts& prm = *reinterpret_cast<const CmpcConsts*>(smem);
-    const int fixedmask = (~c.qmask[k]) & 63;
-    stage_factor(c.QuuF, c.QuuD, c.Pan, c.Lf + (size_t)REC_N * k, prm.D[0], prm.D[1], prm.D[2], c.flag, threadIdx.x, fixedmask);
-}
-
+// ---- one stage of the backward sweep, in three out-of-line pieces (each with a register allocation of its
+// own; inlined into one loop the stage needs > 512 VGPRs and spills to scratch):
+//   stage_pre   phases 0-2: descriptors, G = P [B;E], Quu / Qus / qu
+//   stage_qss   Qss, qs on waves 2-3 while waves 0-1 factorise (phase_factor)
+//   stage_post  phase 4: P <- [Qss 0; 0 D] - W^T W, value gradient ----
 template <int NT, int NC, bool FG>
-__device__ int riccati_backward(const Ctx& c, const CmpcConsts& prm, int tid, bool use_exact, float reg, float cmu)
+__device__ inline void stage_pre_body(const Ctx& c, const CmpcConsts& prm, int tid, int k, const float* Pcur, bool havep,
+                                      bool use_exact, float reg, float cmu)
 {
-    const int N = c.N;
-    float* Pcur = c.P0;  // value function of stage k+1
-    float* Pnew = c.P1;
-    bool havep = false;
-    for (int e = tid; e < NXA * PLD; e += NT) Pcur[e] = 0.f;
-    if (tid == 0) *c.flag = 0;
-    __syncthreads();
-    if (tid < NS) {
-        Pcur[tid * PLD + tid] = qdiag(prm, N, tid);
-        c.pv[tid] = grad_track(c, prm, N, tid);
-    } else if (tid < NXA) c.pv[tid] = 0.0;
-    __syncthreads();
-
-    for (int k = N - 1; k >= 0; --k) {
-        const bool pk = k > 0;
-        const float* u = c.U + NU * k;
-        const float* geo = c.geoA + GEO * k;
+    const bool pk = k > 0;
+    const float* u = c.U + NU * k;
+    const float* geo = c.geoA + GEO * k;
         PROF_DECL;
         // ---- phase 0: column descriptors of A and B, barrier coefficients ----
         if (tid < NU) {
@@ -697,47 +678,70 @@ __device__ int riccati_backward(const Ctx& c, const CmpcConsts& prm, int tid, bo
         // (cost, barrier and Levenberg terms).  Wave 3: qu in float64. ----
         PROF2_DECL;
         if (tid < 128) {
-            // seven items per thread: all values first, stores last (the loads of one item do not wait for another's store)
-            float val[7];
-            int adr[7];
+            // 285 triples of consecutive entries -- 135 of Quu (row i, block column bj < bi), 150 of Qus^T (row j, the xyz
+            // of one corner / one foot's offset) -- in three rounds of one branch-free formula:
+            //   out_c = sum_a w_a G[row_a][col0 + c] + ew E[c es]          (descriptor (row_a, w_a): column i of B or j of A)
+            // Addresses, then descriptor loads, then G loads, then arithmetic, then stores: the rounds overlap.
+            const float* Gp = c.G;
+            int dsc[3], col0[3], sto[3], eo[3], es[3], symc[3];
+            float ew[3], symw[3];
+            bool ok[3];
 #pragma unroll
-            for (int it = 0; it < 7; ++it) {
-                const int e = tid + 128 * it;
-                float vf = 0.f;
-                int ad = -1;
-                if (e < 405) {
-                    // block pair (bi > bj) number e / 9 of the strict lower block triangle, entry e % 9 inside it
-                    const unsigned short ij = c.tri[e / 9];
-                    const int w = e % 9;
-                    const int i = 3 * ((ij >> 8) + 1) + w / 3, j = 3 * (ij & 255) + w % 3;
-                    const int b0 = c.Brow[3 * i], b1 = c.Brow[3 * i + 1], b2 = c.Brow[3 * i + 2];
-                    // [B;E]^T P [B;E]
-                    vf = c.Bval[3 * i] * c.G[b0 * GLD + j] + c.Bval[3 * i + 1] * c.G[b1 * GLD + j] + c.Bval[3 * i + 2] * c.G[b2 * GLD + j];
-                    if (havep && i < NF) vf += c.G[(NS + i) * GLD + j];
-                    if (i < NF && (i / 12) == (j / 12) && (i % 3) == (j % 3)) {
-                        // another corner of the same foot, same axis: symmetry-cost coupling
-                        const float gam = gam_of(c, i / 12, k);
-                        vf -= 2.f * prm.w_sym * 0.25f * gam * (2.f - gam);
-                    }
-                    ad = (int)(c.QuuF - c.Pan) + i * RLD + j;
-                } else if (e < 405 + NS * NU) {  // identity rows of the panel are made in registers (phase 3)
-                    const int e2 = e - 405, j = e2 / NU, i = e2 % NU;  // panel row j (column of Qus), entry i
-                    vf = c.G[c.Arow[3 * j] * GLD + i] * c.Aval[3 * j] + c.G[c.Arow[3 * j + 1] * GLD + i] * c.Aval[3 * j + 1]
-                         + c.G[c.Arow[3 * j + 2] * GLD + i] * c.Aval[3 * j + 2];
-                    if (i < NF) {
-                        // S[f_cj, pos_c] = gam Sx ; S[f_cj, com] = -gam Sx   (Sx = dt [lam_h]x, zero diagonal)
-                        const int ct = i / 12, a = i % 3;
-                        const int b = j < 3 ? j : j - 9 - 3 * ct;
-                        const float sgn = j < 3 ? -1.f : ((b >= 0 && b < 3) ? 1.f : 0.f);
-                        vf += sgn * gam_of(c, ct, k) * c.arow[96 + 3 * a + ((b >= 0 && b < 3) ? b : 0)];
-                    }
-                    ad = j * RLD + i;
-                }
-                val[it] = vf; adr[it] = ad;
+            for (int rd = 0; rd < 3; ++rd) {
+                int id = tid + 128 * rd;
+                ok[rd] = id < 285;
+                id = ok[rd] ? id : 0;
+                const bool kind = id < 135;  // true: Quu
+                const int idq = kind ? id : 0, idp = kind ? 0 : id - 135;
+                const unsigned short ij = c.tri[idq / 3];
+                const int i = 3 * ((ij >> 8) + 1) + idq % 3, j0 = 3 * (ij & 255);
+                const int jr = idp / 10, i0 = 3 * (idp % 10);
+                dsc[rd] = kind ? 3 * i : 3 * NU + 3 * jr;
+                col0[rd] = kind ? j0 : i0;
+                sto[rd] = kind ? (int)(c.QuuF - c.Pan) + i * RLD + j0 : jr * RLD + i0;
+                // extra term: Quu rows of a force get the E^T P block; Qus^T entries of a force get -/+ gam Sx
+                const int ct = i0 / 12;
+                const int bb = jr < 3 ? jr : jr - 9 - 3 * ct;
+                const bool bin = bb >= 0 && bb < 3;
+                const float sgn = jr < 3 ? -1.f : (bin ? 1.f : 0.f);
+                eo[rd] = kind ? (NS + (i < NF ? i : 0)) * GLD + j0 : (int)(c.arow - c.G) + 96 + (bin ? bb : 0);
+                es[rd] = kind ? 1 : 3;
+                ew[rd] = kind ? ((havep && i < NF) ? 1.f : 0.f) : (i0 < NF ? sgn * gam_of(c, ct, k) : 0.f);
+                // another corner of the same foot, same axis: symmetry-cost coupling (Quu only)
+                const bool sy = kind && i < NF && (i / 12) == (j0 / 12);
+                const float gq = gam_of(c, i < 12 ? 0 : 1, k);
+                symc[rd] = i % 3;
+                symw[rd] = sy ? 2.f * prm.w_sym * 0.25f * gq * (2.f - gq) : 0.f;
             }
+            int r0[3], r1[3], r2[3];
+            float w0[3], w1[3], w2[3];
 #pragma unroll
-            for (int it = 0; it < 7; ++it)
-                if (it < 6 || adr[it] != -1) c.Pan[adr[it]] = val[it];   // QuuF sits NU * RLD floats below Pan
+            for (int rd = 0; rd < 3; ++rd) {
+                r0[rd] = c.Brow[dsc[rd]]; r1[rd] = c.Brow[dsc[rd] + 1]; r2[rd] = c.Brow[dsc[rd] + 2];
+                w0[rd] = c.Bval[dsc[rd]]; w1[rd] = c.Bval[dsc[rd] + 1]; w2[rd] = c.Bval[dsc[rd] + 2];
+            }
+            float o[3][3];
+#pragma unroll
+            for (int rd = 0; rd < 3; ++rd) {
+                const float* g0 = Gp + r0[rd] * GLD + col0[rd];
+                const float* g1 = Gp + r1[rd] * GLD + col0[rd];
+                const float* g2 = Gp + r2[rd] * GLD + col0[rd];
+                const float* E = Gp + eo[rd];
+#pragma unroll
+                for (int cc = 0; cc < 3; ++cc) {
+                    float v = w0[rd] * g0[cc] + w1[rd] * g1[cc] + w2[rd] * g2[cc] + ew[rd] * E[cc * es[rd]];
+                    if (cc == symc[rd]) v -= symw[rd];
+                    o[rd][cc] = v;
+                }
+            }
+            PROF2(5);
+#pragma unroll
+            for (int rd = 0; rd < 3; ++rd)
+                if (ok[rd]) {
+                    float* dst = c.Pan + sto[rd];   // QuuF sits NU * RLD floats below Pan
+                    dst[0] = o[rd][0]; dst[1] = o[rd][1]; dst[2] = o[rd][2];
+                }
+            PROF2(6);
         } else if (tid < 128 + 60) {
             // lower entry w of diagonal block tid' / 6: (row, col) = (0,0) (1,0) (1,1) (2,0) (2,1) (2,2)
             const int t = tid - 128, b = t / 6, w = t - 6 * b;
@@ -764,6 +768,7 @@ __device__ int riccati_backward(const Ctx& c, const CmpcConsts& prm, int tid, bo
             }
             c.QuuD[9 * b + 3 * rr + cc] = v;
             c.QuuF[i * RLD + j] = 0.f;  // the float copy of a diagonal block collects the updates by earlier blocks
+            PROF4(7);
         } else if (tid >= 192 && tid < 192 + NU) {
             // qu (float64 -> float: it vanishes at convergence, so float keeps its relative accuracy)
             const int iq = tid - 192;
@@ -781,14 +786,15 @@ __device__ int riccati_backward(const Ctx& c, const CmpcConsts& prm, int tid, bo
             }
             g += Bt_vec<double>(c, prm, k, iq, c.Pd);
             c.Pan[(NPAN - 1) * RLD + iq] = (float)g;
+            PROF3(8);
         }
         __syncthreads();
         PROF(2);
-        // ---- phase 3: fused Cholesky + panel solve on waves 0 and 1 (each repeats the factorisation).  Waves 2, 3
-        // meanwhile build what only phase 4 reads: Qss = A^T Pss A + Q (lower triangle, nine products per entry
-        // straight from the column descriptors) and qs ----
-        if (tid < 128) phase_factor<NC, FG>(N, FG ? c.Lf : nullptr, k);
-        else {
+}
+
+template <int NT>
+__device__ inline void stage_qss_body(const Ctx& c, const CmpcConsts& prm, int tid, int k, const float* Pcur, float* Pnew)
+{
             const int t = tid - 128;
             if (t < 120) {
                 const unsigned short ij = c.tri[t];
@@ -805,10 +811,14 @@ __device__ int riccati_backward(const Ctx& c, const CmpcConsts& prm, int tid, bo
                 Pnew[i * PLD + j] = v;
             }
             if (t < NS) c.qs[t] = grad_track(c, prm, k, t) + At_vec<double>(c, prm, k, t, c.Pd);
-        }
-        __syncthreads();
-        PROF(3);
-        if (*c.flag) return 1;
+}
+
+template <int NT>
+__device__ inline void stage_post_body(const Ctx& c, const CmpcConsts& prm, int tid, int k, float* Pnew)
+{
+    const bool pk = k > 0;
+    const float* u = c.U + NU * k;
+    PROF_DECL;
         // ---- phase 4: P = [Qss 0; 0 D] - W^T W  (rows of the panel are W^T rows; p rows pre-scaled by -D) ----
         {
             // 2x2 output tiles: thread <-> tile (bi, bj), bj <= bi, of the 39x39 (or 15x15) lower triangle
@@ -871,12 +881,72 @@ __device__ int riccati_backward(const Ctx& c, const CmpcConsts& prm, int tid, bo
         }
         __syncthreads();
         PROF(4);
-        if (tid < NXA) c.pv[tid] = c.pn[tid];
-        {
-            float* t = Pcur; Pcur = Pnew; Pnew = t;
-        }
-        havep = pk;
+    if (tid < NXA) c.pv[tid] = c.pn[tid];
+    __syncthreads();
+}
+
+// ---- out-of-line phases: each rebuilds the LDS map from the LDS base it is handed (an address-space-3
+// pointer, so the callee needs no dynamic-LDS table lookup and still addresses LDS with ds_ instructions) ----
+typedef __attribute__((address_space(3))) char* lds_t;
+#define CMPC_PHASE_PROLOGUE                                                            \
+    char* smem = (char*)lds;                                                           \
+    const int N = NC > 0 ? NC : Nrt;                                                   \
+    Ctx c;                                                                             \
+    make_ctx<FG>(c, smem, N, fg_base);                                                 \
+    const CmpcConsts& prm = *reinterpret_cast<const CmpcConsts*>(smem);                \
+    const int tid = threadIdx.x
+
+template <int NC, bool FG>
+__device__ __attribute__((noinline)) void phase_factor(lds_t lds, int Nrt, float* fg_base, int k)
+{
+    CMPC_PHASE_PROLOGUE;
+    const int fixedmask = (~c.qmask[k]) & 63;
+    stage_factor(c.QuuF, c.QuuD, c.Pan, c.Lf + (size_t)REC_N * k, prm.D[0], prm.D[1], prm.D[2], c.flag, tid, fixedmask);
+}
+template <int NT, int NC, bool FG>
+__device__ __attribute__((noinline)) void stage_pre(lds_t lds, int Nrt, float* fg_base, int k, int par, bool havep, bool use_exact, float reg, float cmu)
+{
+    CMPC_PHASE_PROLOGUE;
+    stage_pre_body<NT, NC, FG>(c, prm, tid, k, par ? c.P1 : c.P0, havep, use_exact, reg, cmu);
+}
+template <int NT, int NC, bool FG>
+__device__ __attribute__((noinline)) void stage_qss(lds_t lds, int Nrt, float* fg_base, int k, int par)
+{
+    CMPC_PHASE_PROLOGUE;
+    stage_qss_body<NT>(c, prm, tid, k, par ? c.P1 : c.P0, par ? c.P0 : c.P1);
+}
+template <int NT, int NC, bool FG>
+__device__ __attribute__((noinline)) void stage_post(lds_t lds, int Nrt, float* fg_base, int k, int par)
+{
+    CMPC_PHASE_PROLOGUE;
+    stage_post_body<NT>(c, prm, tid, k, par ? c.P0 : c.P1);
+}
+
+// ---- Riccati backward sweep (matrices + right-hand side of the affine step, or of a centring step with target
+// cmu).  Returns (uniformly) 0 ok, 1 non-positive pivot. ----
+template <int NT, int NC, bool FG>
+__device__ int riccati_backward(lds_t lds, const Ctx& c, const CmpcConsts& prm, int tid, float* fg_base, bool use_exact, float reg, float cmu)
+{
+    const int N = c.N;
+    for (int e = tid; e < NXA * PLD; e += NT) c.P0[e] = 0.f;
+    if (tid == 0) *c.flag = 0;
+    __syncthreads();
+    if (tid < NS) {
+        c.P0[tid * PLD + tid] = qdiag(prm, N, tid);
+        c.pv[tid] = grad_track(c, prm, N, tid);
+    } else if (tid < NXA) c.pv[tid] = 0.0;
+    __syncthreads();
+    int par = 0;  // P0 holds the value function of stage k+1
+    for (int k = N - 1; k >= 0; --k) {
+        stage_pre<NT, NC, FG>(lds, N, fg_base, k, par, k < N - 1, use_exact, reg, cmu);
+        PROF_DECL;
+        if (tid < 128) phase_factor<NC, FG>(lds, N, fg_base, k);
+        else stage_qss<NT, NC, FG>(lds, N, fg_base, k, par);
         __syncthreads();
+        PROF(3);
+        if (*c.flag) return 1;
+        stage_post<NT, NC, FG>(lds, N, fg_base, k, par);
+        par ^= 1;
     }
     return 0;
 }
@@ -1195,40 +1265,25 @@ __device__ void costate_update(const Ctx& c, const CmpcConsts& prm, int tid, flo
     __syncthreads();
 }
 
-// ---- out-of-line entry points of the sweeps: each rebuilds the LDS map from the dynamic LDS base ----
-#define CMPC_PHASE_PROLOGUE                                                            \
-    extern __shared__ __attribute__((aligned(16))) char smem[];                        \
-    const int N = NC > 0 ? NC : Nrt;                                                   \
-    Ctx c;                                                                             \
-    make_ctx<FG>(c, smem, N, fg_base);                                                 \
-    const CmpcConsts& prm = *reinterpret_cast<const CmpcConsts*>(smem);                \
-    const int tid = threadIdx.x
-
+// ---- out-of-line entry points of the sweeps ----
 template <int NT, int NC, bool FG>
-__device__ __attribute__((noinline)) void phase_forward(int Nrt, float* fg_base, bool affine)
+__device__ __attribute__((noinline)) void phase_forward(lds_t lds, int Nrt, float* fg_base, bool affine)
 {
     CMPC_PHASE_PROLOGUE;
     riccati_forward<NT>(c, prm, tid, affine);
 }
 template <int NT, int NC, bool FG>
-__device__ __attribute__((noinline)) void phase_delta(int Nrt, float* fg_base)
+__device__ __attribute__((noinline)) void phase_delta(lds_t lds, int Nrt, float* fg_base)
 {
     CMPC_PHASE_PROLOGUE;
     riccati_delta(c, prm, tid);
 }
 template <int NT, int NC, bool FG>
-__device__ __attribute__((noinline)) void phase_costate(int Nrt, float* fg_base, float ap, bool use_exact)
+__device__ __attribute__((noinline)) void phase_costate(lds_t lds, int Nrt, float* fg_base, float ap, bool use_exact)
 {
     CMPC_PHASE_PROLOGUE;
     costate_update(c, prm, tid, ap, use_exact);
 }
-template <int NT, int NC, bool FG>
-__device__ __attribute__((noinline)) int phase_backward(int Nrt, float* fg_base, bool use_exact, float reg, float cmu)
-{
-    CMPC_PHASE_PROLOGUE;
-    return riccati_backward<NT, NC, FG>(c, prm, tid, use_exact, reg, cmu);
-}
-
 // NC > 0: horizon known at compile time (every LDS offset becomes an immediate); NC == 0: runtime N
 // FG: the per-stage factors (Linv, Ws: 915 floats per stage) live in global scratch instead of LDS
 // (horizons whose LDS image would exceed 160 KiB)
@@ -1249,6 +1304,11 @@ __global__ __launch_bounds__(NT, FG ? 2 : 1) void cmpc_solve_kernel(CmpcParams k
     const CmpcConsts& prm = prmw;
     const long long t_start = __builtin_amdgcn_s_memtime();
     Ctx c;
+    // (made opaque: interprocedural constant propagation would otherwise hand every phase the dynamic-LDS symbol
+    // back and with it a table lookup per call)
+    unsigned ldsv = (unsigned)(unsigned long long)(lds_t)smem;
+    asm volatile("" : "+s"(ldsv));
+    const lds_t lds = (lds_t)(unsigned long long)ldsv;
     float* const fg_base = FG ? kp.scratch + (size_t)b * kp.scratch_stride : nullptr;
     make_ctx<FG>(c, smem, N, fg_base);
     float* spw = const_cast<float*>(c.sp);
@@ -1362,7 +1422,7 @@ __global__ __launch_bounds__(NT, FG ? 2 : 1) void cmpc_solve_kernel(CmpcParams k
         float reg = prm.reg;
         int fail = 1;
         for (int attempt = 0; attempt < 4; ++attempt) {
-            fail = phase_backward<NT, NC, FG>(N, fg_base, exact, reg, centring ? prm.mu_min : 0.f);
+            fail = riccati_backward<NT, NC, FG>(lds, c, prm, tid, fg_base, exact, reg, centring ? prm.mu_min : 0.f);
             if (!fail) break;
             __syncthreads();
             ++gn; exact = false;
@@ -1374,10 +1434,10 @@ __global__ __launch_bounds__(NT, FG ? 2 : 1) void cmpc_solve_kernel(CmpcParams k
         if (centring) {
             for (int e = tid; e < NI * N; e += NT) c.dZ[e] = row_active(c, e / NI, e % NI) ? prm.mu_min : 0.f;
             __syncthreads();
-            phase_forward<NT, NC, FG>(N, fg_base, false);
+            phase_forward<NT, NC, FG>(lds, N, fg_base, false);
             PROF(15);
         } else {
-        phase_forward<NT, NC, FG>(N, fg_base, true);
+        phase_forward<NT, NC, FG>(lds, N, fg_base, true);
         PROF(12);
         if (finishing) {
             // last step: affine-scaling extrapolation of the central path to mu = 0 (primal only)
@@ -1405,14 +1465,14 @@ __global__ __launch_bounds__(NT, FG ? 2 : 1) void cmpc_solve_kernel(CmpcParams k
         }
         __syncthreads();
         PROF(13);
-        phase_delta<NT, NC, FG>(N, fg_base);
+        phase_delta<NT, NC, FG>(lds, N, fg_base);
         PROF(14);
-        phase_forward<NT, NC, FG>(N, fg_base, false);
+        phase_forward<NT, NC, FG>(lds, N, fg_base, false);
         PROF(15);
         }
         step_lengths<NT>(c, tid, fmaxf(0.99f, 1.f - mu_t), ap, ad);
         // ---- costates, then the iterate ----
-        phase_costate<NT, NC, FG>(N, fg_base, ap, exact);
+        phase_costate<NT, NC, FG>(lds, N, fg_base, ap, exact);
         PROF(16);
         for (int e = tid; e < NS * (N + 1); e += NT) c.S[e] += ap * c.dS[e];
         for (int e = tid; e < NU * N; e += NT) c.U[e] += ap * c.dU[e];
