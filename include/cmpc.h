@@ -88,6 +88,10 @@ int cmpc_solve_device(cmpc_handle h, const float* dP, const float* dX0, float* d
 int cmpc_solve(cmpc_handle h, const float* P, const float* X0, float* X, float* info);
 /* duration of the last solve kernel in ms (HIP events on the launch stream); < 0 if none */
 float cmpc_last_solve_ms(cmpc_handle h);
+/* test hook: fills the LDS of every compute unit with NaN bit patterns (a kernel on the handle's stream), so that a
+ * test can show that a solve does not depend on what an earlier workgroup or kernel left there.  No reference
+ * counterpart. */
+int cmpc_test_poison_lds(cmpc_handle h);
 
 /* ---- NLP callbacks (what IPOPT evaluated through the generated code), batched on the device ----
  * any output pointer may be NULL.  dLamG[B][n_g], lam_f scalar (hess of lam_f f + lam_g^T g).

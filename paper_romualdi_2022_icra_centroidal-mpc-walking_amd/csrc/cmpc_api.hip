@@ -163,6 +163,9 @@ int cmpc_create(const cmpc_config* cfg, int batch, int device, cmpc_handle* out)
         fill_consts(h, q);
         HIPCHK(h, hipMemcpy(h->dConsts, &q, sizeof(q), hipMemcpyHostToDevice));
     }
+    // the memset and the copy above ran on the null stream; solves run on a non-blocking stream that does not
+    // wait for it (a first solve racing the tail of a 350 MB memset was observed to fail): drain the device once
+    HIPCHK(h, hipDeviceSynchronize());
     *out = h;
     return CMPC_OK;
 }
@@ -243,6 +246,28 @@ int cmpc_solve_device(cmpc_handle h, const float* dP, const float* dX0, float* d
     if (rc != 0) return fail(h, CMPC_ERR_HIP, std::string("solver launch: ") + hipGetErrorString((hipError_t)rc));
     HIPCHK(h, hipEventRecord(h->ev1, st));
     h->timed = true;
+    return CMPC_OK;
+}
+
+namespace {
+__global__ __launch_bounds__(256) void poison_lds_kernel(int words, unsigned* sink)
+{
+    extern __shared__ unsigned pl[];
+    for (int e = threadIdx.x; e < words; e += 256) pl[e] = 0x7fc00000u | (unsigned)(e & 0xffff);
+    __syncthreads();
+    if (sink && threadIdx.x == 0 && pl[(blockIdx.x * 97) % words] == 1u) *sink = 1u;  // keep the stores alive
+}
+}  // namespace
+
+int cmpc_test_poison_lds(cmpc_handle h)
+{
+    if (!h) return CMPC_ERR_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    const int bytes = 160 * 1024;
+    HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(poison_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    // one workgroup per CU at a time (160 KiB each); several waves of them so that every CU is visited
+    hipLaunchKernelGGL(poison_lds_kernel, dim3(2048), dim3(256), bytes, h->stream, bytes / 4, reinterpret_cast<unsigned*>(h->dInfo));
+    HIPCHK(h, hipGetLastError());
     return CMPC_OK;
 }
 

@@ -103,4 +103,5 @@ struct CmpcParams {
     float mu_init, t_floor;      // starting barrier parameter and slack floor of this solve (cold: 0.1 / 1e-2)
     float* scratch;              // per-problem factor storage when it does not fit in LDS, else null
     long long scratch_stride;    // floats per problem
+    int lds_words;               // 4-byte words of dynamic LDS the launch was given (set by cmpc_launch_solver)
 };

@@ -1294,6 +1294,14 @@ __global__ __launch_bounds__(NT, FG ? 2 : 1) void cmpc_solve_kernel(CmpcParams k
     const int tid = threadIdx.x;
     const int b = blockIdx.x;
     const int N = NC > 0 ? NC : kp.N;
+    // The whole LDS image starts at zero.  LDS arrives with whatever the previous workgroup -- or the previous
+    // kernel -- left in it, and several formulas read entries under a zero weight (the E^T P rows of G before the
+    // first value function exists, zero blocks of the factor records): 0 x NaN is NaN.
+    {
+        int* z = reinterpret_cast<int*>(smem);
+        for (int e = tid; e < kp.lds_words; e += NT) z[e] = 0;
+    }
+    __syncthreads();
     // constants first in LDS
     CmpcConsts& prmw = *reinterpret_cast<CmpcConsts*>(smem);
     {
@@ -1320,11 +1328,7 @@ __global__ __launch_bounds__(NT, FG ? 2 : 1) void cmpc_solve_kernel(CmpcParams k
         while (i * (i + 1) / 2 > e) --i;
         c.tri[e] = (unsigned short)((i << 8) | (e - i * (i + 1) / 2));
     }
-    if (!FG)  // zero blocks of the factor records (HBM scratch is zeroed once, at cmpc_create)
-        for (int e = tid; e < REC_N * N; e += NT) c.Lf[e] = 0.f;
-    for (int e = tid; e < NPAN * RLD; e += NT) c.Pan[e] = 0.f;
-    for (int e = tid; e < NU * RLD; e += NT) c.QuuF[e] = 0.f;
-    if (tid < 90) c.QuuD[tid] = 0.0;
+    // (zero blocks of the factor records: LDS was zeroed above; HBM scratch is zeroed once, at cmpc_create)
     {
         const float* gp = kp.P + (size_t)b * c.L.np();
         for (int e = tid; e < c.L.np(); e += NT) spw[e] = gp[e];
@@ -1413,6 +1417,15 @@ __global__ __launch_bounds__(NT, FG ? 2 : 1) void cmpc_solve_kernel(CmpcParams k
         const float ec = block_max<NT>(l_ec, c.red, tid);
         mu_cur = (float)(block_sum<NT>(l_mu, c.redd, tid) / (double)nrow);
         PROF(10);
+        // The step that produced this iterate was already below the step tolerance and its residuals are converged:
+        // stop here, before paying for a factorisation whose step would only confirm it (the error of the iterate is
+        // the size of that unneeded step, an order of magnitude or more below the last one taken).
+        if (it > 0 && !finishing && fmaxf(ep, ec) <= prm.tol && step_out <= (prm.dev[3] > 0.f ? prm.dev[3] : 1.f) * prm.step_tol) {
+            err = fmaxf(ep, ec);
+            status = 0;
+            if (!prm.final_extrap) break;
+            finishing = true;
+        }
         // ---- predictor (affine scaling): factorise; on a non-positive pivot fall back to the
         // Gauss-Newton Hessian, then to a larger Levenberg shift ----
         // once the complementarity products sit at the barrier floor the predictor has nothing to predict
@@ -1592,6 +1605,8 @@ extern "C" int cmpc_launch_solver(const CmpcParams* prm, size_t lds_bytes, hipSt
 #endif
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(kern, dim3(prm->B), dim3(NT), lds_bytes, stream, *prm);
+    CmpcParams kp = *prm;
+    kp.lds_words = (int)(lds_bytes / 4);
+    hipLaunchKernelGGL(kern, dim3(prm->B), dim3(NT), lds_bytes, stream, kp);
     return (int)hipGetLastError();
 }

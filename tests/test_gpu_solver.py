@@ -181,3 +181,22 @@ def test_long_horizon_uses_global_factor_storage():
     for b in range(64):
         e = parity.errors(cfg.N, P32[b], X[b], Xr[b])
         assert e["com"] < TOL and e["force0"] < TOL and e["pos"] < TOL, (b, e)
+
+
+@pytest.mark.parametrize("factors", ["lds", "hbm"])
+def test_solve_does_not_depend_on_stale_lds(factors, monkeypatch):
+    """LDS arrives uninitialised: poison every CU's LDS with NaNs (test hook of the C ABI), then solve more
+    problems than there are CUs so that later workgroups also inherit an earlier workgroup's image.  Results must
+    be bit-identical to an unpoisoned solve and all converged.  (Regression: entries read under a zero weight.)"""
+    monkeypatch.setenv("CMPC_FACTORS", factors)
+    B = 768
+    cfg, P, X0 = cm.synthetic.config3_external_push(B, seed=11)
+    P32, X032 = P.astype(np.float32), X0.astype(np.float32)
+    s = cm.BatchSolver(cfg, B)
+    X1, info1, rc1 = s.solve_host(P32, X032)
+    assert rc1 == 0 and (info1[:, 5] == 0).all(), s.last_error
+    assert s._lib.cmpc_test_poison_lds(s._h) == 0
+    X2, info2, rc2 = s.solve_host(P32, X032)
+    assert rc2 == 0 and (info2[:, 5] == 0).all(), s.last_error
+    np.testing.assert_array_equal(X1, X2)
+    np.testing.assert_array_equal(info1[:, 0], info2[:, 0])

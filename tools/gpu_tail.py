@@ -13,6 +13,8 @@ for name, gen in (("cfg2", cm.synthetic.config2_perturbed_com), ("cfg3", cm.synt
     it = info[:, 0].astype(int)
     # the B = 256 bench is bound by the slowest problem of each batch of 256
     mx = it[: (B // 256) * 256].reshape(-1, 256).max(axis=1)
+    if rc != 0:
+        print("solve_host rc", rc, s.last_error)
     print(name, "env", {k: v for k, v in os.environ.items() if k.startswith("CMPC_") or k == "MU_INIT"}, "mean %.2f" % it.mean(), "hist", np.bincount(it),
           "bad", int((info[:, 5] != 0).sum()), "mean of per-256 max %.2f" % mx.mean(), flush=True)
     s.close()
