@@ -58,7 +58,8 @@ typedef struct {
     int max_iterations;       /* Newton iteration budget per solve (default 40)                   */
     double tolerance;         /* on the primal residuals and on max t*z (default 1e-6)                 */
     double step_tolerance;    /* on the last Newton step, max-norm over states and forces (default 1e-4) */
-    double mu_init;           /* initial barrier parameter (default 0.1)                          */
+    double mu_init;           /* initial barrier parameter; <= 0 (default): per problem, from its
+                               * initial infeasibility ep0: clamp(3.5 ep0^2, 0.03, 0.5)           */
     double mu_min;            /* final barrier parameter (default 1e-7)                           */
     int exact_hessian;        /* 1 (default): Lagrangian Hessian; 0: Gauss-Newton                 */
     int final_extrapolation;  /* 1: finish with one extra affine-scaling step towards mu = 0 (default 0) */

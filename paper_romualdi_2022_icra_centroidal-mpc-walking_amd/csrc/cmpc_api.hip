@@ -81,7 +81,7 @@ void cmpc_default_config(cmpc_config* c)
     c->max_iterations = 40;
     c->tolerance = 1e-6;
     c->step_tolerance = 1e-4;
-    c->mu_init = 0.1;
+    c->mu_init = 0.0;  // <= 0: chosen per problem from its initial infeasibility
     c->mu_min = 1e-7;
     c->exact_hessian = 1;
     c->final_extrapolation = 0;
@@ -118,7 +118,6 @@ int cmpc_create(const cmpc_config* cfg, int batch, int device, cmpc_handle* out)
     if (h->cfg.max_iterations <= 0) h->cfg.max_iterations = 40;
     if (!(h->cfg.tolerance > 0)) h->cfg.tolerance = 1e-6;
     if (!(h->cfg.step_tolerance > 0)) h->cfg.step_tolerance = 100.0 * h->cfg.tolerance;
-    if (!(h->cfg.mu_init > 0)) h->cfg.mu_init = 0.1;
     if (!(h->cfg.mu_min > 0)) h->cfg.mu_min = 1e-7;
     if (!(h->cfg.gravity > 0)) h->cfg.gravity = 9.80665;
     h->B = batch;
@@ -230,7 +229,12 @@ static void fill_params(cmpc_handle h, CmpcParams& p)
     std::memset(&p, 0, sizeof(p));
     p.kc = h->dConsts; p.N = h->cfg.horizon; p.B = h->B;
     p.scratch = h->dScratch; p.scratch_stride = h->scratch_stride;
-    p.mu_init = (float)h->cfg.mu_init; p.t_floor = 1e-2f;
+    // cold start: a fixed initial barrier parameter if the configuration names one, else per problem
+    // mu0 = clamp(3.5 ep0^2, 0.03, 0.5) from the initial primal infeasibility ep0 (measured on 4096-problem batches:
+    // config 2 wants ~0.03, config 3 ~0.3; the rule cuts the slowest problem of a 256-batch by ~0.7 iterations)
+    p.mu_init = h->cfg.mu_init > 0 ? (float)h->cfg.mu_init : 0.1f;
+    p.mu_adapt = h->cfg.mu_init > 0 ? 0.f : 3.5f;
+    p.t_floor = 1e-2f;
 }
 
 int cmpc_solve_device(cmpc_handle h, const float* dP, const float* dX0, float* dX, float* dInfo, void* stream)
@@ -444,8 +448,8 @@ int cmpc_advance(cmpc_handle h)
         CmpcParams p;
         fill_params(h, p);
         p.P = h->dP; p.X0 = h->dX0; p.X = h->dX; p.info = h->dInfo;
-        if (h->warm) { p.mu_init = (float)h->mu_warm; p.t_floor = (float)h->floor_warm; }
-        if (const char* e = std::getenv("CMPC_MU_WARM")) { if (h->warm) { p.mu_init = (float)std::atof(e); p.t_floor = std::min(1e-2f, p.mu_init); } }
+        if (h->warm) { p.mu_init = (float)h->mu_warm; p.mu_adapt = 0.f; p.t_floor = (float)h->floor_warm; }
+        if (const char* e = std::getenv("CMPC_MU_WARM")) { if (h->warm) { p.mu_init = (float)std::atof(e); p.mu_adapt = 0.f; p.t_floor = std::min(1e-2f, p.mu_init); } }
         HIPCHK(h, hipEventRecord(h->ev0, h->stream));
         int lrc = cmpc_launch_solver(&p, h->lds, h->stream);
         if (lrc != 0) return fail(h, CMPC_ERR_HIP, std::string("solver launch: ") + hipGetErrorString((hipError_t)lrc));

@@ -1416,6 +1416,14 @@ __global__ __launch_bounds__(NT, FG ? 2 : 1) void cmpc_solve_kernel(CmpcParams k
         ep = block_max<NT>(l_ep, c.red, tid);
         const float ec = block_max<NT>(l_ec, c.red, tid);
         mu_cur = (float)(block_sum<NT>(l_mu, c.redd, tid) / (double)nrow);
+        if (it == 0 && kp.mu_adapt > 0.f) {
+            // cold start: the initial barrier parameter scales with the squared initial infeasibility (z = mu / t)
+            const float mu0 = fminf(fmaxf(kp.mu_adapt * ep * ep, 0.03f), 0.5f);
+            const float sc = mu0 / mu_cur;
+            for (int e = tid; e < NI * N; e += NT) c.Z[e] *= sc;
+            mu_cur = mu0;
+            __syncthreads();
+        }
         PROF(10);
         // The step that produced this iterate was already below the step tolerance and its residuals are converged:
         // stop here, before paying for a factorisation whose step would only confirm it (the error of the iterate is
@@ -1469,10 +1477,9 @@ __global__ __launch_bounds__(NT, FG ? 2 : 1) void cmpc_solve_kernel(CmpcParams k
         sigma = mu_aff / mu_cur;
         sigma = sigma * sigma * sigma;
         mu_t = fmaxf(fmaxf(sigma, prm.sigma_min) * mu_cur, prm.mu_min);
-        const float so = prm.dev[0] > 0.5f ? ap * ad : 1.f;
         // ---- corrector ----
         for (int e = tid; e < NI * N; e += NT) {
-            const float cmu = row_active(c, e / NI, e % NI) ? mu_t - so * c.dT[e] * c.dZ[e] : 0.f;  // complementarity target
+            const float cmu = row_active(c, e / NI, e % NI) ? mu_t - c.dT[e] * c.dZ[e] : 0.f;  // complementarity target
             c.dZ[e] = cmu;
             c.dT[e] = cmu / c.T[e];   // row coefficient change, read by the corrector sweep (dT is rebuilt by the forward sweep)
         }
@@ -1492,7 +1499,6 @@ __global__ __launch_bounds__(NT, FG ? 2 : 1) void cmpc_solve_kernel(CmpcParams k
         for (int e = tid; e < NI * N; e += NT) {
             const float tn = c.T[e] + ap * c.dT[e];
             float zn = c.Z[e] + ad * c.dZ[e];
-            if (prm.dev[2] > 0.f && row_active(c, e / NI, e % NI)) zn = fminf(fmaxf(zn, mu_t / (prm.dev[2] * tn)), prm.dev[2] * mu_t / tn);
             c.T[e] = tn; c.Z[e] = zn;
         }
         // ---- convergence: the Newton step itself is the error estimate.  Flat directions of the cost

@@ -7,11 +7,12 @@ import torch  # noqa
 import cmpc_amd as cm
 cm._capi.LIB_PATH = os.path.join(os.path.dirname(cm._capi.LIB_PATH), "libcmpc_hip_prof.so")
 gen = cm.synthetic.config2_perturbed_com if len(sys.argv) < 2 or sys.argv[1] == "config2" else cm.synthetic.config3_external_push
-cfg, P, X0 = gen(256)
-s = cm.BatchSolver(cfg, 256)
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 256
+cfg, P, X0 = gen(B, seed=7)
+s = cm.BatchSolver(cfg, B)
 X, info, rc = s.solve_host(P, X0)
 print("histogram of iterations:", np.bincount(info[:, 0].astype(int)))
-for b in np.argsort(-info[:, 0])[:2]:
+for b in list(np.argsort(-info[:, 0])[:3]) + [int(np.argsort(info[:, 0])[B // 2])]:
     s1 = cm.BatchSolver(cfg, 1)
     X1, info1, rc = s1.solve_host(P[b:b + 1], X0[b:b + 1])
     tr = (C.c_float * 512)()
