@@ -1390,7 +1390,7 @@ __global__ __launch_bounds__(NT, FG ? 2 : 1) void cmpc_solve_kernel(CmpcParams k
     nrow += 32 * N;
 
     int it = 0, status = 1, gn = 0;
-    float err = 0.f, ep = 0.f, mu_cur = 0.f, step_out = 0.f;
+    float err = 0.f, ep = 0.f, mu_cur = 0.f, step_out = 0.f, step_prev = 0.f;
     bool finishing = false;
     for (it = 0; it < prm.max_iter + 1; ++it) {
         if (it == prm.max_iter && !finishing) break;
@@ -1428,7 +1428,15 @@ __global__ __launch_bounds__(NT, FG ? 2 : 1) void cmpc_solve_kernel(CmpcParams k
         // The step that produced this iterate was already below the step tolerance and its residuals are converged:
         // stop here, before paying for a factorisation whose step would only confirm it (the error of the iterate is
         // the size of that unneeded step, an order of magnitude or more below the last one taken).
-        if (it > 0 && !finishing && fmaxf(ep, ec) <= prm.tol && step_out <= (prm.dev[3] > 0.f ? prm.dev[3] : 1.f) * prm.step_tol) {
+        // Its error is what the steps still to come would add: at most the last step, and -- once two steps are known --
+        // their geometric tail s rho / (1 - rho) with the observed contraction rho = s_k / s_{k-1}, taken no smaller
+        // than 0.25 (the convergence is superlinear only at the very end) and no larger than 0.9.
+        float est = step_out;
+        if (it > 1 && step_prev > 0.f) {
+            const float rho = fminf(fmaxf(step_out / step_prev, 0.25f), 0.9f);
+            est = fminf(est, step_out * rho / (1.f - rho));
+        }
+        if (it > 0 && !finishing && fmaxf(ep, ec) <= prm.tol && est <= prm.step_tol) {
             err = fmaxf(ep, ec);
             status = 0;
             if (!prm.final_extrap) break;
@@ -1522,6 +1530,7 @@ __global__ __launch_bounds__(NT, FG ? 2 : 1) void cmpc_solve_kernel(CmpcParams k
             } else l_st = fmaxf(l_st, fabsf(du));
         }
         const float step = ap * block_max<NT>(l_st, c.red, tid);
+        step_prev = step_out;
         step_out = step;
         err = fmaxf(ep, ec);
 #ifdef CMPC_PROFILE
