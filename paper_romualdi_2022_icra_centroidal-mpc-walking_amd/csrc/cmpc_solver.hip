@@ -48,6 +48,10 @@
 //                   reads are pointed at.
 //   [REC_WT, +512)  16 rows x 32: row j < 15 = Ws[:, j], row 15 = lq = L^{-1} qu; the float4 index inside a row
 //                   is XOR-swizzled with j & 7 (row reads of 16 consecutive j stay 2-way conflict-free)
+// Column descriptors and barrier coefficients of a stage exist twice: stage k uses set k & 1, so that the set of
+// stage k-1 can be written while stage k is being factorised
+#define DSET_F (3 * NU + 3 * NS + 3 + 108)   // floats: Bval | Aval | arow
+#define DSET_I (3 * NU + 3 * NS + 3)         // ints:   Brow | Arow
 #define REC_UB 0
 #define REC_WT 576
 #define REC_ZERO 572
@@ -83,7 +87,7 @@ struct Ctx {
     float *dS, *dU, *dT, *dZ, *d;
     float *Lf;             // per-stage factor records (REC_N floats each)
     float *geoA;           // N x GEO
-    float *P0, *P1, *G, *T1, *QuuF, *Pan, *Bval, *Aval, *arow, *ybuf, *fpv, *fpn;
+    float *P0, *P1, *G, *QuuF, *Pan, *Bval, *Aval, *arow, *ybuf, *fpv, *fpn;
     int *Brow, *Arow, *qmask;
     unsigned short* tri;
     double *QuuD, *pv, *pn, *qs, *Pd, *sig, *gco, *redd;
@@ -108,7 +112,8 @@ __device__ inline void make_ctx(Ctx& c, char* smem, int N, float* fg_base)
     c.LAM = dp; dp += NS * (N + 1) + ((NS * (N + 1)) & 1);
     c.QuuD = dp; dp += 90;
     c.pv = dp; dp += 40; c.pn = dp; dp += 40; c.qs = dp; dp += 16; c.Pd = dp; dp += 40;
-    c.sig = dp; dp += NI; c.gco = dp; dp += NI; c.redd = dp; dp += 8;
+    c.sig = dp; dp += NI; c.gco = dp; dp += NI; dp += 2 * NI;  // (second descriptor set)
+    c.redd = dp; dp += 8;
     float* fp = reinterpret_cast<float*>(dp);
     c.QuuF = fp; fp += NU * RLD;
     c.Pan = fp; fp += NPAN * RLD;
@@ -120,14 +125,22 @@ __device__ inline void make_ctx(Ctx& c, char* smem, int N, float* fg_base)
     c.d = fp; fp += NS * N;
     c.geoA = fp; fp += GEO * N;
     c.P0 = fp; fp += NXA * PLD; c.P1 = fp; fp += NXA * PLD;
-    c.G = fp; fp += NXA * GLD; c.T1 = fp; fp += NS * NS;
+    c.G = fp; fp += NXA * GLD;
     c.Bval = fp; fp += 3 * NU; c.Aval = fp; fp += 3 * NS + 3;
-    c.arow = fp; fp += 96 + 12; c.fpv = fp; fp += 40; c.fpn = fp; fp += 40; c.red = fp; fp += 8;
+    c.arow = fp; fp += 96 + 12; fp += DSET_F;  // (second descriptor set)
+    c.fpv = fp; fp += 40; c.fpn = fp; fp += 40; c.red = fp; fp += 8;
     c.Brow = reinterpret_cast<int*>(fp); fp += 3 * NU;
-    c.Arow = reinterpret_cast<int*>(fp); fp += 3 * NS + 3;
+    c.Arow = reinterpret_cast<int*>(fp); fp += 3 * NS + 3; fp += DSET_I;  // (second descriptor set)
     c.flag = reinterpret_cast<int*>(fp); fp += 4;
     c.qmask = reinterpret_cast<int*>(fp); fp += CMPC_NMAX;
     c.tri = reinterpret_cast<unsigned short*>(fp); fp += NTRI / 2;
+}
+
+__device__ inline void use_desc_set(Ctx& c, int s)
+{
+    c.Bval += s * DSET_F; c.Aval += s * DSET_F; c.arow += s * DSET_F;
+    c.Brow += s * DSET_I; c.Arow += s * DSET_I;
+    c.sig += s * 2 * NI; c.gco += s * 2 * NI;
 }
 
 // U[m][a] (a >= 4 (m / 4)) lives at ub_row(m) + a - 4 (m / 4)
@@ -562,41 +575,39 @@ __device__ inline void stage_factor(const float* QuuF, const double* QuuD, float
 
 // ---- Riccati backward sweep (matrices + right-hand side of the affine step).
 // Returns (uniformly) 0 ok, 1 non-positive pivot. ----
-// ---- one stage of the backward sweep, in three out-of-line pieces (each with a register allocation of its
-// own; inlined into one loop the stage needs > 512 VGPRs and spills to scratch):
-//   stage_pre   phases 0-2: descriptors, G = P [B;E], Quu / Qus / qu
-//   stage_qss   Qss, qs on waves 2-3 while waves 0-1 factorise (phase_factor)
+// ---- one stage of the backward sweep, in out-of-line pieces (each with a register allocation of its own; inlined
+// into one loop the stage needs > 512 VGPRs and spills to scratch):
+//   stage_pre   phases 1-2: G = P [B;E], then Quu / Qus / Pd / qu
+//   stage_qss   Qss, qs of this stage and the descriptors of the next on waves 2-3 while waves 0-1 factorise (phase_factor)
 //   stage_post  phase 4: P <- [Qss 0; 0 D] - W^T W, value gradient ----
-template <int NT, int NC, bool FG>
-__device__ inline void stage_pre_body(const Ctx& c, const CmpcConsts& prm, int tid, int k, const float* Pcur, bool havep,
-                                      bool use_exact, float reg, float cmu)
+// ---- column descriptors of A_k and B_k (closed forms; <= 3 non-zeros per column), barrier coefficients z/t and the
+// friction rows, the exact-Hessian block: 128 threads (t = 0..127), into the descriptor set selected in c ----
+__device__ inline void stage_desc_body(const Ctx& c, const CmpcConsts& prm, int t, int k, bool use_exact, float cmu)
 {
-    const bool pk = k > 0;
     const float* u = c.U + NU * k;
     const float* geo = c.geoA + GEO * k;
-        PROF_DECL;
         // ---- phase 0: column descriptors of A and B, barrier coefficients ----
-        if (tid < NU) {
+        if (t < NU) {
             int r0, r1, r2;
             float v0, v1, v2;
-            if (tid < NF) {
-                const int ct = tid / 12, a = tid % 3, a1 = (a + 1) % 3, a2 = (a + 2) % 3;
+            if (t < NF) {
+                const int ct = t / 12, a = t % 3, a1 = (a + 1) % 3, a2 = (a + 2) % 3;
                 const float g = prm.dt * gam_of(c, ct, k);
-                const float* r = geo + 3 * (tid / 3);
+                const float* r = geo + 3 * (t / 3);
                 r0 = 3 + a; v0 = g;
                 r1 = 6 + a1; v1 = g * r[a2];
                 r2 = 6 + a2; v2 = -g * r[a1];
             } else {
-                const int q = tid - 24, ct = q / 3, m = q % 3;
+                const int q = t - 24, ct = q / 3, m = q % 3;
                 const float* R = c.sp + c.L.pR(ct) + 9 * k;
                 const float g1 = qfree(c, k, q) ? 1.f - gam_of(c, ct, k) : 0.f;
                 r0 = 9 + 3 * ct; r1 = r0 + 1; r2 = r0 + 2;
                 v0 = g1 * Rm(R, 0, m); v1 = g1 * Rm(R, 1, m); v2 = g1 * Rm(R, 2, m);
             }
-            c.Brow[3 * tid] = r0; c.Brow[3 * tid + 1] = r1; c.Brow[3 * tid + 2] = r2;
-            c.Bval[3 * tid] = v0; c.Bval[3 * tid + 1] = v1; c.Bval[3 * tid + 2] = v2;
-        } else if (tid >= 32 && tid < 32 + NS) {
-            const int j = tid - 32;
+            c.Brow[3 * t] = r0; c.Brow[3 * t + 1] = r1; c.Brow[3 * t + 2] = r2;
+            c.Bval[3 * t] = v0; c.Bval[3 * t + 1] = v1; c.Bval[3 * t + 2] = v2;
+        } else if (t >= 32 && t < 32 + NS) {
+            const int j = t - 32;
             int r0 = j, r1 = j, r2 = j;
             float v0 = 1.f, v1 = 0.f, v2 = 0.f;
             if (j < 3) {
@@ -615,8 +626,8 @@ __device__ inline void stage_pre_body(const Ctx& c, const CmpcConsts& prm, int t
             }
             c.Arow[3 * j] = r0; c.Arow[3 * j + 1] = r1; c.Arow[3 * j + 2] = r2;
             c.Aval[3 * j] = v0; c.Aval[3 * j + 1] = v1; c.Aval[3 * j + 2] = v2;
-        } else if (tid >= 64 && tid < 64 + NI) {
-            const int i = tid - 64;
+        } else if (t >= 48 && t < 48 + NI) {
+            const int i = t - 48;
             double sg = 0.0, gc = 0.0;
             if (row_active(c, k, i)) {
                 const double t = c.T[NI * k + i], z = c.Z[NI * k + i];
@@ -630,27 +641,25 @@ __device__ inline void stage_pre_body(const Ctx& c, const CmpcConsts& prm, int t
                 fric_row(c, prm, k, i, a0, a1, a2);
                 c.arow[3 * i] = a0; c.arow[3 * i + 1] = a1; c.arow[3 * i + 2] = a2;
             }
-        } else if (tid >= 112 && tid < 121) {
+        } else if (t >= 96 && t < 105) {
             // exact-Hessian block dt [lam_h]x (zero for the Gauss-Newton Hessian), row-major 3x3
-            const int a = (tid - 112) / 3, b = (tid - 112) % 3;
+            const int a = (t - 96) / 3, b = (t - 96) % 3;
             float sv = 0.f;
             if (use_exact && a != b) {
                 const float lv = (float)c.LAM[NS * (k + 1) + 6 + (3 - a - b)];
                 sv = prm.dt * (((b - a + 3) % 3 == 1) ? -lv : lv);
             }
-            c.arow[96 + tid - 112] = sv;
-        } else if (tid >= 128 && tid < 128 + NXA) {
-            // Pd = P [d; 0] + pv  (float64)
-            const int r = tid - 128;
-            double acc = c.pv[r];
-            if (r < NS || havep) {
-#pragma unroll
-                for (int a = 0; a < NS; ++a) acc += (double)Pcur[r * PLD + a] * (double)c.d[NS * k + a];
-            }
-            c.Pd[r] = acc;
+            c.arow[96 + t - 96] = sv;
         }
-        __syncthreads();
-        PROF(0);
+}
+
+template <int NT, int NC, bool FG>
+__device__ inline void stage_pre_body(const Ctx& c, const CmpcConsts& prm, int tid, int k, const float* Pcur, bool havep,
+                                      bool use_exact, float reg, float cmu)
+{
+    const bool pk = k > 0;
+    const float* u = c.U + NU * k;
+    PROF_DECL;
         // ---- phase 1: G = P [B;E] (39 x 30): thread <-> column, its three non-zeros in registers, rows strided over 8 ----
         {
             const int nrow = havep ? NXA : NS;
@@ -769,7 +778,19 @@ __device__ inline void stage_pre_body(const Ctx& c, const CmpcConsts& prm, int t
             c.QuuD[9 * b + 3 * rr + cc] = v;
             c.QuuF[i * RLD + j] = 0.f;  // the float copy of a diagonal block collects the updates by earlier blocks
             PROF4(7);
-        } else if (tid >= 192 && tid < 192 + NU) {
+        } else if (tid >= 192) {
+          // wave 3: Pd = P [d; 0] + pv (float64), then qu, which reads it (same wave: LDS order suffices)
+          if (tid < 192 + NXA) {
+            const int r = tid - 192;
+            double acc = c.pv[r];
+            if (r < NS || havep) {
+#pragma unroll
+                for (int a = 0; a < NS; ++a) acc += (double)Pcur[r * PLD + a] * (double)c.d[NS * k + a];
+            }
+            c.Pd[r] = acc;
+          }
+          wave_lds_sync();
+          if (tid < 192 + NU) {
             // qu (float64 -> float: it vanishes at convergence, so float keeps its relative accuracy)
             const int iq = tid - 192;
             double g;
@@ -787,6 +808,7 @@ __device__ inline void stage_pre_body(const Ctx& c, const CmpcConsts& prm, int t
             g += Bt_vec<double>(c, prm, k, iq, c.Pd);
             c.Pan[(NPAN - 1) * RLD + iq] = (float)g;
             PROF3(8);
+          }
         }
         __syncthreads();
         PROF(2);
@@ -907,13 +929,27 @@ template <int NT, int NC, bool FG>
 __device__ __attribute__((noinline)) void stage_pre(lds_t lds, int Nrt, float* fg_base, int k, int par, bool havep, bool use_exact, float reg, float cmu)
 {
     CMPC_PHASE_PROLOGUE;
+    use_desc_set(c, k & 1);
     stage_pre_body<NT, NC, FG>(c, prm, tid, k, par ? c.P1 : c.P0, havep, use_exact, reg, cmu);
 }
+// waves 2-3 (t = tid - 128) while waves 0-1 factorise stage k: Qss and qs of stage k, then the descriptors of stage k-1
 template <int NT, int NC, bool FG>
-__device__ __attribute__((noinline)) void stage_qss(lds_t lds, int Nrt, float* fg_base, int k, int par)
+__device__ __attribute__((noinline)) void stage_qss(lds_t lds, int Nrt, float* fg_base, int k, int par, bool use_exact, float cmu)
 {
     CMPC_PHASE_PROLOGUE;
+    use_desc_set(c, k & 1);
     stage_qss_body<NT>(c, prm, tid, k, par ? c.P1 : c.P0, par ? c.P0 : c.P1);
+    if (k > 0) {
+        use_desc_set(c, ((k - 1) & 1) - (k & 1));
+        stage_desc_body(c, prm, tid - 128, k - 1, use_exact, cmu);
+    }
+}
+template <int NT, int NC, bool FG>
+__device__ __attribute__((noinline)) void stage_desc(lds_t lds, int Nrt, float* fg_base, int k, bool use_exact, float cmu)
+{
+    CMPC_PHASE_PROLOGUE;
+    use_desc_set(c, k & 1);
+    stage_desc_body(c, prm, tid - 128, k, use_exact, cmu);
 }
 template <int NT, int NC, bool FG>
 __device__ __attribute__((noinline)) void stage_post(lds_t lds, int Nrt, float* fg_base, int k, int par)
@@ -935,13 +971,14 @@ __device__ int riccati_backward(lds_t lds, const Ctx& c, const CmpcConsts& prm, 
         c.P0[tid * PLD + tid] = qdiag(prm, N, tid);
         c.pv[tid] = grad_track(c, prm, N, tid);
     } else if (tid < NXA) c.pv[tid] = 0.0;
+    if (tid >= 128) stage_desc<NT, NC, FG>(lds, N, fg_base, N - 1, use_exact, cmu);
     __syncthreads();
     int par = 0;  // P0 holds the value function of stage k+1
     for (int k = N - 1; k >= 0; --k) {
         stage_pre<NT, NC, FG>(lds, N, fg_base, k, par, k < N - 1, use_exact, reg, cmu);
         PROF_DECL;
         if (tid < 128) phase_factor<NC, FG>(lds, N, fg_base, k);
-        else stage_qss<NT, NC, FG>(lds, N, fg_base, k, par);
+        else stage_qss<NT, NC, FG>(lds, N, fg_base, k, par, use_exact, cmu);
         __syncthreads();
         PROF(3);
         if (*c.flag) return 1;
@@ -1430,10 +1467,10 @@ __global__ __launch_bounds__(NT, FG ? 2 : 1) void cmpc_solve_kernel(CmpcParams k
         // the size of that unneeded step, an order of magnitude or more below the last one taken).
         // Its error is what the steps still to come would add: at most the last step, and -- once two steps are known --
         // their geometric tail s rho / (1 - rho) with the observed contraction rho = s_k / s_{k-1}, taken no smaller
-        // than 0.25 (the convergence is superlinear only at the very end) and no larger than 0.9.
+        // than 0.2 (the convergence is superlinear only at the very end; floors of 0.1 ... 0.3 give the same worst parity error) and no larger than 0.9.
         float est = step_out;
         if (it > 1 && step_prev > 0.f) {
-            const float rho = fminf(fmaxf(step_out / step_prev, 0.25f), 0.9f);
+            const float rho = fminf(fmaxf(step_out / step_prev, 0.2f), 0.9f);
             est = fminf(est, step_out * rho / (1.f - rho));
         }
         if (it > 0 && !finishing && fmaxf(ep, ec) <= prm.tol && est <= prm.step_tol) {
@@ -1579,11 +1616,11 @@ extern "C" size_t cmpc_solver_lds_bytes(int N, int factors_global)
     CmpcLayout L;
     cmpc_layout_init(L, N);
     const size_t nlam = (size_t)NS * (N + 1) + (((size_t)NS * (N + 1)) & 1);
-    const size_t dbl = nlam + 90 + 40 + 40 + 16 + 40 + NI + NI + 8;
+    const size_t dbl = nlam + 90 + 40 + 40 + 16 + 40 + 4 * NI + 8;
     const size_t flt = (size_t)NU * RLD + (size_t)NPAN * RLD + 96 + ((L.np + 3) & ~3)
                        + 2 * ((size_t)NS * (N + 1) + (size_t)NU * N + 2 * (size_t)NI * N) + (size_t)NS * N
-                       + (size_t)GEO * N + 2 * NXA * PLD + NXA * GLD + NS * NS + 3 * NU + 3 * NS + 3 + 96 + 12 + 40 + 40 + 8
-                       + 3 * NU + 3 * NS + 3 + 4 + CMPC_NMAX + NTRI / 2 + (factors_global ? 0 : (size_t)REC_N * N);
+                       + (size_t)GEO * N + 2 * NXA * PLD + NXA * GLD + 2 * DSET_F + 40 + 40 + 8
+                       + 2 * DSET_I + 4 + CMPC_NMAX + NTRI / 2 + (factors_global ? 0 : (size_t)REC_N * N);
     return ((sizeof(CmpcConsts) + 15) & ~(size_t)15) + dbl * 8 + flt * 4;
 }
 

@@ -7,7 +7,7 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: F401  (same HIP runtime)
 import cmpc_amd as cm
 cm._capi.LIB_PATH = os.path.join(os.path.dirname(cm._capi.LIB_PATH), "libcmpc_hip_prof.so")
-names = ["ph0 desc+rows+Pd", "ph1 G,T1", "ph2 Quu,panel,Qss", "ph3 fused chol+solve", "ph4 P update", "ph2/w0: values", "ph2/w0: stores", "ph2/w2: diag blocks", "ph2/w3: qu", "-",
+names = ["(ph0: under ph3 now)", "ph1 G", "ph2 Quu,panel,Pd,qu", "ph3 fused chol+solve", "ph4 P update", "ph2/w0: values", "ph2/w0: stores", "ph2/w2: diag blocks", "ph2/w3: qu", "-",
          "residuals", "backward(total)", "fwd1", "steps+muaff", "delta", "fwd2", "steplen+costate", "update+conv"]
 cfg, P, X0 = cm.synthetic.config2_perturbed_com(256)
 s = cm.BatchSolver(cfg, 256)

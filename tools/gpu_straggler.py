@@ -8,7 +8,7 @@ import cmpc_amd as cm
 cm._capi.LIB_PATH = os.path.join(os.path.dirname(cm._capi.LIB_PATH), "libcmpc_hip_prof.so")
 gen = cm.synthetic.config2_perturbed_com if len(sys.argv) < 2 or sys.argv[1] == "config2" else cm.synthetic.config3_external_push
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 256
-cfg, P, X0 = gen(B, seed=7)
+cfg, P, X0 = gen(B, seed=int(os.environ.get('SEED', '7')))
 s = cm.BatchSolver(cfg, B)
 X, info, rc = s.solve_host(P, X0)
 print("histogram of iterations:", np.bincount(info[:, 0].astype(int)))
