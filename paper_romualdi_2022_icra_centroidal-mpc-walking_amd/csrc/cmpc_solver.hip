@@ -653,6 +653,74 @@ __device__ inline void stage_desc_body(const Ctx& c, const CmpcConsts& prm, int 
         }
 }
 
+// ---- phase 2, float32 part: 285 triples of consecutive entries -- 135 of Quu (row i, block column bj < bi), 150 of
+// Qus^T (row j, the xyz of one corner / one foot's offset) -- by one branch-free formula
+//   out_c = sum_a w_a G[row_a][col0 + c] + ew E[c es]          (descriptor (row_a, w_a): column i of B or j of A)
+// R rounds per thread (ids id0, id0 + 128, ...): addresses, then descriptor loads, then G loads, then arithmetic, then
+// stores, so that the rounds overlap ----
+template <int R>
+__device__ inline void quu_qus_triples(const Ctx& c, const CmpcConsts& prm, int k, bool havep, int id0)
+{
+    const float* Gp = c.G;
+    int dsc[R], col0[R], sto[R], eo[R], es[R], symc[R];
+    float ew[R], symw[R];
+    bool ok[R];
+#pragma unroll
+    for (int rd = 0; rd < R; ++rd) {
+        int id = id0 + 128 * rd;
+        ok[rd] = id < 285;
+        id = ok[rd] ? id : 0;
+        const bool kind = id < 135;  // true: Quu
+        const int idq = kind ? id : 0, idp = kind ? 0 : id - 135;
+        const unsigned short ij = c.tri[idq / 3];
+        const int i = 3 * ((ij >> 8) + 1) + idq % 3, j0 = 3 * (ij & 255);
+        const int jr = idp / 10, i0 = 3 * (idp % 10);
+        dsc[rd] = kind ? 3 * i : 3 * NU + 3 * jr;
+        col0[rd] = kind ? j0 : i0;
+        sto[rd] = kind ? (int)(c.QuuF - c.Pan) + i * RLD + j0 : jr * RLD + i0;
+        // extra term: Quu rows of a force get the E^T P block; Qus^T entries of a force get -/+ gam Sx
+        const int ct = i0 / 12;
+        const int bb = jr < 3 ? jr : jr - 9 - 3 * ct;
+        const bool bin = bb >= 0 && bb < 3;
+        const float sgn = jr < 3 ? -1.f : (bin ? 1.f : 0.f);
+        eo[rd] = kind ? (NS + (i < NF ? i : 0)) * GLD + j0 : (int)(c.arow - c.G) + 96 + (bin ? bb : 0);
+        es[rd] = kind ? 1 : 3;
+        ew[rd] = kind ? ((havep && i < NF) ? 1.f : 0.f) : (i0 < NF ? sgn * gam_of(c, ct, k) : 0.f);
+        // another corner of the same foot, same axis: symmetry-cost coupling (Quu only)
+        const bool sy = kind && i < NF && (i / 12) == (j0 / 12);
+        const float gq = gam_of(c, i < 12 ? 0 : 1, k);
+        symc[rd] = i % 3;
+        symw[rd] = sy ? 2.f * prm.w_sym * 0.25f * gq * (2.f - gq) : 0.f;
+    }
+    int r0[R], r1[R], r2[R];
+    float w0[R], w1[R], w2[R];
+#pragma unroll
+    for (int rd = 0; rd < R; ++rd) {
+        r0[rd] = c.Brow[dsc[rd]]; r1[rd] = c.Brow[dsc[rd] + 1]; r2[rd] = c.Brow[dsc[rd] + 2];
+        w0[rd] = c.Bval[dsc[rd]]; w1[rd] = c.Bval[dsc[rd] + 1]; w2[rd] = c.Bval[dsc[rd] + 2];
+    }
+    float o[R][3];
+#pragma unroll
+    for (int rd = 0; rd < R; ++rd) {
+        const float* g0 = Gp + r0[rd] * GLD + col0[rd];
+        const float* g1 = Gp + r1[rd] * GLD + col0[rd];
+        const float* g2 = Gp + r2[rd] * GLD + col0[rd];
+        const float* E = Gp + eo[rd];
+#pragma unroll
+        for (int cc = 0; cc < 3; ++cc) {
+            float v = w0[rd] * g0[cc] + w1[rd] * g1[cc] + w2[rd] * g2[cc] + ew[rd] * E[cc * es[rd]];
+            if (cc == symc[rd]) v -= symw[rd];
+            o[rd][cc] = v;
+        }
+    }
+#pragma unroll
+    for (int rd = 0; rd < R; ++rd)
+        if (ok[rd]) {
+            float* dst = c.Pan + sto[rd];   // QuuF sits NU * RLD floats below Pan
+            dst[0] = o[rd][0]; dst[1] = o[rd][1]; dst[2] = o[rd][2];
+        }
+}
+
 template <int NT, int NC, bool FG>
 __device__ inline void stage_pre_body(const Ctx& c, const CmpcConsts& prm, int tid, int k, const float* Pcur, bool havep,
                                       bool use_exact, float reg, float cmu)
@@ -687,73 +755,13 @@ __device__ inline void stage_pre_body(const Ctx& c, const CmpcConsts& prm, int t
         // (cost, barrier and Levenberg terms).  Wave 3: qu in float64. ----
         PROF2_DECL;
         if (tid < 128) {
-            // 285 triples of consecutive entries -- 135 of Quu (row i, block column bj < bi), 150 of Qus^T (row j, the xyz
-            // of one corner / one foot's offset) -- in three rounds of one branch-free formula:
-            //   out_c = sum_a w_a G[row_a][col0 + c] + ew E[c es]          (descriptor (row_a, w_a): column i of B or j of A)
-            // Addresses, then descriptor loads, then G loads, then arithmetic, then stores: the rounds overlap.
-            const float* Gp = c.G;
-            int dsc[3], col0[3], sto[3], eo[3], es[3], symc[3];
-            float ew[3], symw[3];
-            bool ok[3];
-#pragma unroll
-            for (int rd = 0; rd < 3; ++rd) {
-                int id = tid + 128 * rd;
-                ok[rd] = id < 285;
-                id = ok[rd] ? id : 0;
-                const bool kind = id < 135;  // true: Quu
-                const int idq = kind ? id : 0, idp = kind ? 0 : id - 135;
-                const unsigned short ij = c.tri[idq / 3];
-                const int i = 3 * ((ij >> 8) + 1) + idq % 3, j0 = 3 * (ij & 255);
-                const int jr = idp / 10, i0 = 3 * (idp % 10);
-                dsc[rd] = kind ? 3 * i : 3 * NU + 3 * jr;
-                col0[rd] = kind ? j0 : i0;
-                sto[rd] = kind ? (int)(c.QuuF - c.Pan) + i * RLD + j0 : jr * RLD + i0;
-                // extra term: Quu rows of a force get the E^T P block; Qus^T entries of a force get -/+ gam Sx
-                const int ct = i0 / 12;
-                const int bb = jr < 3 ? jr : jr - 9 - 3 * ct;
-                const bool bin = bb >= 0 && bb < 3;
-                const float sgn = jr < 3 ? -1.f : (bin ? 1.f : 0.f);
-                eo[rd] = kind ? (NS + (i < NF ? i : 0)) * GLD + j0 : (int)(c.arow - c.G) + 96 + (bin ? bb : 0);
-                es[rd] = kind ? 1 : 3;
-                ew[rd] = kind ? ((havep && i < NF) ? 1.f : 0.f) : (i0 < NF ? sgn * gam_of(c, ct, k) : 0.f);
-                // another corner of the same foot, same axis: symmetry-cost coupling (Quu only)
-                const bool sy = kind && i < NF && (i / 12) == (j0 / 12);
-                const float gq = gam_of(c, i < 12 ? 0 : 1, k);
-                symc[rd] = i % 3;
-                symw[rd] = sy ? 2.f * prm.w_sym * 0.25f * gq * (2.f - gq) : 0.f;
-            }
-            int r0[3], r1[3], r2[3];
-            float w0[3], w1[3], w2[3];
-#pragma unroll
-            for (int rd = 0; rd < 3; ++rd) {
-                r0[rd] = c.Brow[dsc[rd]]; r1[rd] = c.Brow[dsc[rd] + 1]; r2[rd] = c.Brow[dsc[rd] + 2];
-                w0[rd] = c.Bval[dsc[rd]]; w1[rd] = c.Bval[dsc[rd] + 1]; w2[rd] = c.Bval[dsc[rd] + 2];
-            }
-            float o[3][3];
-#pragma unroll
-            for (int rd = 0; rd < 3; ++rd) {
-                const float* g0 = Gp + r0[rd] * GLD + col0[rd];
-                const float* g1 = Gp + r1[rd] * GLD + col0[rd];
-                const float* g2 = Gp + r2[rd] * GLD + col0[rd];
-                const float* E = Gp + eo[rd];
-#pragma unroll
-                for (int cc = 0; cc < 3; ++cc) {
-                    float v = w0[rd] * g0[cc] + w1[rd] * g1[cc] + w2[rd] * g2[cc] + ew[rd] * E[cc * es[rd]];
-                    if (cc == symc[rd]) v -= symw[rd];
-                    o[rd][cc] = v;
-                }
-            }
+            quu_qus_triples<2>(c, prm, k, havep, tid);   // triples 0..255; wave 2 takes 256..284 after its float64 blocks
             PROF2(5);
-#pragma unroll
-            for (int rd = 0; rd < 3; ++rd)
-                if (ok[rd]) {
-                    float* dst = c.Pan + sto[rd];   // QuuF sits NU * RLD floats below Pan
-                    dst[0] = o[rd][0]; dst[1] = o[rd][1]; dst[2] = o[rd][2];
-                }
-            PROF2(6);
-        } else if (tid < 128 + 60) {
-            // lower entry w of diagonal block tid' / 6: (row, col) = (0,0) (1,0) (1,1) (2,0) (2,1) (2,2)
-            const int t = tid - 128, b = t / 6, w = t - 6 * b;
+        } else if (tid < 192) {
+          const int t = tid - 128;
+          if (t < 60) {
+            // lower entry w of diagonal block t / 6: (row, col) = (0,0) (1,0) (1,1) (2,0) (2,1) (2,2)
+            const int b = t / 6, w = t - 6 * b;
             const int rr = w >= 3 ? 2 : (w >= 1 ? 1 : 0), cc = w - rr * (rr + 1) / 2;
             const int i = 3 * b + rr, j = 3 * b + cc;
             const int b0 = c.Brow[3 * i], b1 = c.Brow[3 * i + 1], b2 = c.Brow[3 * i + 2];
@@ -778,6 +786,8 @@ __device__ inline void stage_pre_body(const Ctx& c, const CmpcConsts& prm, int t
             c.QuuD[9 * b + 3 * rr + cc] = v;
             c.QuuF[i * RLD + j] = 0.f;  // the float copy of a diagonal block collects the updates by earlier blocks
             PROF4(7);
+          }
+          if (t < 285 - 256) quu_qus_triples<1>(c, prm, k, havep, 256 + t);
         } else if (tid >= 192) {
           // wave 3: Pd = P [d; 0] + pv (float64), then qu, which reads it (same wave: LDS order suffices)
           if (tid < 192 + NXA) {
