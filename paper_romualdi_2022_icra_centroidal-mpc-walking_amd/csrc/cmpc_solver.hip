@@ -455,13 +455,15 @@ __device__ inline double readlane_d(double x, int lane)
 // three columns of L per step, then one rank-3 update of the trailing columns.
 __device__ inline double rsqrt_d(double x)
 {
-    double r = (double)rsqrtf((float)x);
-    return r * (1.5 - 0.5 * x * r * r);  // one Newton step in float64: ~1e-14 relative
+    // v_rsq_f32 seed (pivots are far from denormal: no range scaling), one Newton step in float64: ~1e-14 relative.
+    // A non-positive pivot gives NaN (or inf), which every later entry of the block inherits: tested once per block.
+    double r = (double)__builtin_amdgcn_rsqf((float)x);
+    return r * (1.5 - 0.5 * x * r * r);
 }
 __device__ inline bool chol_solve_fused(float (&v)[NU], double (&dd)[3], int lane, int fixedmask)
 {
-    bool bad = false;
     const int myblk = lane / 3, jm = lane - 3 * myblk;
+    bool bad = false;
 #pragma unroll
     for (int b = 0; b < NU / 3; ++b) {
         const int j0 = 3 * b;
@@ -479,18 +481,15 @@ __device__ inline bool chol_solve_fused(float (&v)[NU], double (&dd)[3], int lan
         const double d00 = readlane_d(dd[0], j0);
         const double d10 = readlane_d(dd[0], j0 + 1), d11 = readlane_d(dd[1], j0 + 1);
         const double d20 = readlane_d(dd[0], j0 + 2), d21 = readlane_d(dd[1], j0 + 2), d22 = readlane_d(dd[2], j0 + 2);
-        double p0 = d00;
-        if (!(p0 > 0.0)) { bad = true; p0 = 1.0; }
-        const double r00 = rsqrt_d(p0);
-        const double l00 = p0 * r00, l10 = d10 * r00, l20 = d20 * r00;
-        double p1 = d11 - l10 * l10;
-        if (!(p1 > 0.0)) { bad = true; p1 = 1.0; }
+        const double r00 = rsqrt_d(d00);
+        const double l00 = d00 * r00, l10 = d10 * r00, l20 = d20 * r00;
+        const double p1 = d11 - l10 * l10;
         const double r11 = rsqrt_d(p1);
         const double l11 = p1 * r11, l21 = (d21 - l20 * l10) * r11;
-        double p2 = d22 - l20 * l20 - l21 * l21;
-        if (!(p2 > 0.0)) { bad = true; p2 = 1.0; }
+        const double p2 = d22 - l20 * l20 - l21 * l21;
         const double r22 = rsqrt_d(p2);
         const double l22 = p2 * r22;
+        bad = bad || !(l22 > 0.0);  // the last link of the chain: a non-positive pivot anywhere before it arrives here as NaN
         // rows below the block and panel rows: x = v[j0..j0+2] L_bb^{-T}
         float x0 = v[j0] * (float)r00;
         float x1 = (v[j0 + 1] - x0 * (float)l10) * (float)r11;
