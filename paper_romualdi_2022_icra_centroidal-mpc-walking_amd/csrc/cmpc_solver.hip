@@ -460,7 +460,10 @@ __device__ inline double rsqrt_d(double x)
     double r = (double)__builtin_amdgcn_rsqf((float)x);
     return r * (1.5 - 0.5 * x * r * r);
 }
-__device__ inline bool chol_solve_fused(float (&v)[NU], double (&dd)[3], int lane, int fixedmask)
+// The row lives in 15 register pairs (vv[j / 2][j % 2] = entry j) so that the trailing update can use packed FMAs.
+typedef float float2v __attribute__((ext_vector_type(2)));
+#define VE(j) vv[(j) >> 1][(j) & 1]
+__device__ inline bool chol_solve_fused(float2v (&vv)[NU / 2], double (&dd)[3], int lane, int fixedmask)
 {
     const int myblk = lane / 3, jm = lane - 3 * myblk;
     bool bad = false;
@@ -472,9 +475,9 @@ __device__ inline bool chol_solve_fused(float (&v)[NU], double (&dd)[3], int lan
         asm volatile("" : "+v"(myb), "+v"(jmo));
         const bool inblk = (myb == b);
         if (inblk) {
-            dd[0] += (double)v[j0];
-            dd[1] += (double)v[j0 + 1];
-            dd[2] += (double)v[j0 + 2];
+            dd[0] += (double)VE(j0);
+            dd[1] += (double)VE(j0 + 1);
+            dd[2] += (double)VE(j0 + 2);
         }
         // a stance foot's landing offsets are identity rows and columns: nothing to do
         if (j0 >= NF && ((fixedmask >> (j0 - NF)) & 7) == 7) continue;
@@ -491,21 +494,38 @@ __device__ inline bool chol_solve_fused(float (&v)[NU], double (&dd)[3], int lan
         const double l22 = p2 * r22;
         bad = bad || !(l22 > 0.0);  // the last link of the chain: a non-positive pivot anywhere before it arrives here as NaN
         // rows below the block and panel rows: x = v[j0..j0+2] L_bb^{-T}
-        float x0 = v[j0] * (float)r00;
-        float x1 = (v[j0 + 1] - x0 * (float)l10) * (float)r11;
-        float x2 = (v[j0 + 2] - x0 * (float)l20 - x1 * (float)l21) * (float)r22;
+        float x0 = VE(j0) * (float)r00;
+        float x1 = (VE(j0 + 1) - x0 * (float)l10) * (float)r11;
+        float x2 = (VE(j0 + 2) - x0 * (float)l20 - x1 * (float)l21) * (float)r22;
         if (inblk) {  // the block's own rows of L, from the float64 factor
             x0 = (float)(jmo == 0 ? l00 : (jmo == 1 ? l10 : l20));
             x1 = jmo == 0 ? 0.f : (float)(jmo == 1 ? l11 : l21);
             x2 = jmo == 2 ? (float)l22 : 0.f;
         }
-        v[j0] = x0; v[j0 + 1] = x1; v[j0 + 2] = x2;
+        VE(j0) = x0; VE(j0 + 1) = x1; VE(j0 + 2) = x2;
+        // rank-3 update of the trailing columns: a leading odd column alone, then two columns per packed FMA.  Each
+        // update is pinned here: left alone, the optimiser sinks the FMAs to the block that next reads the column and
+        // the broadcast scalars (81 per block) wait for them in SGPRs spilled to VGPR lanes
+        if ((j0 + 3) & 1) {
+            const int cc = j0 + 3;
+            if (cc < NU) {
+                VE(cc) = fmaf(-x2, readlane_f(x2, cc), fmaf(-x1, readlane_f(x1, cc), fmaf(-x0, readlane_f(x0, cc), VE(cc))));
+                asm volatile("" : "+v"(vv[cc >> 1]));
+            }
+        }
+        const float2v nx0 = {-x0, -x0}, nx1 = {-x1, -x1}, nx2 = {-x2, -x2};
 #pragma unroll
-        for (int cc = j0 + 3; cc < NU; ++cc) {
-            v[cc] = fmaf(-x2, readlane_f(x2, cc), fmaf(-x1, readlane_f(x1, cc), fmaf(-x0, readlane_f(x0, cc), v[cc])));
-            // pin the update here: left alone, the optimiser sinks the FMAs to the block that next reads v[cc] and the
-            // broadcast scalars (81 per block) wait for them in SGPRs spilled to VGPR lanes
-            asm volatile("" : "+v"(v[cc]));
+        for (int pp = (j0 + 4) >> 1; pp < NU / 2; ++pp) {
+            const int cc = 2 * pp;
+            const float2v s0 = {readlane_f(x0, cc), readlane_f(x0, cc + 1)};
+            const float2v s1 = {readlane_f(x1, cc), readlane_f(x1, cc + 1)};
+            const float2v s2 = {readlane_f(x2, cc), readlane_f(x2, cc + 1)};
+            float2v acc = vv[pp];
+            acc = __builtin_elementwise_fma(nx0, s0, acc);
+            acc = __builtin_elementwise_fma(nx1, s1, acc);
+            acc = __builtin_elementwise_fma(nx2, s2, acc);
+            vv[pp] = acc;
+            asm volatile("" : "+v"(vv[pp]));
         }
     }
     return bad;
@@ -520,7 +540,7 @@ __device__ inline void stage_factor(const float* QuuF, const double* QuuD, float
     const int prow = lane - 30 + 34 * wv;  // panel row of lanes >= 30
     const bool isL = lane < NU;
     const bool active = isL || prow < NPAN;
-    float v[NU];
+    float2v vv[NU / 2];
     double dd[3] = {0.0, 0.0, 0.0};
     PROF2_DECL;
     const bool idrow = !isL && prow >= NS && prow < NS + NU;
@@ -529,14 +549,12 @@ __device__ inline void stage_factor(const float* QuuF, const double* QuuD, float
 #pragma unroll
         for (int q4 = 0; q4 < 8; ++q4) {
             const float4 t4 = *reinterpret_cast<const float4*>(src + 4 * q4);
-            if (4 * q4 + 0 < NU) v[4 * q4 + 0] = t4.x;
-            if (4 * q4 + 1 < NU) v[4 * q4 + 1] = t4.y;
-            if (4 * q4 + 2 < NU) v[4 * q4 + 2] = t4.z;
-            if (4 * q4 + 3 < NU) v[4 * q4 + 3] = t4.w;
+            vv[2 * q4] = float2v{t4.x, t4.y};
+            if (2 * q4 + 1 < NU / 2) vv[(2 * q4 + 1) % (NU / 2)] = float2v{t4.z, t4.w};
         }
         if (idrow) {
 #pragma unroll
-            for (int cc = 0; cc < NU; ++cc) v[cc] = (cc == prow - NS) ? 1.f : 0.f;
+            for (int cc = 0; cc < NU; ++cc) VE(cc) = (cc == prow - NS) ? 1.f : 0.f;
         }
         if (isL) {
             dd[0] = QuuD[9 * (lane / 3) + 3 * (lane % 3) + 0];
@@ -545,7 +563,7 @@ __device__ inline void stage_factor(const float* QuuF, const double* QuuD, float
         }
     }
     PROF2(28);
-    const bool bad = chol_solve_fused(v, dd, lane, fixedmask);
+    const bool bad = chol_solve_fused(vv, dd, lane, fixedmask);
     PROF2(29);
     if (bad && tid == 0) *flag = 1;
     if (!isL && active) {
@@ -561,9 +579,9 @@ __device__ inline void stage_factor(const float* QuuF, const double* QuuD, float
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             float4 w;
-            w.x = v[4 * q]; w.y = v[4 * q + 1];
-            w.z = 4 * q + 2 < NU ? v[(4 * q + 2) % NU] : 0.f;
-            w.w = 4 * q + 3 < NU ? v[(4 * q + 3) % NU] : 0.f;
+            w.x = vv[2 * q].x; w.y = vv[2 * q].y;
+            w.z = 2 * q + 1 < NU / 2 ? vv[(2 * q + 1) % (NU / 2)].x : 0.f;
+            w.w = 2 * q + 1 < NU / 2 ? vv[(2 * q + 1) % (NU / 2)].y : 0.f;
             *reinterpret_cast<float4*>(prow_p + 4 * q) = make_float4(sc * w.x, sc * w.y, sc * w.z, sc * w.w);
             if (isId) { if (q >= I) *reinterpret_cast<float4*>(rrow + 4 * q) = w; }
             else *reinterpret_cast<float4*>(rrow + 4 * (q ^ (jw & 7))) = w;
