@@ -576,6 +576,10 @@ __device__ inline void stage_factor(const float* QuuF, const double* QuuD, float
         const int I = isId ? (m >> 2) : 0;
         float* prow_p = Pan + prow * RLD;
         float* rrow = rec + (isId ? ub_row(m) - 4 * I : REC_WT + 32 * jw);
+        // one store per float4 for both kinds of row; float4s left of an identity row's diagonal block go to row 30
+        // of U, a row whose only readers are lanes that discard what they compute (REC_ZERO is row 31)
+        float* trash = rec + ub_row(30);
+        const int sw = isId ? 0 : (jw & 7);
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             float4 w;
@@ -583,8 +587,7 @@ __device__ inline void stage_factor(const float* QuuF, const double* QuuD, float
             w.z = 2 * q + 1 < NU / 2 ? vv[(2 * q + 1) % (NU / 2)].x : 0.f;
             w.w = 2 * q + 1 < NU / 2 ? vv[(2 * q + 1) % (NU / 2)].y : 0.f;
             *reinterpret_cast<float4*>(prow_p + 4 * q) = make_float4(sc * w.x, sc * w.y, sc * w.z, sc * w.w);
-            if (isId) { if (q >= I) *reinterpret_cast<float4*>(rrow + 4 * q) = w; }
-            else *reinterpret_cast<float4*>(rrow + 4 * (q ^ (jw & 7))) = w;
+            *reinterpret_cast<float4*>(q >= I ? rrow + 4 * (q ^ sw) : trash) = w;
         }
     }
     PROF2(30);
