@@ -1584,7 +1584,9 @@ __global__ __launch_bounds__(NT, FG ? 2 : 1) void cmpc_solve_kernel(CmpcParams k
         // each corner force from its foot's mean, the force rate, the landing offsets.  A constant
         // internal force along the line joining two stance feet changes none of them (the NLP does
         // not determine it; it only drifts slowly towards the barrier's analytic centre).
-        float l_st = 0.f;
+        // Force steps count relative to the largest corner-force component of the iterate (the parity tolerance is
+        // relative; forces are ~1-3 N/kg here), states and landing offsets absolutely (metres, m/s: order one or less).
+        float l_st = 0.f, l_sf = 0.f, l_fm = 1.f;
         for (int e = tid; e < NS * (N + 1); e += NT) l_st = fmaxf(l_st, fabsf(c.dS[e]));
         for (int e = tid; e < NU * N; e += NT) {
             const int k = e / NU, m = e % NU;
@@ -1592,11 +1594,13 @@ __global__ __launch_bounds__(NT, FG ? 2 : 1) void cmpc_solve_kernel(CmpcParams k
             if (m < NF) {
                 const float* f = c.dU + NU * k + 12 * (m / 12) + m % 3;
                 const float mean = 0.25f * (f[0] + f[3] + f[6] + f[9]);
-                l_st = fmaxf(l_st, fabsf(du - gam_of(c, m / 12, k) * mean));
-                if (k > 0) l_st = fmaxf(l_st, fabsf(du - c.dU[e - NU]));
+                l_sf = fmaxf(l_sf, fabsf(du - gam_of(c, m / 12, k) * mean));
+                if (k > 0) l_sf = fmaxf(l_sf, fabsf(du - c.dU[e - NU]));
+                l_fm = fmaxf(l_fm, fabsf(c.U[e]));
             } else l_st = fmaxf(l_st, fabsf(du));
         }
-        const float step = ap * block_max<NT>(l_st, c.red, tid);
+        const float fm = prm.dev[3] > 0.5f ? 1.f : block_max<NT>(l_fm, c.red, tid);
+        const float step = ap * block_max<NT>(fmaxf(l_st, l_sf / fm), c.red, tid);
         step_prev = step_out;
         step_out = step;
         err = fmaxf(ep, ec);
