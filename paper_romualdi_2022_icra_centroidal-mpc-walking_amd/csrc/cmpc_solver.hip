@@ -1599,7 +1599,7 @@ __global__ __launch_bounds__(NT, FG ? 2 : 1) void cmpc_solve_kernel(CmpcParams k
                 l_fm = fmaxf(l_fm, fabsf(c.U[e]));
             } else l_st = fmaxf(l_st, fabsf(du));
         }
-        const float fm = prm.dev[3] > 0.5f ? 1.f : block_max<NT>(l_fm, c.red, tid);
+        const float fm = block_max<NT>(l_fm, c.red, tid);
         const float step = ap * block_max<NT>(fmaxf(l_st, l_sf / fm), c.red, tid);
         step_prev = step_out;
         step_out = step;
