@@ -200,3 +200,18 @@ def test_solve_does_not_depend_on_stale_lds(factors, monkeypatch):
     assert rc2 == 0 and (info2[:, 5] == 0).all(), s.last_error
     np.testing.assert_array_equal(X1, X2)
     np.testing.assert_array_equal(info1[:, 0], info2[:, 0])
+
+
+def test_fixed_initial_barrier_parameter_still_available(golden_dir):
+    """cmpc_config.mu_init > 0 pins the initial barrier parameter (default: per problem from its initial
+    infeasibility); both reach the same optimum."""
+    cfg, P, X0 = cm.synthetic.config3_external_push(8)
+    d = np.load(os.path.join(golden_dir, "argmin_cfg3.npz"))
+    for kw in ({}, {"mu_init": 0.1}, {"mu_init": 0.5}):
+        s = cm.BatchSolver(cfg, 8, **kw)
+        X, info, rc = s.solve_host(d["P"].astype(np.float32), d["X0"].astype(np.float32))
+        assert rc == 0 and (info[:, 5] == 0).all(), (kw, s.last_error)
+        for b in range(8):
+            e = parity.errors(cfg.N, d["P"][b], X[b], d["x_star"][b])
+            assert e["com"] < TOL and e["force0"] < TOL and e["pos"] < TOL, (kw, b, e)
+        s.close()
