@@ -1513,7 +1513,7 @@ __global__ __launch_bounds__(NT, FG ? 2 : 1) void cmpc_solve_kernel(CmpcParams k
         // Gauss-Newton Hessian, then to a larger Levenberg shift ----
         // once the complementarity products sit at the barrier floor the predictor has nothing to predict
         // (sigma ~ 0, second-order term ~ 0): take plain centring Newton steps, one sweep pair instead of three
-        const bool centring = !finishing && mu_cur <= 1.5f * prm.mu_min && ec <= 4.f * prm.mu_min;
+        const bool centring = !finishing && mu_cur <= fmaxf(1.5f * prm.mu_min, 0.15f * prm.tol) && ec <= fmaxf(4.f * prm.mu_min, 0.4f * prm.tol);
         bool exact = prm.exact_hessian != 0;
         float reg = prm.reg;
         int fail = 1;
