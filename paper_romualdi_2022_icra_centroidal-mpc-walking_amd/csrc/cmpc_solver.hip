@@ -15,15 +15,18 @@
 // Hessian Quu through its Cholesky (barrier terms z/t span 1e-6..1e9 inside one corner's block
 // next to cost curvature of order 10).
 //
-// Structure of one stage of the backward sweep (256 threads = 4 waves, ~5 barriers):
-//   1. G = P [B;E], T1 = Pss A           sparse: every column of A, B has <= 3 non-zeros
-//   2. Quu, Qus, Qss, right-hand sides    (Quu diag blocks in float64)
-//   3. fused Cholesky + panel solve       one wave, matrix rows in registers: lanes 0-29 hold the
-//      rows of Quu, lanes 30-63 hold rows of [Qus | I | qu]^T, so L^{-1}[Qus | I | qu] falls out of
-//      the same rank-1 updates (v_readlane broadcasts, no LDS traffic, no barriers)
+// Structure.  The kernel body is a driver; every phase is an out-of-line device function (a register
+// allocation of its own) handed the LDS base.  One stage of the backward sweep (256 threads = 4 waves,
+// 4 barriers):
+//   1. G = P [B;E]                        sparse: every column of A, B has <= 3 non-zeros
+//   2. Quu, Qus (waves 0-1, float32), Quu diagonal blocks (wave 2, float64), Pd and qu (wave 3, float64)
+//   3. fused Cholesky + panel solve       waves 0-1, matrix rows in registers: lanes 0-29 hold the rows of
+//      Quu, lanes 30-63 rows of [Qus | I | qu]^T, so L^{-1}[Qus | I | qu] falls out of the same rank-3
+//      updates (3x3 pivot blocks in float64, v_readlane broadcasts, packed FMAs, no LDS traffic);
+//      meanwhile waves 2-3 build Qss, qs and the column descriptors of the next stage
 //   4. P = [Qss 0; 0 D] - W^T W           30-term dot products on 16-byte LDS reads
 // The vector sweeps (forward, corrector right-hand side, costates) run on one wave without
-// workgroup barriers.
+// workgroup barriers; the per-stage factors they read are stored transposed, a row per lane.
 #include "cmpc_device.h"
 
 #define NS CMPC_NS
