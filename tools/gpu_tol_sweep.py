@@ -13,7 +13,10 @@ if 'SWEEP_SETS' in os.environ:
     SETS = tuple(tuple(float(x) for x in v.split(':')) for v in os.environ['SWEEP_SETS'].split(','))
 elif 'SWEEP_STEPTOL' in os.environ:
     SETS = tuple((1e-6, 1e-7, float(v)) for v in os.environ['SWEEP_STEPTOL'].split(','))
-for name, gen in (("cfg2", cm.synthetic.config2_perturbed_com), ("cfg3", cm.synthetic.config3_external_push)):
+CONFIGS = [("cfg2", cm.synthetic.config2_perturbed_com), ("cfg3", cm.synthetic.config3_external_push)]
+if os.environ.get("SWEEP_CFG5"):
+    CONFIGS.append(("cfg5", cm.synthetic.config5_footstep_candidates))
+for name, gen in CONFIGS:
     cfg, P, X0 = gen(B)
     P32, X032 = P.astype(np.float32), X0.astype(np.float32)
     oc = problem_nlp.oracle_cfg(cfg)
