@@ -153,7 +153,7 @@ def main():
         if ag_ms is not None:
             out["allgather_ms"] = round(ag_ms, 4)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(cfg, P32, X032, 1e-6, 3e-8, args.cpu_sample)
+            out["cpu_baseline"] = cpu_baseline(cfg, P32, X032, 1e-6, 5e-8, args.cpu_sample)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

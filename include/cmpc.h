@@ -60,7 +60,7 @@ typedef struct {
     double step_tolerance;    /* on the last Newton step, max-norm over states and forces (default 1e-4) */
     double mu_init;           /* initial barrier parameter; <= 0 (default): per problem, from its
                                * initial infeasibility ep0: clamp(3.5 ep0^2, 0.03, 0.5)           */
-    double mu_min;            /* final barrier parameter (default 0.03 x tolerance = 3e-8)        */
+    double mu_min;            /* final barrier parameter (default 0.05 x tolerance = 5e-8)        */
     int exact_hessian;        /* 1 (default): Lagrangian Hessian; 0: Gauss-Newton                 */
     int final_extrapolation;  /* 1: finish with one extra affine-scaling step towards mu = 0 (default 0) */
 } cmpc_config;

@@ -82,7 +82,7 @@ void cmpc_default_config(cmpc_config* c)
     c->tolerance = 1e-6;
     c->step_tolerance = 1e-4;
     c->mu_init = 0.0;  // <= 0: chosen per problem from its initial infeasibility
-    c->mu_min = 3e-8;
+    c->mu_min = 5e-8;
     c->exact_hessian = 1;
     c->final_extrapolation = 0;
 }
@@ -118,9 +118,10 @@ int cmpc_create(const cmpc_config* cfg, int batch, int device, cmpc_handle* out)
     if (h->cfg.max_iterations <= 0) h->cfg.max_iterations = 40;
     if (!(h->cfg.tolerance > 0)) h->cfg.tolerance = 1e-6;
     if (!(h->cfg.step_tolerance > 0)) h->cfg.step_tolerance = 100.0 * h->cfg.tolerance;
-    // 0.03 x tolerance: the same iteration counts as tolerance / 10 (the barrier decreases superlinearly at the end)
-    // at half the sqrt(mu) bias of the nearly degenerate rows; 1e-8 is below what float32 factorisations survive
-    if (!(h->cfg.mu_min > 0)) h->cfg.mu_min = 0.03 * h->cfg.tolerance;
+    // 0.05 x tolerance: the same iteration counts as tolerance / 10 (the barrier decreases superlinearly at the end)
+    // at 0.7 x the sqrt(mu) bias of the nearly degenerate rows; float32 factorisations start to fail at 2e-8 (8 of 512
+    // problems of config 5), 1e-8 loses most of config 3
+    if (!(h->cfg.mu_min > 0)) h->cfg.mu_min = 0.05 * h->cfg.tolerance;
     if (!(h->cfg.gravity > 0)) h->cfg.gravity = 9.80665;
     h->B = batch;
     h->device = device;

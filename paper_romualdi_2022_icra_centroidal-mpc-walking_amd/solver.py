@@ -39,7 +39,7 @@ def _c_config(cfg: CentroidalMPCConfig, tolerance=None, mu_min=None, max_iterati
     c.tolerance = tolerance if tolerance is not None else min(cfg.ipopt_tolerance, 1e-6)
     c.step_tolerance = step_tolerance if step_tolerance is not None else 100.0 * c.tolerance
     c.mu_init = mu_init if mu_init is not None else 0.0   # <= 0: per problem, from its initial infeasibility
-    c.mu_min = mu_min if mu_min is not None else 0.03 * c.tolerance
+    c.mu_min = mu_min if mu_min is not None else 0.05 * c.tolerance
     c.exact_hessian = int(exact_hessian)
     c.final_extrapolation = int(final_extrapolation)
     return c

@@ -14,6 +14,8 @@ if 'SWEEP_SETS' in os.environ:
 elif 'SWEEP_STEPTOL' in os.environ:
     SETS = tuple((1e-6, 1e-7, float(v)) for v in os.environ['SWEEP_STEPTOL'].split(','))
 CONFIGS = [("cfg2", cm.synthetic.config2_perturbed_com), ("cfg3", cm.synthetic.config3_external_push)]
+if os.environ.get("SWEEP_CFG5") == "only":
+    CONFIGS = []
 if os.environ.get("SWEEP_CFG5"):
     CONFIGS.append(("cfg5", cm.synthetic.config5_footstep_candidates))
 for name, gen in CONFIGS:
