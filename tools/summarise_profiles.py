@@ -6,7 +6,8 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 src = os.path.join(ROOT, "gpurun_out", "prof")
 dst = os.path.join(ROOT, "profiles")
 
-stats = glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True)
+# (gpurun merges new output over old: several runs may lie side by side -- always the newest file)
+stats = sorted(glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True), key=os.path.getmtime, reverse=True)
 assert stats, "no kernel_stats.csv under " + src
 rows = list(csv.DictReader(open(stats[0])))
 with open(os.path.join(dst, f"{tag}_kernel_stats.csv"), "w") as f:
@@ -19,7 +20,7 @@ per = {}
 for d in sorted(glob.glob(os.path.join(src, "pmc*"))):
     if not os.path.isdir(d):
         continue
-    for fn in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+    for fn in sorted(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True), key=os.path.getmtime, reverse=True)[:1]:
         acc, n = {}, {}
         for r in csv.DictReader(open(fn)):
             if "cmpc_solve_kernel" not in r["Kernel_Name"]:
