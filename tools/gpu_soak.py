@@ -1,0 +1,24 @@
+"""Developer probe: many seeded batches of every config; counts problems that do not converge."""
+import os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa
+import cmpc_amd as cm
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+seeds = range(100, 100 + (int(sys.argv[2]) if len(sys.argv) > 2 else 10))
+for name, gen in (("cfg2", cm.synthetic.config2_perturbed_com), ("cfg3", cm.synthetic.config3_external_push),
+                  ("cfg4", cm.synthetic.config4_monte_carlo), ("cfg5", cm.synthetic.config5_footstep_candidates)):
+    tot = bad = 0
+    itmax = 0
+    its = []
+    s = None
+    for sd in seeds:
+        cfg, P, X0 = gen(B, seed=sd)
+        if s is None:
+            s = cm.BatchSolver(cfg, B)
+        X, info, rc = s.solve_host(P.astype(np.float32), X0.astype(np.float32))
+        tot += B; bad += int((info[:, 5] != 0).sum()); itmax = max(itmax, int(info[:, 0].max())); its.append(info[:, 0].mean())
+        assert np.isfinite(X).all()
+    print(name, "problems", tot, "not converged", bad, "iterations mean %.2f max %d" % (np.mean(its), itmax), flush=True)
+    s.close()
