@@ -51,6 +51,7 @@ def main():
     ap.add_argument("--workload", default="config2", choices=["config2", "config3"])
     ap.add_argument("--cpu-sample", type=int, default=6144)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-collective", action="store_true", help="run the all-gather path with one rank too (rehearsal on a single GPU)")
     args = ap.parse_args()
 
     import torch
@@ -62,7 +63,8 @@ def main():
     assert world == args.gpus, f"WORLD_SIZE {world} != --gpus {args.gpus}"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    coll = world > 1 or args.force_collective
+    if coll:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
 
@@ -74,16 +76,20 @@ def main():
     dP, dX0 = torch.from_numpy(P32).to(dev), torch.from_numpy(X032).to(dev)
     dX = torch.empty_like(dX0)
     dInfo = torch.empty((B, 8), dtype=torch.float32, device=dev)
-    cols = torch.from_numpy(cm.distributed.compact_columns(cfg.N)).to(dev)
+    # N > 1: one kernel packs the compact record of every problem, one RCCL all-gather shares it (preallocated buffers)
+    W = 3 * (cfg.N + 1) + 38
+    cbuf = torch.empty((B, W), dtype=torch.float32, device=dev) if coll else None
+    gbuf = torch.empty((world * B, W), dtype=torch.float32, device=dev) if coll else None
+
+    def gather():
+        return cm.distributed.all_gather_solutions(solver.compact_output_device(dX, dInfo, cbuf), world, out=gbuf, force=True)
 
     def step():
         solver.solve_device(dP, dX0, dX, dInfo)
-        if world > 1:
-            return cm.distributed.all_gather_solutions(cm.distributed.compact_output(dX, dInfo, cols), world)
-        return None
+        return gather() if coll else None
 
     def barrier():
-        if world > 1:
+        if coll:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -97,8 +103,8 @@ def main():
         ev[2 * i].record(ks)
         solver.solve_device(dP, dX0, dX, dInfo)
         ev[2 * i + 1].record(ks)
-        if world > 1:
-            cm.distributed.all_gather_solutions(cm.distributed.compact_output(dX, dInfo, cols), world)
+        if coll:
+            gather()
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -108,12 +114,11 @@ def main():
     kern_ms = np.array([ev[2 * i].elapsed_time(ev[2 * i + 1]) for i in range(args.steps)])
     info = dInfo.cpu().numpy()
     ag_ms = None
-    if world > 1:  # the collective alone, for the record
-        c = cm.distributed.compact_output(dX, dInfo, cols)
+    if coll:  # packing + collective alone, for the record
         barrier()
         t1 = time.perf_counter()
         for _ in range(10):
-            cm.distributed.all_gather_solutions(c, world)
+            gather()
         barrier()
         ag_ms = (time.perf_counter() - t1) / 10 * 1e3
 
@@ -155,7 +160,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, P32, X032, 1e-6, 5e-8, args.cpu_sample)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if coll:
         dist.destroy_process_group()
 
 

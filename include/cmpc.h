@@ -141,6 +141,11 @@ int cmpc_set_reference_from_planner(cmpc_handle h, const float* com_in, const fl
 int cmpc_plant_step_device(cmpc_handle h, const float* dX, const float* dP, const float* dStateIn, float* dStateOut,
                            float* dZmp, double step, int substeps, double zmp_half_x, double zmp_half_y, void* stream);
 
+/* 8e, the record a Monte-Carlo driver gathers across GPUs (no reference counterpart: the reference runs one problem):
+ * dOut[B][3(N+1) + 38] = CoM trajectory 3(N+1) | first-knot corner forces 24 | knot-0 and knot-1 foot positions 12 |
+ * iterations | status, from dX[B][n_x] and dInfo[B][8].  Device pointers; asynchronous on `stream` (NULL: the handle's). */
+int cmpc_compact_output_device(cmpc_handle h, const float* dX, const float* dInfo, float* dOut, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -39,6 +39,7 @@ EXPORTS = [
     "cmpc_eval_nlp_device", "cmpc_nlp_sparsity", "cmpc_set_state", "cmpc_set_reference",
     "cmpc_set_contacts", "cmpc_set_initial_guess", "cmpc_advance", "cmpc_get_solution",
     "cmpc_get_output", "cmpc_set_reference_from_planner", "cmpc_plant_step_device", "cmpc_test_poison_lds",
+    "cmpc_compact_output_device",
 ]
 
 _lib = None
@@ -73,6 +74,7 @@ def lib():
         L.cmpc_solve.argtypes = [vp, fp, fp, fp, fp]
         L.cmpc_last_solve_ms.argtypes = [vp]
         L.cmpc_test_poison_lds.argtypes = [vp]
+        L.cmpc_compact_output_device.argtypes = [vp, fp, fp, fp, vp]
         L.cmpc_last_solve_ms.restype = C.c_float
         L.cmpc_eval_nlp_device.argtypes = [vp, fp, fp, fp, C.c_float, fp, fp, fp, fp, fp, vp]
         L.cmpc_nlp_sparsity.argtypes = [C.c_int, vp, vp, vp, vp]

@@ -16,6 +16,7 @@ extern "C" int cmpc_launch_nlp_eval(const CmpcParams* prm, const float* dX, cons
                                     float lam_f, float* dF, float* dG, float* dGradF, float* dJac, float* dHess,
                                     hipStream_t stream);
 extern "C" int cmpc_launch_warm_shift(const CmpcParams* prm, const float* dXprev, float* dX0, hipStream_t stream);
+extern "C" int cmpc_launch_compact(int N, int B, const float* dX, const float* dInfo, float* dOut, hipStream_t stream);
 extern "C" int cmpc_launch_plant_step(int N, int B, float grav, const float* dCorners, const float* dX, const float* dP,
                                       const float* dStateIn, float* dStateOut, float* dZmp, float h, int nsub, float zx, float zy,
                                       hipStream_t stream);
@@ -563,6 +564,16 @@ int cmpc_plant_step_device(cmpc_handle h, const float* dX, const float* dP, cons
     int rc = cmpc_launch_plant_step(h->cfg.horizon, h->B, (float)h->cfg.gravity, corners, dX, dP, dStateIn, dStateOut, dZmp, (float)step,
                                     substeps, (float)zmp_half_x, (float)zmp_half_y, stream ? (hipStream_t)stream : h->stream);
     if (rc != 0) return fail(h, CMPC_ERR_HIP, std::string("plant step launch: ") + hipGetErrorString((hipError_t)rc));
+    return CMPC_OK;
+}
+
+// ---- 8e: compact per-problem output for the all-gather (see cmpc_compact_kernel) ----
+int cmpc_compact_output_device(cmpc_handle h, const float* dX, const float* dInfo, float* dOut, void* stream)
+{
+    if (!h || !dX || !dInfo || !dOut) return fail(h, CMPC_ERR_ARG, "cmpc_compact_output_device: null pointer");
+    HIPCHK(h, hipSetDevice(h->device));
+    int rc = cmpc_launch_compact(h->cfg.horizon, h->B, dX, dInfo, dOut, stream ? (hipStream_t)stream : h->stream);
+    if (rc != 0) return fail(h, CMPC_ERR_HIP, std::string("compact output launch: ") + hipGetErrorString((hipError_t)rc));
     return CMPC_OK;
 }
 

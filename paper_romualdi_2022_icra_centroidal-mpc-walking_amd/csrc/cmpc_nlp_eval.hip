@@ -549,3 +549,29 @@ extern "C" int cmpc_launch_plant_step(int N, int B, float grav, const float* dCo
                        dStateOut, dZmp, h, nsub, zx, zy);
     return (int)hipGetLastError();
 }
+
+// ---- compact per-problem output for the all-gather of the multi-GPU path: CoM trajectory 3(N+1), first-knot
+// corner forces 24, knot-0 and knot-1 foot positions 12, iterations, status  ->  out[B][3(N+1) + 38] ----
+namespace {
+__global__ __launch_bounds__(128) void cmpc_compact_kernel(int N, const float* __restrict__ X, const float* __restrict__ info,
+                                                           float* __restrict__ out)
+{
+    const CmpcIdx L{N};
+    const int b = blockIdx.x, ncom = 3 * (N + 1), W = ncom + 38;
+    const float* x = X + (size_t)b * L.nx();
+    for (int c = threadIdx.x; c < W; c += 128) {
+        float v;
+        if (c < ncom) v = x[L.oCom() + c];
+        else if (c < ncom + 24) { const int f = c - ncom; v = x[L.oF(f / 12, (f % 12) / 3) + f % 3]; }
+        else if (c < ncom + 36) { const int p = c - ncom - 24; v = x[L.oPos(p / 6) + p % 6]; }
+        else v = info[(size_t)b * CMPC_INFO_N + (c == ncom + 36 ? 0 : 5)];
+        out[(size_t)b * W + c] = v;
+    }
+}
+}  // namespace
+
+extern "C" int cmpc_launch_compact(int N, int B, const float* dX, const float* dInfo, float* dOut, hipStream_t stream)
+{
+    hipLaunchKernelGGL(cmpc_compact_kernel, dim3(B), dim3(128), 0, stream, N, dX, dInfo, dOut);
+    return (int)hipGetLastError();
+}

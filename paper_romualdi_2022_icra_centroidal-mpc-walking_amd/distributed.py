@@ -37,13 +37,15 @@ def compact_output(X, info, cols):
     return torch.cat([X.index_select(1, cols), info[:, [0, 5]]], dim=1)
 
 
-def all_gather_solutions(local, world: int):
+def all_gather_solutions(local, world: int, out=None, force: bool = False):
     """Gathers the per-rank compact outputs [B_r, W] into [sum B_r, W] on every rank (equal shard
-    sizes; torch.distributed must be initialised when world > 1)."""
-    if world == 1:
+    sizes; torch.distributed must be initialised when world > 1).  `out`: a preallocated result
+    (steady-state loops); `force` runs the collective for one rank too (rehearsal on a single GPU)."""
+    if world == 1 and not force:
         return local
     import torch
     import torch.distributed as dist
-    out = torch.empty((world * local.shape[0], local.shape[1]), dtype=local.dtype, device=local.device)
+    if out is None:
+        out = torch.empty((world * local.shape[0], local.shape[1]), dtype=local.dtype, device=local.device)
     dist.all_gather_into_tensor(out, local.contiguous())
     return out

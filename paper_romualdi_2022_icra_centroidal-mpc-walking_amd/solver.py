@@ -125,6 +125,24 @@ class BatchSolver:
     def last_solve_ms(self) -> float:
         return float(self._lib.cmpc_last_solve_ms(self._h))
 
+    def compact_output_device(self, dX, dInfo, out=None):
+        """[B, 3(N+1) + 38] compact record of every problem (what distributed.compact_output builds with torch ops), by
+        one kernel on the solver's stream; torch CUDA tensors."""
+        import torch
+        W = 3 * (self.cfg.N + 1) + 38
+        if out is None:
+            out = torch.empty((self.batch, W), dtype=torch.float32, device=dX.device)
+        assert out.is_contiguous() and tuple(out.shape) == (self.batch, W)
+        if self._stream is None:
+            self._stream = torch.cuda.Stream(dX.device)
+        cur = torch.cuda.current_stream(dX.device)
+        self._stream.wait_stream(cur)
+        rc = self._lib.cmpc_compact_output_device(self._h, dX.data_ptr(), dInfo.data_ptr(), out.data_ptr(), self._stream.cuda_stream)
+        if rc != 0:
+            raise RuntimeError(f"cmpc_compact_output_device failed ({rc}): {self.last_error}")
+        cur.wait_stream(self._stream)
+        return out
+
     def plant_step_device(self, dX, dP, dState, dStateOut=None, dZmp=None, step=0.01, substeps=6,
                           zmp_half_x=0.08, zmp_half_y=0.03):
         """Closed-loop plant between two MPC ticks (WholeBodyQPBlock.cpp:805-873, 1083-1084, 1150): RK4 of the

@@ -215,3 +215,16 @@ def test_fixed_initial_barrier_parameter_still_available(golden_dir):
             e = parity.errors(cfg.N, d["P"][b], X[b], d["x_star"][b])
             assert e["com"] < TOL and e["force0"] < TOL and e["pos"] < TOL, (kw, b, e)
         s.close()
+
+
+def test_compact_output_kernel_matches_the_torch_restatement():
+    import torch
+    cfg, P, X0 = cm.synthetic.config3_external_push(64)
+    s = cm.BatchSolver(cfg, 64)
+    dX, dInfo = s.solve_device(torch.from_numpy(P.astype(np.float32)).cuda(), torch.from_numpy(X0.astype(np.float32)).cuda())
+    cols = torch.from_numpy(cm.distributed.compact_columns(cfg.N)).cuda()
+    ref = cm.distributed.compact_output(dX, dInfo, cols)
+    out = s.compact_output_device(dX, dInfo)
+    torch.cuda.synchronize()
+    assert tuple(out.shape) == tuple(ref.shape)
+    np.testing.assert_array_equal(out.cpu().numpy(), ref.cpu().numpy())
