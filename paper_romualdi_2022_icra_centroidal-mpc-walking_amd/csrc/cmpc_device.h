@@ -8,7 +8,6 @@
 #define CMPC_NU 30
 #define CMPC_NXA 39  // NS + NF: the previous force rides along as state (force-rate cost)
 #define CMPC_NI 44   // inequality rows per stage: 32 friction + 6 q upper + 6 q lower
-#define CMPC_LP 465  // packed lower triangle of a 30x30
 #define CMPC_REC_N 1088  // floats of one stage's factor record (layout: cmpc_solver.hip)
 #define CMPC_NMAX 40 // largest horizon the kernels are built for
 #define CMPC_INFO_N 8

@@ -35,7 +35,6 @@
 #define NU CMPC_NU
 #define NXA CMPC_NXA
 #define NI CMPC_NI
-#define LP CMPC_LP
 #define PLD 39     // leading dim of P (odd: column walks are conflict-free)
 #define GLD 30     // G = P [B;E]  (39 x 30)
 #define RLD 36     // leading dim of the row-major float panels (16-byte aligned rows)
@@ -434,8 +433,6 @@ __device__ inline float AB_step(const Ctx& c, const CmpcConsts& prm, int k, int 
         if (qfree(c, k, 3 * ct + m)) land += Rm(R, a, m) * du[24 + 3 * ct + m];
     return gam * ds[i] + (1.f - gam) * land;
 }
-
-__device__ inline int lpk(int i, int j) { return i * (i + 1) / 2 + j; }  // packed lower (i >= j)
 
 __device__ inline float readlane_f(float x, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), lane)); }
 __device__ inline double readlane_d(double x, int lane)
