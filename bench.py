@@ -2,14 +2,26 @@
 """Benchmark of the hot path: batched centroidal-MPC solves (BASELINE.json metric).
 
     python bench.py --gpus N --steps K --warmup W
-(N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`,
-one rank per GPU.)  A step = one batched solve of the workload on every GPU (weak scaling: each rank
-solves its own batch), inputs resident in HBM, followed for N > 1 by the RCCL all-gather of the
-compact solutions.  Rank 0 prints ONE JSON line.
+
+N > 1: this script starts its own N ranks (one per GPU, `python -m torch.distributed.run` as a child process,
+BEFORE anything in this process touches the GPU) unless it is already running as a rank of such a launch
+(RANK/WORLD_SIZE in the environment: the driver's own `torch.distributed.run ... bench.py --gpus N`).
+A step = one batched solve of the workload on every GPU, inputs resident in HBM, followed for N > 1 by the
+RCCL all-gather of the compact solutions.  Rank 0 prints ONE JSON line.
+
+Workloads (BASELINE.json configs):
+    config2  B=256 per GPU, perturbed-CoM standing problems, horizon 20       (the headline `value`; weak scaling)
+    config3  B=4096 per GPU, swing phase + external pushes, step adjustment   (secondary; weak)
+    config4  65536 Monte-Carlo problems in total (config-3 generator, seed 2), contiguous shards of 65536/N
+             problems per GPU (8 x 8192 at N=8)                              (secondary; STRONG scaling)
+    config5  B=8192 per GPU, yawed footstep candidates, horizon 30            (secondary; weak)
+plus the single-problem (B=1) solve latency the metric names.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -20,12 +32,240 @@ sys.path.insert(0, ROOT)
 
 # canonical algorithmic work: F_iter(N) = 4.25e5 * N flop per interior-point iteration
 F_ITER_PER_STAGE = 4.25e5
-PEAK_F32_TFLOPS = 157.3  # MI355X_MICROARCH.md: f32 vector == f32-input MFMA peak
+PEAK_F32_TFLOPS = 157.3  # MI355X_MICROARCH.md: f32 vector peak (the kernel issues no MFMA: bound = VALU f32)
+CONFIG4_TOTAL = 65536
 
 
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=0, help="problems per GPU of the primary workload (0: its BASELINE size)")
+    ap.add_argument("--workload", default="config2", choices=["config2", "config3", "config4", "config5"])
+    ap.add_argument("--secondary", default="config3,config5,config4,latency",
+                    help="comma list of extra workloads reported under `secondary` ('' or 'none': skip)")
+    ap.add_argument("--secondary-steps", type=int, default=5)
+    ap.add_argument("--cpu-sample", type=int, default=6144)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="run the all-gather path with one rank too (rehearsal on a single GPU)")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="rehearsal only: more ranks than GPUs, ranks share the devices round-robin and the collective runs on "
+                         "gloo (RCCL refuses two ranks on one device); the line is marked `rehearsal`")
+    return ap.parse_args()
+
+
+def launch_ranks(args):
+    """Parent of an N > 1 run that was started as plain `python bench.py --gpus N`: starts the ranks as a child
+    process and exits with its code.  Nothing here initialises the GPU (device_count() does not, on this image)."""
+    import torch
+    ndev = torch.cuda.device_count()
+    if ndev < 1:
+        sys.exit("bench.py: no GPU visible (this benchmark has no CPU path)")
+    if args.gpus > ndev and not args.share_gpu:
+        sys.exit(f"bench.py: --gpus {args.gpus} but only {ndev} GPU(s) are visible; run on a node with {args.gpus} GPUs "
+                 f"(or add --share-gpu for a functional rehearsal with the ranks sharing the device)")
+    if args.share_gpu and args.gpus > 6:
+        sys.exit("bench.py: --share-gpu is limited to 6 ranks per device")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "2")
+    sys.exit(subprocess.call(cmd, env=env))
+
+
+# ------------------------------------------------------------------------------------------------------------
+def make_workload(cm, name, rank, world, batch=0):
+    """-> (cfg, P32, X032, scaling, description).  Each rank builds only its own problems."""
+    if name == "config2":
+        B = batch or 256
+        cfg, P, X0 = cm.synthetic.config2_perturbed_com(B, seed=0 + 1000 * rank)
+        return cfg, P, X0, "weak", f"config2: batch={B}/GPU perturbed-CoM standing problems"
+    if name == "config3":
+        B = batch or 4096
+        cfg, P, X0 = cm.synthetic.config3_external_push(B, seed=1 + 1000 * rank)
+        return cfg, P, X0, "weak", f"config3: batch={B}/GPU swing phase + external pushes (+-50 N), step adjustment on"
+    if name == "config4":
+        total = batch * world if batch else CONFIG4_TOTAL
+        lo, hi = cm.distributed.shard_bounds(total, world, rank)
+        cfg, P, X0 = cm.synthetic.config4_monte_carlo(total, shard=(lo, hi))
+        return cfg, P, X0, "strong", (f"config4: {total} Monte-Carlo disturbances (config-3 generator, seed 2), contiguous shards of "
+                                      f"{hi - lo} per GPU")
+    if name == "config5":
+        B = batch or 8192
+        cfg, P, X0 = cm.synthetic.config5_footstep_candidates(B, seed=3 + 1000 * rank)
+        return cfg, P, X0, "weak", f"config5: batch={B}/GPU yawed footstep candidates, horizon 30"
+    raise ValueError(name)
+
+
+class Runner:
+    def __init__(self, args):
+        import torch
+        import cmpc_amd as cm
+        self.torch, self.cm, self.args = torch, cm, args
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        ndev = torch.cuda.device_count()
+        if ndev < 1:
+            sys.exit("bench.py: no GPU visible (this benchmark has no CPU path)")
+        if self.world != args.gpus:
+            sys.exit(f"bench.py: launched with WORLD_SIZE={self.world} but --gpus {args.gpus}; they must agree")
+        if self.world > ndev and not args.share_gpu:
+            sys.exit(f"bench.py: {self.world} ranks but {ndev} GPU(s); add --share-gpu for a rehearsal")
+        self.devidx = self.local_rank % ndev
+        torch.cuda.set_device(self.devidx)
+        self.dev = torch.device("cuda", self.devidx)
+        self.coll = self.world > 1 or args.force_collective
+        self.backend = None
+        if self.coll:
+            import torch.distributed as dist
+            self.dist = dist
+            self.backend = "gloo" if (args.share_gpu and self.world > ndev) else "nccl"
+            if "RANK" not in os.environ:  # --force-collective with a single, unlaunched rank
+                os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+                os.environ.setdefault("MASTER_PORT", "29533")
+                os.environ["RANK"], os.environ["WORLD_SIZE"] = "0", "1"
+            if self.backend == "nccl":
+                dist.init_process_group("nccl", device_id=self.dev)
+            else:
+                dist.init_process_group("gloo")
+
+    def barrier(self):
+        if self.coll:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
+
+    def max_over_ranks(self, v):
+        if self.world == 1:
+            return v
+        t = self.torch.tensor([v], dtype=self.torch.float64, device=self.dev if self.backend == "nccl" else "cpu")
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def gather_floats(self, vals):
+        """list of python floats per rank -> [world][len] on every rank"""
+        if self.world == 1:
+            return [list(vals)]
+        t = self.torch.tensor(vals, dtype=self.torch.float64, device=self.dev if self.backend == "nccl" else "cpu")
+        out = [self.torch.empty_like(t) for _ in range(self.world)]
+        self.dist.all_gather(out, t)
+        return [o.cpu().tolist() for o in out]
+
+    def run(self, name, steps, warmup, batch=0):
+        """Times `steps` steps of one workload; returns (measurement dict on every rank, host-side problem data)."""
+        torch, cm = self.torch, self.cm
+        cfg, P, X0, scaling, desc = make_workload(cm, name, self.rank, self.world, batch)
+        P32, X032 = P.astype(np.float32), X0.astype(np.float32)
+        del P, X0
+        B = P32.shape[0]
+        solver = cm.BatchSolver(cfg, B, device=self.devidx)
+        dP, dX0 = torch.from_numpy(P32).to(self.dev), torch.from_numpy(X032).to(self.dev)
+        dX = torch.empty_like(dX0)
+        dInfo = torch.empty((B, 8), dtype=torch.float32, device=self.dev)
+        # N > 1: one kernel packs the compact record of every problem, one all-gather shares it (preallocated buffers)
+        W = 3 * (cfg.N + 1) + 38
+        counts = [int(c) for c in np.array(self.gather_floats([float(B)]))[:, 0]]
+        equal = len(set(counts)) == 1
+        cbuf = torch.empty((B, W), dtype=torch.float32, device=self.dev) if self.coll else None
+        gbuf = torch.empty((sum(counts), W), dtype=torch.float32, device=self.dev) if self.coll else None
+
+        def gather():
+            local = solver.compact_output_device(dX, dInfo, cbuf)
+            return cm.distributed.all_gather_solutions(local, self.world, out=gbuf, force=True, counts=None if equal else counts)
+
+        def step():
+            solver.solve_device(dP, dX0, dX, dInfo)
+            return gather() if self.coll else None
+
+        for _ in range(warmup):
+            step()
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2 * steps)]
+        ks = solver.launch_stream       # the HIP stream the solve kernel is launched on
+        self.barrier()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            ev[2 * i].record(ks)
+            solver.solve_device(dP, dX0, dX, dInfo)
+            ev[2 * i + 1].record(ks)
+            if self.coll:
+                gather()
+        self.barrier()
+        elapsed = self.max_over_ranks(time.perf_counter() - t0)
+        kern_ms = np.array([ev[2 * i].elapsed_time(ev[2 * i + 1]) for i in range(steps)])
+        info = dInfo.cpu().numpy()
+        ag_ms = None
+        if self.coll:  # packing + collective alone, for the record
+            self.barrier()
+            t1 = time.perf_counter()
+            for _ in range(10):
+                gather()
+            self.barrier()
+            ag_ms = self.max_over_ranks((time.perf_counter() - t1) / 10 * 1e3)
+        iters = info[:, 0]
+        per_rank = self.gather_floats([float(kern_ms.mean()), float(iters.sum()), float(iters.max()), float((info[:, 5] == 0).sum()), float(B)])
+        pr = np.array(per_rank)
+        total_B = int(pr[:, 4].sum())
+        flop_per_launch = float(iters.sum()) * F_ITER_PER_STAGE * cfg.N     # this rank's launch
+        achieved = flop_per_launch / (kern_ms.mean() * 1e-3) / 1e12
+        m = {
+            "workload": f"{desc}, ergoCubGazeboV1 parameters, horizon={cfg.N}, dt={cfg.sampling_time}, cold start, converged to 1e-6",
+            "value": round(total_B * steps / elapsed, 1), "unit": "solves/s", "scaling": scaling,
+            "ms_per_step": round(elapsed / steps * 1e3, 4), "steps": steps,
+            "batch_per_gpu": B, "batch_total": total_B, "horizon": cfg.N,
+            "iterations_mean": round(float(pr[:, 1].sum() / total_B), 2), "iterations_max": int(pr[:, 2].max()),
+            "converged_fraction": round(float(pr[:, 3].sum() / total_B), 6),
+            "kernel_ms_per_rank": [round(v, 4) for v in pr[:, 0].tolist()],
+            "roofline": {"bound": "valu_f32", "achieved": round(achieved, 4), "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / PEAK_F32_TFLOPS, 5), "traffic": None,
+                         "kernel": "cmpc_solve_kernel", "kernel_ms_avg": round(float(kern_ms.mean()), 4),
+                         "algorithmic_flop_per_launch": flop_per_launch,
+                         "algorithmic_hbm_bytes_per_launch": 4 * B * (cm.Layout(cfg.N).np + 2 * cm.Layout(cfg.N).nx + 8)},
+        }
+        if ag_ms is not None:
+            m["allgather_ms"] = round(ag_ms, 4)
+        data = dict(cfg=cfg, P32=P32, X032=X032, X=dX.cpu().numpy(), info=info, kern_ms=kern_ms)
+        del solver, dP, dX0, dX, dInfo, cbuf, gbuf
+        torch.cuda.empty_cache()
+        return m, data
+
+    def latency(self, n=64):
+        """The metric's second half: solve latency of ONE problem (B=1, one workgroup), p50 over n different config-2
+        problems, HIP events on the launch stream."""
+        torch, cm = self.torch, self.cm
+        cfg, P, X0 = cm.synthetic.config2_perturbed_com(n, seed=7)
+        dP, dX0 = torch.from_numpy(P.astype(np.float32)).to(self.dev), torch.from_numpy(X0.astype(np.float32)).to(self.dev)
+        solver = cm.BatchSolver(cfg, 1, device=self.devidx)
+        dX = torch.empty((1, dX0.shape[1]), dtype=torch.float32, device=self.dev)
+        dInfo = torch.empty((1, 8), dtype=torch.float32, device=self.dev)
+        ks = solver.launch_stream
+        for i in range(3):
+            solver.solve_device(dP[i:i + 1], dX0[i:i + 1], dX, dInfo)
+        torch.cuda.synchronize()
+        ms, its = [], []
+        for i in range(n):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(ks)
+            solver.solve_device(dP[i:i + 1], dX0[i:i + 1], dX, dInfo)
+            e1.record(ks)
+            torch.cuda.synchronize()
+            ms.append(e0.elapsed_time(e1))
+            its.append(float(dInfo[0, 0].item()))
+        ms = np.array(ms)
+        return {"workload": f"B=1: one config-2 problem per launch, {n} different problems", "p50_ms": round(float(np.median(ms)), 4),
+                "p90_ms": round(float(np.quantile(ms, 0.9)), 4), "iterations_mean": round(float(np.mean(its)), 2),
+                "ms_per_iteration": round(float(ms.sum() / np.sum(its)), 4)}
+
+
+# ---- the CPU leg: the only place the oracle (test infrastructure) is used, as baseline and as checker ------------
 def cpu_baseline(cfg, P32, X032, tol, mu_min, sample):
-    """oracle/ipm_ref.c (float64 port of the same algorithm) on the host cores, OpenMP over a
-    bounded sample of the same workload."""
+    """oracle/ipm_ref.c (float64 port of the same algorithm) on the host cores, OpenMP over a bounded sample of the
+    same workload.  This is the CPU restatement baseline, NOT IPOPT+MUMPS (absent from the image)."""
     from oracle import oracle_lib as ol, problem_nlp
     # the box's CPU share for one GPU is 16 cores; never more threads than the affinity mask allows
     cores = min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
@@ -37,131 +277,108 @@ def cpu_baseline(cfg, P32, X032, tol, mu_min, sample):
     t = time.perf_counter()
     _, info = ol.ref_solve_batch(oc, P, X0, ol.ipm_opts(tol=tol, mu_min=mu_min, max_iter=60), nthreads=cores)
     dt = time.perf_counter() - t
+    # single-thread latency of one solve (p50 over 32 problems)
+    lat = []
+    for b in range(min(32, P.shape[0])):
+        t1 = time.perf_counter()
+        ol.ref_solve_batch(oc, P[b:b + 1], X0[b:b + 1], ol.ipm_opts(tol=tol, mu_min=mu_min, max_iter=60), nthreads=1)
+        lat.append((time.perf_counter() - t1) * 1e3)
     return {"value": round(sample / dt, 1), "unit": "solves/s", "cores": cores, "kind": "port",
+            "label": "CPU restatement baseline (oracle/ipm_ref.c, float64 Riccati interior point), not IPOPT+MUMPS",
+            "p50_solve_latency_ms_1thread": round(float(np.median(lat)), 3),
             "sample": f"{sample} problems of the same workload, float64, OpenMP x{cores}, {dt:.1f} s wall, "
                       f"{int((info[:, 5] == 0).sum())}/{sample} converged, mean {info[:, 0].mean():.1f} iterations"}
 
 
+def parity_sample(data, n=64):
+    """Worst relative error of the GPU result on the first n problems against the float64 oracle converged to 1e-9
+    (checker only; part of the CPU leg)."""
+    from oracle import oracle_lib as ol, problem_nlp
+    from tests import parity
+    cfg = data["cfg"]
+    n = min(n, data["P32"].shape[0])
+    cores = min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
+    Xr, infr = ol.ref_solve_batch(problem_nlp.oracle_cfg(cfg), data["P32"][:n].astype(np.float64), data["X032"][:n].astype(np.float64),
+                                  ol.ipm_opts(tol=1e-9, mu_min=1e-10), nthreads=cores)
+    worst = {}
+    for b in range(n):
+        if infr[b, 5] != 0:
+            continue
+        for k, v in parity.errors(cfg.N, data["P32"][b], data["X"][b], Xr[b]).items():
+            worst[k] = max(worst.get(k, 0.0), v)
+    return {"problems": n, "oracle_converged": int((infr[:, 5] == 0).sum()),
+            "worst_rel_err": {k: float(f"{v:.3g}") for k, v in worst.items()},
+            "note": "com/force0/forces/dcom relative (max-norm), pos/h absolute; tolerance 1e-4 on com and forces"}
+
+
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=256, help="problems per GPU (config 2: 256)")
-    ap.add_argument("--workload", default="config2", choices=["config2", "config3"])
-    ap.add_argument("--cpu-sample", type=int, default=6144)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--force-collective", action="store_true", help="run the all-gather path with one rank too (rehearsal on a single GPU)")
-    args = ap.parse_args()
+    args = parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        launch_ranks(args)      # does not return
+    R = Runner(args)
+    sec_names = [s for s in args.secondary.split(",") if s and s != "none" and s != args.workload]
+    m, data = R.run(args.workload, args.steps, args.warmup, args.batch)
+    secondary = {}
+    sec_data = {}
+    for s in sec_names:
+        if s == "latency":
+            if R.rank == 0:
+                secondary["single_problem_latency"] = R.latency()
+            continue
+        sm, sd = R.run(s, args.secondary_steps, 2)
+        secondary[s] = sm
+        if R.rank == 0 and R.world == 1 and not args.no_cpu_baseline:
+            sec_data[s] = {k: (v[:64] if isinstance(v, np.ndarray) and v.ndim == 2 else v) for k, v in sd.items()}
+        del sd
 
-    import torch
-    import cmpc_amd as cm
-
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    assert world == args.gpus, f"WORLD_SIZE {world} != --gpus {args.gpus}"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    coll = world > 1 or args.force_collective
-    if coll:
-        import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
-
-    B = args.batch
-    gen = cm.synthetic.config2_perturbed_com if args.workload == "config2" else cm.synthetic.config3_external_push
-    cfg, P, X0 = gen(B, seed=(0 if args.workload == "config2" else 1) + 1000 * rank)
-    P32, X032 = P.astype(np.float32), X0.astype(np.float32)
-    solver = cm.BatchSolver(cfg, B, device=local_rank)
-    dP, dX0 = torch.from_numpy(P32).to(dev), torch.from_numpy(X032).to(dev)
-    dX = torch.empty_like(dX0)
-    dInfo = torch.empty((B, 8), dtype=torch.float32, device=dev)
-    # N > 1: one kernel packs the compact record of every problem, one RCCL all-gather shares it (preallocated buffers)
-    W = 3 * (cfg.N + 1) + 38
-    cbuf = torch.empty((B, W), dtype=torch.float32, device=dev) if coll else None
-    gbuf = torch.empty((world * B, W), dtype=torch.float32, device=dev) if coll else None
-
-    def gather():
-        return cm.distributed.all_gather_solutions(solver.compact_output_device(dX, dInfo, cbuf), world, out=gbuf, force=True)
-
-    def step():
-        solver.solve_device(dP, dX0, dX, dInfo)
-        return gather() if coll else None
-
-    def barrier():
-        if coll:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2 * args.steps)]
-    ks = solver.launch_stream       # the HIP stream the solve kernel is launched on
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        ev[2 * i].record(ks)
-        solver.solve_device(dP, dX0, dX, dInfo)
-        ev[2 * i + 1].record(ks)
-        if coll:
-            gather()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    kern_ms = np.array([ev[2 * i].elapsed_time(ev[2 * i + 1]) for i in range(args.steps)])
-    info = dInfo.cpu().numpy()
-    ag_ms = None
-    if coll:  # packing + collective alone, for the record
-        barrier()
-        t1 = time.perf_counter()
-        for _ in range(10):
-            gather()
-        barrier()
-        ag_ms = (time.perf_counter() - t1) / 10 * 1e3
-
-    if rank == 0:
-        total = world * B * args.steps
-        iters = info[:, 0]
-        traffic = None   # HBM bytes per launch from the committed PMC passes (profiles/), same command
+    if R.rank == 0:
+        traffic, tsrc = None, None   # HBM bytes per launch from the committed PMC passes (profiles/), same command
         try:
             import glob
             pm = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))
-            if pm and args.workload == "config2" and B == 256:
+            if pm and args.workload == "config2" and m["batch_per_gpu"] == 256:
                 traffic = json.load(open(pm[-1]))["hbm_bytes_per_launch"]
+                tsrc = os.path.relpath(pm[-1], ROOT)
         except Exception:
             traffic = None
-        flop_per_launch = float(iters.sum()) * F_ITER_PER_STAGE * cfg.N
-        achieved = flop_per_launch / (kern_ms.mean() * 1e-3) / 1e12
+        m["roofline"]["traffic"] = traffic
+        m["roofline"]["traffic_source"] = (f"{tsrc} (rocprofv3 --pmc passes of this command, committed; not measured in this run)"
+                                           if tsrc else None)
+        m["roofline"]["note"] = ("bound = f32 VALU issue (the kernel contains no MFMA instruction; f32-input MFMA peak equals the "
+                                 "vector peak, 157.3 TFLOP/s); flop = executed IP iterations x 4.25e5*N (SURVEY 8d canonical "
+                                 "count); HBM traffic is ~11 KB/solve")
         out = {
             "metric": "centroidal-MPC solves/sec (batch, horizon=20)",
-            "value": round(total / elapsed, 1), "unit": "solves/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "value": m["value"], "unit": "solves/s",
+            "n_gpus": R.world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": m["ms_per_step"],
+            "higher_is_better": True, "scaling": m["scaling"], "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.workload}: batch={B}/GPU perturbed iCub/ergoCub problems, ergoCubGazeboV1 "
-                                   f"parameters, horizon={cfg.N}, dt={cfg.sampling_time}, cold start, converged to 1e-6",
-                       "batch_per_gpu": B, "horizon": cfg.N, "precision": "f32 storage+factorisation, f64 residuals"},
-            "p50_solve_latency_ms": round(float(np.median(kern_ms)), 4),
-            "iterations_mean": round(float(iters.mean()), 2), "iterations_max": int(iters.max()),
-            "converged_fraction": round(float((info[:, 5] == 0).mean()), 4),
-            "roofline": {"bound": "mfma", "achieved": round(achieved, 4), "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_F32_TFLOPS, 5), "traffic": traffic,
-                         "kernel": "cmpc_solve_kernel", "kernel_ms_avg": round(float(kern_ms.mean()), 4),
-                         "algorithmic_flop_per_launch": flop_per_launch,
-                         "note": "f32 vector peak == f32-input MFMA peak (157.3 TFLOP/s); flop = executed IP iterations x "
-                                 "4.25e5*N (SURVEY 8d canonical count); HBM traffic is ~11 KB/solve (see profiles/)"},
+            "config": {"workload": m["workload"], "batch_per_gpu": m["batch_per_gpu"], "batch_total": m["batch_total"],
+                       "horizon": m["horizon"], "precision": "f32 storage+factorisation, f64 residuals"},
+            "p50_solve_latency_ms": round(float(np.median(data["kern_ms"])), 4),
+            "iterations_mean": m["iterations_mean"], "iterations_max": m["iterations_max"],
+            "converged_fraction": m["converged_fraction"],
+            "kernel_ms_per_rank": m["kernel_ms_per_rank"],
+            "roofline": m["roofline"],
         }
-        if ag_ms is not None:
-            out["allgather_ms"] = round(ag_ms, 4)
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(cfg, P32, X032, 1e-6, 5e-8, args.cpu_sample)
+        if R.coll:
+            out["ranks"] = R.world
+            out["collective_backend"] = "rccl" if R.backend == "nccl" else R.backend
+            out["allgather_ms"] = m.get("allgather_ms")
+        if args.share_gpu and R.backend == "gloo":
+            out["rehearsal"] = f"{R.world} ranks sharing {R.torch.cuda.device_count()} GPU(s), gloo collective: functional check, not a scaling number"
+        if R.world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(data["cfg"], data["P32"], data["X032"], 1e-6, 5e-8, args.cpu_sample)
+            out["parity_sample"] = parity_sample(data)
+            for s, sd in sec_data.items():
+                secondary[s]["parity_sample"] = parity_sample(sd)
+        if secondary:
+            out["secondary"] = secondary
         print(json.dumps(out), flush=True)
-    if coll:
-        dist.destroy_process_group()
+    if R.coll:
+        R.barrier()
+        R.dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -62,13 +62,19 @@ typedef struct {
                                * initial infeasibility ep0: clamp(3.5 ep0^2, 0.03, 0.5)           */
     double mu_min;            /* final barrier parameter (default 0.05 x tolerance = 5e-8)        */
     int exact_hessian;        /* 1 (default): Lagrangian Hessian; 0: Gauss-Newton                 */
-    int final_extrapolation;  /* 1: finish with one extra affine-scaling step towards mu = 0 (default 0) */
+    int final_extrapolation;  /* 1 (default): a converged solve finishes with one affine-scaling Newton step towards
+                               * mu = 0 (one more factorisation): removes the O(mu) bias of the barrier floor and
+                               * the remaining termination error -- worst parity error of 1024 problems 8.7e-5 ->
+                               * 1.7e-5 (config 2) for +0.8 iteration; 0: stop at the barrier floor */
 } cmpc_config;
 
 /* number of floats per solve in the info array */
 #define CMPC_INFO 8
-/* info[b] = { iterations, kkt_error, mu, gauss_newton_fallbacks, primal_inf, status(0 ok,1 max
- * iter,2 factorisation failed), solve_cycles (shader clock), stationarity residual } */
+/* info[b] = { iterations, kkt_error = max(primal_inf, max t*z), mu, gauss_newton_fallbacks, primal_inf,
+ * status (0 ok, 1 iteration budget exhausted, 2 factorisation failed), solve_cycles (shader clock),
+ * last_step (max-norm of the last Newton step taken inside the loop, forces relative to the largest force) }.
+ * kkt_error, mu and primal_inf are those of the last iterate whose residuals were evaluated: the iterate the
+ * termination test accepted.  With final_extrapolation the returned x is one affine-scaling step beyond it. */
 
 void cmpc_default_config(cmpc_config* cfg);                      /* ergoCubGazeboV1 values, N=20 */
 int cmpc_dims(int horizon, int* n_x, int* n_p, int* n_g, int* nnz_jac, int* nnz_hess);

@@ -85,7 +85,7 @@ void cmpc_default_config(cmpc_config* c)
     c->mu_init = 0.0;  // <= 0: chosen per problem from its initial infeasibility
     c->mu_min = 5e-8;
     c->exact_hessian = 1;
-    c->final_extrapolation = 0;
+    c->final_extrapolation = 1;
 }
 
 int cmpc_dims(int N, int* nx, int* np, int* ng, int* nnzj, int* nnzh)

@@ -89,7 +89,7 @@ struct Ctx {
     float *dS, *dU, *dT, *dZ, *d;
     float *Lf;             // per-stage factor records (REC_N floats each)
     float *geoA;           // N x GEO
-    float *P0, *P1, *G, *QuuF, *Pan, *Bval, *Aval, *arow, *ybuf, *fpv, *fpn;
+    float *P0, *Qb, *G, *QuuF, *Pan, *Bval, *Aval, *arow, *ybuf, *fpv, *fpn;
     int *Brow, *Arow, *qmask;
     unsigned short* tri;
     double *QuuD, *pv, *pn, *qs, *Pd, *sig, *gco, *redd;
@@ -126,7 +126,7 @@ __device__ inline void make_ctx(Ctx& c, char* smem, int N, float* fg_base)
     c.dS = fp; fp += NS * (N + 1); c.dU = fp; fp += NU * N; c.dT = fp; fp += NI * N; c.dZ = fp; fp += NI * N;
     c.d = fp; fp += NS * N;
     c.geoA = fp; fp += GEO * N;
-    c.P0 = fp; fp += NXA * PLD; c.P1 = fp; fp += NXA * PLD;
+    c.P0 = fp; fp += NXA * PLD; c.Qb = fp; fp += NS * 16;   // value function (in place); Qss of the stage in flight
     c.G = fp; fp += NXA * GLD;
     c.Bval = fp; fp += 3 * NU; c.Aval = fp; fp += 3 * NS + 3;
     c.arow = fp; fp += 96 + 12; fp += DSET_F;  // (second descriptor set)
@@ -651,9 +651,9 @@ __device__ inline void stage_desc_body(const Ctx& c, const CmpcConsts& prm, int 
             double sg = 0.0, gc = 0.0;
             if (row_active(c, k, i)) {
                 const double t = c.T[NI * k + i], z = c.Z[NI * k + i];
-                const double r = (double)row_val(c, prm, k, i, u) + t;
+                const double rv = (double)row_val(c, prm, k, i, u);
                 sg = z / t;
-                gc = (double)cmu / t + sg * r;  // complementarity target cmu (0: affine-scaling predictor)
+                gc = (double)cmu / t + sg * (rv + t);  // complementarity target cmu (0: affine-scaling predictor)
             }
             c.sig[i] = sg; c.gco[i] = gc;
             if (i < 32) {
@@ -845,7 +845,7 @@ __device__ inline void stage_pre_body(const Ctx& c, const CmpcConsts& prm, int t
 }
 
 template <int NT>
-__device__ inline void stage_qss_body(const Ctx& c, const CmpcConsts& prm, int tid, int k, const float* Pcur, float* Pnew)
+__device__ inline void stage_qss_body(const Ctx& c, const CmpcConsts& prm, int tid, int k, const float* Pcur, float* Qb)
 {
             const int t = tid - 128;
             if (t < 120) {
@@ -860,13 +860,13 @@ __device__ inline void stage_qss_body(const Ctx& c, const CmpcConsts& prm, int t
                 float v = (i == j) ? qdiag(prm, k, i) : 0.f;
                 v += ai0 * (aj0 * P0r[c0] + aj1 * P0r[c1] + aj2 * P0r[c2]) + ai1 * (aj0 * P1r[c0] + aj1 * P1r[c1] + aj2 * P1r[c2])
                      + ai2 * (aj0 * P2r[c0] + aj1 * P2r[c1] + aj2 * P2r[c2]);
-                Pnew[i * PLD + j] = v;
+                Qb[i * 16 + j] = v;
             }
             if (t < NS) c.qs[t] = grad_track(c, prm, k, t) + At_vec<double>(c, prm, k, t, c.Pd);
 }
 
 template <int NT>
-__device__ inline void stage_post_body(const Ctx& c, const CmpcConsts& prm, int tid, int k, float* Pnew)
+__device__ inline void stage_post_body(const Ctx& c, const CmpcConsts& prm, int tid, int k, float* Pnew, const float* Qb)
 {
     const bool pk = k > 0;
     const float* u = c.U + NU * k;
@@ -897,7 +897,7 @@ __device__ inline void stage_post_body(const Ctx& c, const CmpcConsts& prm, int 
                 auto put = [&](int i, int j, float acc) {
                     if (j > i || i >= ncol) return;
                     float base = 0.f;
-                    if (i < NS) base = Pnew[i * PLD + j];
+                    if (i < NS) base = Qb[i * 16 + j];
                     else if (i == j) base = prm.D[(i - NS) % 3];
                     const float r = base - acc;
                     Pnew[i * PLD + j] = r;
@@ -956,19 +956,19 @@ __device__ __attribute__((noinline)) void phase_factor(lds_t lds, int Nrt, float
     stage_factor(c.QuuF, c.QuuD, c.Pan, c.Lf + (size_t)REC_N * k, prm.D[0], prm.D[1], prm.D[2], c.flag, tid, fixedmask);
 }
 template <int NT, int NC, bool FG>
-__device__ __attribute__((noinline)) void stage_pre(lds_t lds, int Nrt, float* fg_base, int k, int par, bool havep, bool use_exact, float reg, float cmu)
+__device__ __attribute__((noinline)) void stage_pre(lds_t lds, int Nrt, float* fg_base, int k, bool havep, bool use_exact, float reg, float cmu)
 {
     CMPC_PHASE_PROLOGUE;
     use_desc_set(c, k & 1);
-    stage_pre_body<NT, NC, FG>(c, prm, tid, k, par ? c.P1 : c.P0, havep, use_exact, reg, cmu);
+    stage_pre_body<NT, NC, FG>(c, prm, tid, k, c.P0, havep, use_exact, reg, cmu);
 }
 // waves 2-3 (t = tid - 128) while waves 0-1 factorise stage k: Qss and qs of stage k, then the descriptors of stage k-1
 template <int NT, int NC, bool FG>
-__device__ __attribute__((noinline)) void stage_qss(lds_t lds, int Nrt, float* fg_base, int k, int par, bool use_exact, float cmu)
+__device__ __attribute__((noinline)) void stage_qss(lds_t lds, int Nrt, float* fg_base, int k, bool use_exact, float cmu)
 {
     CMPC_PHASE_PROLOGUE;
     use_desc_set(c, k & 1);
-    stage_qss_body<NT>(c, prm, tid, k, par ? c.P1 : c.P0, par ? c.P0 : c.P1);
+    stage_qss_body<NT>(c, prm, tid, k, c.P0, c.Qb);
     if (k > 0) {
         use_desc_set(c, ((k - 1) & 1) - (k & 1));
         stage_desc_body(c, prm, tid - 128, k - 1, use_exact, cmu);
@@ -982,10 +982,10 @@ __device__ __attribute__((noinline)) void stage_desc(lds_t lds, int Nrt, float* 
     stage_desc_body(c, prm, tid - 128, k, use_exact, cmu);
 }
 template <int NT, int NC, bool FG>
-__device__ __attribute__((noinline)) void stage_post(lds_t lds, int Nrt, float* fg_base, int k, int par)
+__device__ __attribute__((noinline)) void stage_post(lds_t lds, int Nrt, float* fg_base, int k)
 {
     CMPC_PHASE_PROLOGUE;
-    stage_post_body<NT>(c, prm, tid, k, par ? c.P0 : c.P1);
+    stage_post_body<NT>(c, prm, tid, k, c.P0, c.Qb);
 }
 
 // ---- Riccati backward sweep (matrices + right-hand side of the affine step, or of a centring step with target
@@ -1003,17 +1003,16 @@ __device__ int riccati_backward(lds_t lds, const Ctx& c, const CmpcConsts& prm, 
     } else if (tid < NXA) c.pv[tid] = 0.0;
     if (tid >= 128) stage_desc<NT, NC, FG>(lds, N, fg_base, N - 1, use_exact, cmu);
     __syncthreads();
-    int par = 0;  // P0 holds the value function of stage k+1
+    // P0 holds the value function of stage k+1 and is overwritten in place by phase 4 (its last reader, Qss, ran in phase 3)
     for (int k = N - 1; k >= 0; --k) {
-        stage_pre<NT, NC, FG>(lds, N, fg_base, k, par, k < N - 1, use_exact, reg, cmu);
+        stage_pre<NT, NC, FG>(lds, N, fg_base, k, k < N - 1, use_exact, reg, cmu);
         PROF_DECL;
         if (tid < 128) phase_factor<NC, FG>(lds, N, fg_base, k);
-        else stage_qss<NT, NC, FG>(lds, N, fg_base, k, par, use_exact, cmu);
+        else stage_qss<NT, NC, FG>(lds, N, fg_base, k, use_exact, cmu);
         __syncthreads();
         PROF(3);
         if (*c.flag) return 1;
-        stage_post<NT, NC, FG>(lds, N, fg_base, k, par);
-        par ^= 1;
+        stage_post<NT, NC, FG>(lds, N, fg_base, k);
     }
     return 0;
 }
@@ -1358,8 +1357,8 @@ template <int NT, int NC, bool FG>
 __global__ __launch_bounds__(NT, FG ? 2 : 1) void cmpc_solve_kernel(CmpcParams kp)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x;
     const int b = blockIdx.x;
+    const int tid = threadIdx.x;
     const int N = NC > 0 ? NC : kp.N;
     // The whole LDS image starts at zero.  LDS arrives with whatever the previous workgroup -- or the previous
     // kernel -- left in it, and several formulas read entries under a zero weight (the E^T P rows of G before the
@@ -1524,7 +1523,7 @@ __global__ __launch_bounds__(NT, FG ? 2 : 1) void cmpc_solve_kernel(CmpcParams k
             ++gn; exact = false;
             if (attempt > 0) reg *= 1e3f;
         }
-        if (fail) { status = 2; break; }
+        if (fail) { if (!finishing) status = 2; break; }   // (a failed extrapolation step leaves the converged iterate)
         PROF(11);
         float ap, ad, sigma = 0.f, mu_t = prm.mu_min;
         if (centring) {
@@ -1639,6 +1638,10 @@ __global__ __launch_bounds__(NT, FG ? 2 : 1) void cmpc_solve_kernel(CmpcParams k
             inf[0] = (float)it; inf[1] = err; inf[2] = mu_cur; inf[3] = (float)gn; inf[4] = ep; inf[5] = (float)status;
             inf[6] = (float)(__builtin_amdgcn_s_memtime() - t_start); inf[7] = step_out;
         }
+        if (prm.dev[2] != 0.f) {  // developer probe: where the hardware put each wave (overwrites x[0..3]; HW_ID: wave slot
+            __syncthreads();      // [3:0], SIMD [5:4], CU [11:8], SH [12], SE [15:13])
+            if ((threadIdx.x & 63) == 0) x[threadIdx.x >> 6] = (float)(__builtin_amdgcn_s_getreg((31 << 11) | 4) & 0xffff);
+        }
     }
 }
 
@@ -1653,7 +1656,7 @@ extern "C" size_t cmpc_solver_lds_bytes(int N, int factors_global)
     const size_t dbl = nlam + 90 + 40 + 40 + 16 + 40 + 4 * NI + 8;
     const size_t flt = (size_t)NU * RLD + (size_t)NPAN * RLD + 96 + ((L.np + 3) & ~3)
                        + 2 * ((size_t)NS * (N + 1) + (size_t)NU * N + 2 * (size_t)NI * N) + (size_t)NS * N
-                       + (size_t)GEO * N + 2 * NXA * PLD + NXA * GLD + 2 * DSET_F + 40 + 40 + 8
+                       + (size_t)GEO * N + NXA * PLD + NS * 16 + NXA * GLD + 2 * DSET_F + 40 + 40 + 8
                        + 2 * DSET_I + 4 + CMPC_NMAX + NTRI / 2 + (factors_global ? 0 : (size_t)REC_N * N);
     return ((sizeof(CmpcConsts) + 15) & ~(size_t)15) + dbl * 8 + flt * 4;
 }

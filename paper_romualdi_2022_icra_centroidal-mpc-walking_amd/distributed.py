@@ -37,15 +37,37 @@ def compact_output(X, info, cols):
     return torch.cat([X.index_select(1, cols), info[:, [0, 5]]], dim=1)
 
 
-def all_gather_solutions(local, world: int, out=None, force: bool = False):
-    """Gathers the per-rank compact outputs [B_r, W] into [sum B_r, W] on every rank (equal shard
-    sizes; torch.distributed must be initialised when world > 1).  `out`: a preallocated result
-    (steady-state loops); `force` runs the collective for one rank too (rehearsal on a single GPU)."""
+def all_gather_solutions(local, world: int, out=None, force: bool = False, counts=None):
+    """Gathers the per-rank compact outputs [B_r, W] into [sum B_r, W] on every rank (torch.distributed must be
+    initialised when world > 1).  Equal shards: one all_gather_into_tensor straight into `out` (a preallocated
+    result for steady-state loops).  `counts` (problems per rank, from shard_bounds) allows ragged shards: every
+    rank pads to the largest shard and the padding is dropped after the collective.  `force` runs the collective
+    for one rank too (rehearsal on a single GPU).  On the `gloo` backend (CPU tests, --share-gpu rehearsals)
+    device tensors are staged through the host."""
     if world == 1 and not force:
         return local
     import torch
     import torch.distributed as dist
+    total = int(sum(counts)) if counts is not None else world * local.shape[0]
     if out is None:
-        out = torch.empty((world * local.shape[0], local.shape[1]), dtype=local.dtype, device=local.device)
-    dist.all_gather_into_tensor(out, local.contiguous())
+        out = torch.empty((total, local.shape[1]), dtype=local.dtype, device=local.device)
+    staged = local.is_cuda and dist.get_backend() == "gloo"
+    src = local.contiguous().cpu() if staged else local.contiguous()
+    if counts is None or len(set(int(c) for c in counts)) == 1:
+        if staged:
+            tmp = torch.empty((total, local.shape[1]), dtype=local.dtype)
+            dist.all_gather_into_tensor(tmp, src)
+            out.copy_(tmp)
+        else:
+            dist.all_gather_into_tensor(out, src)
+        return out
+    mx = int(max(counts))
+    pad = torch.zeros((mx, local.shape[1]), dtype=src.dtype, device=src.device)
+    pad[:src.shape[0]] = src
+    parts = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(parts, pad)
+    o = 0
+    for r, c in enumerate(counts):
+        out[o:o + int(c)] = parts[r][:int(c)].to(out.device)
+        o += int(c)
     return out

@@ -21,7 +21,7 @@ from .layout import Layout
 
 
 def _c_config(cfg: CentroidalMPCConfig, tolerance=None, mu_min=None, max_iterations=None,
-              exact_hessian=True, final_extrapolation=False, step_tolerance=None, mu_init=None) -> _capi.CmpcConfig:
+              exact_hessian=True, final_extrapolation=True, step_tolerance=None, mu_init=None) -> _capi.CmpcConfig:
     c = _capi.CmpcConfig()
     c.horizon = cfg.N
     c.sampling_time = cfg.sampling_time

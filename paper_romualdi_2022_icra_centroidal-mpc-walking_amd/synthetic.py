@@ -67,24 +67,31 @@ def _walking_lists(cfg, swing_start, swing_len, step=0.1):
     return {cfg.contacts[0].contact_name: left, cfg.contacts[1].contact_name: right}
 
 
-def config3_external_push(B=4096, N=20, seed=1):
+def config3_external_push(B=4096, N=20, seed=1, shard=None):
     """Walking schedule with a swing phase inside the horizon (left Gamma = 1x6, 0x8, 1x6) so the
-    step adjustment is active, plus an external push U(-50,50) N in x,y over the first 0.2 s."""
+    step adjustment is active, plus an external push U(-50,50) N in x,y over the first 0.2 s.
+    shard=(lo, hi): only problems [lo, hi) of the B-problem batch are built (the random draws are those
+    of the whole batch, so a shard equals the same rows of the unsharded batch bit for bit)."""
     cfg = _cfg.ergocub_gazebo_v1(N, 0.06)
     rng = np.random.default_rng(seed)
-    sched = _tile(sample_schedule(cfg, _walking_lists(cfg, 6, 8)), B)
     com0, dcom0, h0 = _perturbed_state(rng, B, (0.0, 0.0, 0.7))
+    push = rng.uniform(-50.0, 50.0, (B, 2)) / ROBOT_MASS
+    if shard is not None:
+        lo, hi = shard
+        com0, dcom0, h0, push = com0[lo:hi], dcom0[lo:hi], h0[lo:hi], push[lo:hi]
+        B = hi - lo
+    sched = _tile(sample_schedule(cfg, _walking_lists(cfg, 6, 8)), B)
     ref = np.broadcast_to(np.array([0.0, 0.0, 0.7]), (B, N + 1, 3)).copy()
     f_ext = np.zeros((B, N, 3))
     nk = int(np.ceil(0.2 / cfg.sampling_time))
-    push = rng.uniform(-50.0, 50.0, (B, 2)) / ROBOT_MASS
     f_ext[:, :nk, :2] = push[:, None, :]
     return _finish(cfg, sched, com0, dcom0, h0, ref, np.zeros((B, N + 1, 3)), f_ext)
 
 
-def config4_monte_carlo(B=65536, N=20, seed=2):
-    """Config-3 generator with seed 2 (sharded 8 x 8192 by bench.py --gpus 8)."""
-    return config3_external_push(B, N, seed)
+def config4_monte_carlo(B=65536, N=20, seed=2, shard=None):
+    """Config-3 generator with seed 2; `shard=(lo, hi)` builds one rank's contiguous shard (8 x 8192 with
+    distributed.shard_bounds at 8 GPUs)."""
+    return config3_external_push(B, N, seed, shard)
 
 
 def config5_footstep_candidates(B=8192, N=30, seed=3):
