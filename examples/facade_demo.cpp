@@ -1,16 +1,18 @@
-// Links the drop-in class (include/BipedalLocomotion/ReducedModelControllers/CentroidalMPC.h) against
-// libcmpc_hip.so and runs one MPC tick the way CentroidalMPCBlock does.  Prints the first-knot
-// vertical force per foot and the adjusted next footstep.  Build (tests/test_gpu_facade.py does this):
+// Links the drop-in class (include/BipedalLocomotion/ReducedModelControllers/CentroidalMPC.h) against libcmpc_hip.so
+// and runs a short walk the way the reference's block drives it (the Block of csrc/facade_check.cpp: setInput ->
+// setState, then setReferenceTrajectory / updateContactPhaseList / setContactPhaseList / advance / getOutput, clock
+// += dT), 12 ticks across a lift-off, with the class's own static merge cross-checked against the block's function.
+// Build (tests/test_gpu_facade.py does this):
 //   g++ -std=c++17 -I include -I <pkg>/csrc/shim examples/facade_demo.cpp -L <pkg> -lcmpc_hip -Wl,-rpath,<pkg>
-#include <BipedalLocomotion/ReducedModelControllers/CentroidalMPC.h>
+#define CMPC_FACADE_DEMO
+#include "../paper_romualdi_2022_icra_centroidal-mpc-walking_amd/csrc/facade_check.cpp"
 
 #include <cstdio>
 #include <map>
 
-namespace blf = BipedalLocomotion;
 using blf::ParametersHandler::IParametersHandler;
 
-struct MapHandler : IParametersHandler, std::enable_shared_from_this<MapHandler> {
+struct MapHandler : IParametersHandler {
     std::map<std::string, double> d;
     std::map<std::string, std::string> s;
     std::map<std::string, std::vector<double>> v;
@@ -41,39 +43,60 @@ int main()
                 {"bounding_box_lower_limit", i == 0 ? std::vector<double>{-0.01, 0.0, 0} : std::vector<double>{-0.01, -0.05, 0}}};
         h->g["CONTACT_" + std::to_string(i)] = c;
     }
-    blf::ReducedModelControllers::CentroidalMPC mpc;
-    if (!mpc.initialize(h)) return 1;
+    Block block;
+    if (!block.initialize(h)) return 1;
 
+    // the planner's list: the left foot lifts at 0.36 s and lands 0.1 m ahead at 0.84 s; absolute times from zero
     using namespace std::chrono_literals;
     blf::Contacts::ContactListMap lists;
     blf::Contacts::PlannedContact c;
-    c.name = "left_foot"; c.pose.p = Eigen::Vector3d(0, 0.08, 0); c.activationTime = -1s; c.deactivationTime = 360ms;
+    c.name = "left_foot"; c.pose = manif::SE3d(Eigen::Vector3d(0, 0.08, 0), Eigen::Quaterniond(1, 0, 0, 0)); c.activationTime = 0s; c.deactivationTime = 360ms;
     lists["left_foot"].addContact(c);
-    c.pose.p = Eigen::Vector3d(0.1, 0.08, 0); c.activationTime = 840ms; c.deactivationTime = 100s;
+    c.pose = manif::SE3d(Eigen::Vector3d(0.1, 0.08, 0), Eigen::Quaterniond(1, 0, 0, 0)); c.activationTime = 840ms; c.deactivationTime = 100s;
     lists["left_foot"].addContact(c);
-    c.name = "right_foot"; c.pose.p = Eigen::Vector3d(0, -0.08, 0); c.activationTime = -1s; c.deactivationTime = 100s;
+    c.name = "right_foot"; c.pose = manif::SE3d(Eigen::Vector3d(0, -0.08, 0), Eigen::Quaterniond(1, 0, 0, 0)); c.activationTime = 0s; c.deactivationTime = 100s;
     lists["right_foot"].addContact(c);
-    blf::Contacts::ContactPhaseList list;
-    list.setLists(lists);
+    blf::Contacts::ContactPhaseList mann;
+    mann.setLists(lists);
 
     Eigen::Vector3d com(0.01, -0.005, 0.69), dcom(0.02, 0, 0), ang;
     blf::Math::Wrenchd w;
-    std::vector<Eigen::Vector3d> comRef(21, Eigen::Vector3d(0, 0, 0.7)), hRef(21);
-    for (int tick = 0; tick < 2; ++tick) {  // second tick exercises the warm start
-        if (!mpc.setState(com, dcom, ang, w) || !mpc.setReferenceTrajectory(comRef, hRef) || !mpc.setContactPhaseList(list) || !mpc.advance()) {
-            std::fprintf(stderr, "tick failed: %s\n", mpc.lastError().c_str());
+    std::vector<Eigen::Vector3d> comRef(21, Eigen::Vector3d(0.03, -0.02, 0.7)), hRef(21);
+    double fz = 0;
+    for (int tick = 0; tick < 12; ++tick) {
+        if (tick > 0) {  // the class's own merge must rebuild what the block's function builds
+            blf::Contacts::ContactPhaseList a, b;
+            const bool ra = updateContactPhaseList(block.m_absoluteTime, mann, block.m_controller.getOutput().contactPhaseList, a);
+            const bool rb = blf::ReducedModelControllers::CentroidalMPC::mergeContactPhaseLists(block.m_absoluteTime, mann, block.m_controller.getOutput().contactPhaseList, b);
+            if (ra != rb) { std::fprintf(stderr, "merge mismatch (return) at tick %d\n", tick); return 3; }
+            for (const auto& [name, la] : a.lists()) {
+                const auto& lb = b.lists().at(name);
+                if (la.size() != lb.size()) { std::fprintf(stderr, "merge mismatch (size) at tick %d\n", tick); return 3; }
+                auto ib = lb.cbegin();
+                for (auto ia = la.cbegin(); ia != la.cend(); ++ia, ++ib)
+                    if (ia->activationTime != ib->activationTime || ia->deactivationTime != ib->deactivationTime
+                        || std::fabs(ia->pose.translation()[0] - ib->pose.translation()[0]) > 1e-6
+                        || std::fabs(ia->pose.translation()[1] - ib->pose.translation()[1]) > 1e-6) { std::fprintf(stderr, "merge mismatch at tick %d\n", tick); return 3; }
+            }
+        }
+        if (!block.setInput(com, dcom, ang, w) || !block.advance(comRef, hRef, mann)) {
+            std::fprintf(stderr, "tick %d failed: %s\n", tick, block.m_controller.lastError().c_str());
             return 2;
         }
+        // feed the first predicted state back as the next measurement (a stand-in for the whole-body loop)
+        const auto& out = block.m_output;
+        com = out.comTrajectory[1];
+        fz = 0;
+        int ncontacts = 0;
+        for (const auto& [name, contact] : out.contacts) {
+            ++ncontacts;
+            for (const auto& corner : contact.corners) fz += corner.force[2];
+        }
+        std::printf("tick %d contacts %d total_fz %.6f com %.5f %.5f %.5f\n", tick, ncontacts, fz, com[0], com[1], com[2]);
     }
-    const auto& out = mpc.getOutput();
-    double fz = 0;
-    for (const auto& [name, contact] : out.contacts) {
-        double f = 0;
-        for (const auto& corner : contact.corners) f += corner.force[2];
-        std::printf("contact %s fz %.6f\n", name.c_str(), f);
-        fz += f;
-    }
-    const auto& next = *(out.contactPhaseList.lists().at("left_foot").cbegin() + 1);
-    std::printf("total_fz %.6f\nnext_left %.6f %.6f %.6f\n", fz, next.pose.translation()[0], next.pose.translation()[1], next.pose.translation()[2]);
+    const auto& ll = block.m_controller.getOutput().contactPhaseList.lists().at("left_foot");
+    const auto next = ll.getNextContact(block.m_absoluteTime - block.m_dT);
+    if (next == ll.cend()) { std::fprintf(stderr, "no next contact in the adjusted list\n"); return 4; }
+    std::printf("total_fz %.6f\nnext_left %.6f %.6f %.6f\nticks 12\n", fz, next->pose.translation()[0], next->pose.translation()[1], next->pose.translation()[2]);
     return 0;
 }

@@ -4,23 +4,28 @@
 // names, argument meaning and bool-return / no-exception error convention, implemented as a batch = 1
 // facade over the C ABI of libcmpc_hip.so (include/cmpc.h).  Header-only; link with -lcmpc_hip.
 //
-// With the real Eigen/BLF headers on the include path define CMPC_USE_REAL_BLF_HEADERS before including
-// this file; otherwise the shim types of csrc/shim/BipedalLocomotion/ShimTypes.h are used (the build
-// image has neither Eigen nor BLF, so "links unchanged" is asserted by signature, not by linking).
+// It uses only the Eigen / manif / BLF calls the reference itself makes (pose.translation(), pose.rotation(),
+// pose.quat(), manif::SE3d(translation, quat), ContactList::addContact / getActiveContact / getNextContact /
+// cbegin / cend, ContactPhaseList::lists / setLists; CentroidalMPCBlock.cpp:41-107, :345, :362-363).  The build
+// image has none of those libraries: csrc/shim/ holds stand-in headers at the same include paths that declare
+// exactly those members, so this header is compiled and run against them unchanged (no switch, no #ifdef).
+//
+// Time: the reference never tells the controller the time; its block passes absolute-time contact lists and
+// advances its own clock by the sampling time per tick (CentroidalMPCBlock.cpp:631).  The class does the same:
+// its clock starts at zero and advances by dt after every successful advance().
 #pragma once
 
-#ifdef CMPC_USE_REAL_BLF_HEADERS
 #include <Eigen/Dense>
+#include <manif/manif.h>
+
 #include <BipedalLocomotion/Contacts/ContactPhaseList.h>
 #include <BipedalLocomotion/Math/Wrench.h>
 #include <BipedalLocomotion/ParametersHandler/IParametersHandler.h>
-#else
-#include <BipedalLocomotion/ShimTypes.h>
-#endif
 
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <iterator>
 #include <map>
 #include <memory>
 #include <string>
@@ -113,17 +118,18 @@ public:
         return true;
     }
 
-    // com, dcom, angular momentum and wrench are mass-normalised by the caller (CentroidalMPCBlock.cpp:403-410);
-    // the wrench is held constant over the horizon
+    // com, dcom, angular momentum and wrench are mass-normalised by the caller (CentroidalMPCBlock.cpp:403-410).
+    // The measured wrench enters the first knot only, the rest of the horizon sees none (how BLF spreads it is not
+    // visible from the reference tree -- parity unpinned; a persistent push is expressed through the C ABI, which
+    // takes the wrench per knot)
     bool setState(Eigen::Ref<const Eigen::Vector3d> com, Eigen::Ref<const Eigen::Vector3d> dcom,
                   Eigen::Ref<const Eigen::Vector3d> angularMomentum, const Math::Wrenchd& externalWrench)
     {
         if (!m_h) return err("[CentroidalMPC::setState] not initialised");
         float st[9];
         for (int i = 0; i < 3; ++i) { st[i] = (float)com[i]; st[3 + i] = (float)dcom[i]; st[6 + i] = (float)angularMomentum[i]; }
-        std::vector<float> w(6 * (size_t)m_N);
-        for (int k = 0; k < m_N; ++k)
-            for (int i = 0; i < 3; ++i) { w[6 * k + i] = (float)externalWrench.force()[i]; w[6 * k + 3 + i] = (float)externalWrench.torque()[i]; }
+        std::vector<float> w(6 * (size_t)m_N, 0.f);
+        for (int i = 0; i < 3; ++i) { w[i] = (float)externalWrench.force()[i]; w[3 + i] = (float)externalWrench.torque()[i]; }
         return ok(cmpc_set_state(m_h, st, w.data()), "[CentroidalMPC::setState]");
     }
     bool setState(Eigen::Ref<const Eigen::Vector3d> com, Eigen::Ref<const Eigen::Vector3d> dcom,
@@ -144,73 +150,49 @@ public:
         return ok(cmpc_set_reference(m_h, c.data(), h.data()), "[CentroidalMPC::setReferenceTrajectory]");
     }
 
-    // samples the schedule at the MPC knots (rule: contacts.py / DESIGN.md; t = 0 is "now", i.e. the
-    // earliest time for which every foot has an active or upcoming contact is taken from m_now)
+    // samples the schedule at the MPC knots now + k dt (rule: cmpc_contacts_sample, include/cmpc.h)
     bool setContactPhaseList(const Contacts::ContactPhaseList& list)
     {
         if (!m_h) return err("[CentroidalMPC::setContactPhaseList] not initialised");
-        const int N = m_N;
-        std::vector<float> R(2 * (size_t)N * 9), up(2 * (size_t)N * 3), lo(2 * (size_t)N * 3), en(2 * (size_t)N), nom(2 * (size_t)(N + 1) * 3), cur(6);
-        m_landKnot[0] = m_landKnot[1] = -1;
-        for (int c = 0; c < 2; ++c) {
-            auto it = list.lists().find(m_names[c]);
-            if (it == list.lists().end() || it->second.size() == 0) return err("[CentroidalMPC::setContactPhaseList] no contact list for " + m_names[c]);
-            const auto& cl = it->second;
-            auto owner = [&](std::chrono::nanoseconds t, bool& active) {
-                auto a = cl.getActiveContact(t);
-                active = a != cl.cend();
-                if (active) return a;
-                auto n = cl.getNextContact(t);
-                if (n != cl.cend()) return n;
-                return cl.cend() - 1;
-            };
-            for (int k = 0; k < N; ++k) {
-                const auto t = m_now + std::chrono::nanoseconds((long long)std::llround(k * m_dt * 1e9));
-                bool act = false;
-                auto o = owner(t, act);
-                en[(size_t)c * N + k] = act ? 1.f : 0.f;
-                for (int i = 0; i < 9; ++i) R[((size_t)c * N + k) * 9 + i] = (float)o->pose.R[i];
-                for (int i = 0; i < 3; ++i) {
-                    up[((size_t)c * N + k) * 3 + i] = m_up[c][i];
-                    lo[((size_t)c * N + k) * 3 + i] = m_lo[c][i];
-                    nom[((size_t)c * (N + 1) + k + 1) * 3 + i] = (float)o->pose.translation()[i];
-                }
-                if (k == 0)
-                    for (int i = 0; i < 3; ++i) { nom[((size_t)c * (N + 1)) * 3 + i] = (float)o->pose.translation()[i]; cur[3 * c + i] = (float)o->pose.translation()[i]; }
-                if (!act && m_landKnot[c] < 0) {
-                    bool nextAct = false;
-                    if (k + 1 < N) owner(m_now + std::chrono::nanoseconds((long long)std::llround((k + 1) * m_dt * 1e9)), nextAct);
-                    if (k + 1 == N || nextAct) m_landKnot[c] = k + 1;
-                }
-            }
-        }
+        ListArrays a;
+        if (!toArrays(list, a)) return false;
         m_list = list;
-        return ok(cmpc_set_contacts(m_h, R.data(), up.data(), lo.data(), en.data(), nom.data(), cur.data()), "[CentroidalMPC::setContactPhaseList]");
+        m_arrays = a;
+        const float up[6] = {m_up[0][0], m_up[0][1], m_up[0][2], m_up[1][0], m_up[1][1], m_up[1][2]};
+        const float lo[6] = {m_lo[0][0], m_lo[0][1], m_lo[0][2], m_lo[1][0], m_lo[1][1], m_lo[1][2]};
+        return ok(cmpc_set_contact_lists(m_h, a.M, seconds(m_now), a.t.data(), a.pose.data(), a.n, up, lo, m_landKnot),
+                  "[CentroidalMPC::setContactPhaseList]");
     }
-
-    // present time of the schedule (the reference's block passes absolute-time lists, CentroidalMPCBlock.cpp:594)
-    void setCurrentTime(std::chrono::nanoseconds now) { m_now = now; }
 
     bool advance()
     {
         if (!m_h) return err("[CentroidalMPC::advance] not initialised");
         m_valid = false;
+        if (m_arrays.M == 0) return err("[CentroidalMPC::advance] setContactPhaseList has not been called");
         if (cmpc_set_initial_guess(m_h, nullptr, m_warm && m_haveSolution ? 1 : 0) != CMPC_OK) return err(cmpc_last_error(m_h));
         if (cmpc_advance(m_h) != CMPC_OK) return err(std::string("[CentroidalMPC::advance] ") + cmpc_last_error(m_h));
         m_haveSolution = true;
         float f0[24], p0[6], pn[6];
         int kn[2];
         if (cmpc_get_output(m_h, f0, p0, pn, kn) != CMPC_OK) return err(cmpc_last_error(m_h));
+        std::vector<float> x((size_t)45 * m_N + 15);
+        if (cmpc_get_solution(m_h, x.data(), nullptr) != CMPC_OK) return err(cmpc_last_error(m_h));
         m_out.contacts.clear();
-        m_out.contactPhaseList = m_list;
+        m_out.comTrajectory.resize((size_t)m_N + 1);
+        for (int k = 0; k <= m_N; ++k) m_out.comTrajectory[k] = Eigen::Vector3d(x[3 * k], x[3 * k + 1], x[3 * k + 2]);
+        // step adjustment on the arrays (cmpc_contacts_adjust), then the list is rebuilt contact by contact
+        ListArrays adj = m_arrays;
+        if (cmpc_contacts_adjust(m_N, 1, adj.M, seconds(m_now), x.data(), m_landKnot, adj.t.data(), adj.pose.data(), adj.n) != CMPC_OK)
+            return err(cmpc_last_error(nullptr));
+        Contacts::ContactListMap map;
         for (int c = 0; c < 2; ++c) {
-            auto lit = m_list.lists().find(m_names[c]);
-            auto act = lit->second.getActiveContact(m_now);
-            if (act != lit->second.cend()) {  // only active contacts are reported (WholeBodyQPBlock.cpp:824)
+            const Contacts::ContactList& cl = m_list.lists().at(m_names[c]);
+            auto act = cl.getActiveContact(m_now);
+            if (act != cl.cend()) {  // only active contacts are reported (WholeBodyQPBlock.cpp:824)
                 Contacts::DiscreteGeometryContact d;
                 d.name = m_names[c];
-                d.pose = act->pose;
-                d.pose.translation(Eigen::Vector3d(p0[3 * c], p0[3 * c + 1], p0[3 * c + 2]));
+                d.index = act->index;
+                d.pose = manif::SE3d(Eigen::Vector3d(p0[3 * c], p0[3 * c + 1], p0[3 * c + 2]), act->pose.quat());
                 d.corners.resize(4);
                 for (int j = 0; j < 4; ++j) {
                     d.corners[j].position = Eigen::Vector3d(m_cfg.corners[c][j][0], m_cfg.corners[c][j][1], m_cfg.corners[c][j][2]);
@@ -218,12 +200,18 @@ public:
                 }
                 m_out.contacts[m_names[c]] = d;
             }
-            if (kn[c] >= 0) {  // step adjustment: the next contact takes the optimised landing position
-                auto& cl = m_out.contactPhaseList.mutableLists()[m_names[c]];
-                for (std::size_t i = 0; i < cl.size(); ++i)
-                    if (cl.at(i).activationTime > m_now) { cl.at(i).pose.translation(Eigen::Vector3d(pn[3 * c], pn[3 * c + 1], pn[3 * c + 2])); break; }
+            Contacts::ContactList out;
+            int m = 0;
+            for (auto it = cl.cbegin(); it != cl.cend(); ++it, ++m) {
+                Contacts::PlannedContact pc = *it;
+                const float* q = adj.pose.data() + 7 * ((size_t)c * adj.M + m);
+                pc.pose = manif::SE3d(Eigen::Vector3d(q[0], q[1], q[2]), it->pose.quat());
+                if (!out.addContact(pc)) return err("[CentroidalMPC::advance] unable to rebuild the contact list of " + m_names[c]);
             }
+            map[m_names[c]] = out;
         }
+        if (!m_out.contactPhaseList.setLists(map)) return err("[CentroidalMPC::advance] unable to set the adjusted contact lists");
+        m_now += std::chrono::nanoseconds((long long)std::llround(m_dt * 1e9));  // the caller's clock does the same (:631)
         m_valid = true;
         return true;
     }
@@ -232,7 +220,102 @@ public:
     bool isOutputValid() const { return m_valid; }
     const std::string& lastError() const { return m_err; }
 
+    // updateContactPhaseList of the reference's block (CentroidalMPCBlock.cpp:32-110) over the C ABI
+    // (cmpc_contacts_merge): future contacts from the planner; the present contact keeps the pose the MPC gave it and
+    // takes the planner's timing.  false when the planner has no active contact under an active MPC contact (:69-77).
+    static bool mergeContactPhaseLists(const std::chrono::nanoseconds& currentTime, const Contacts::ContactPhaseList& plannerPhaseList,
+                                       const Contacts::ContactPhaseList& mpcPhaseList, Contacts::ContactPhaseList& contactPhaseList)
+    {
+        std::vector<std::string> names;
+        for (const auto& kv : plannerPhaseList.lists()) names.push_back(kv.first);
+        if (names.size() != 2) return false;
+        ListArrays p, q, o;
+        if (!toArrays(plannerPhaseList, names, p) || !toArrays(mpcPhaseList, names, q)) return false;
+        const int M = p.M > q.M ? p.M : q.M;
+        p.resize(M); q.resize(M); o.resize(M);
+        int good = 0;
+        if (cmpc_contacts_merge(1, M, seconds(currentTime), p.t.data(), p.pose.data(), p.n, q.t.data(), q.pose.data(), q.n, o.t.data(),
+                                o.pose.data(), o.n, &good) != CMPC_OK || !good)
+            return false;
+        Contacts::ContactListMap map;
+        for (int c = 0; c < 2; ++c) {
+            Contacts::ContactList out;
+            for (int m = 0; m < o.n[c]; ++m) {
+                const size_t e = (size_t)c * M + m;
+                Contacts::PlannedContact pc;
+                pc.name = names[c];
+                pc.activationTime = std::chrono::nanoseconds((long long)std::llround(o.t[2 * e] * 1e9));
+                pc.deactivationTime = o.t[2 * e + 1] >= 9e9 ? std::chrono::nanoseconds::max() : std::chrono::nanoseconds((long long)std::llround(o.t[2 * e + 1] * 1e9));
+                const float* s = o.pose.data() + 7 * e;
+                pc.pose = manif::SE3d(Eigen::Vector3d(s[0], s[1], s[2]), Eigen::Quaterniond(s[3], s[4], s[5], s[6]));
+                if (!out.addContact(pc)) return false;
+            }
+            map[names[c]] = out;
+        }
+        return contactPhaseList.setLists(map);
+    }
+
 private:
+    // a phase list as the arrays of the C ABI (include/cmpc.h, "contact schedules, batched"), batch = 1
+    struct ListArrays {
+        int M{0};
+        int n[2]{0, 0};
+        std::vector<double> t;
+        std::vector<float> pose;
+        void resize(int newM)
+        {
+            std::vector<double> nt((size_t)4 * newM, 0.0);
+            std::vector<float> np((size_t)14 * newM, 0.f);
+            for (int c = 0; c < 2; ++c)
+                for (int m = 0; m < n[c] && m < newM; ++m) {
+                    nt[2 * ((size_t)c * newM + m)] = t[2 * ((size_t)c * M + m)];
+                    nt[2 * ((size_t)c * newM + m) + 1] = t[2 * ((size_t)c * M + m) + 1];
+                    for (int i = 0; i < 7; ++i) np[7 * ((size_t)c * newM + m) + i] = pose[7 * ((size_t)c * M + m) + i];
+                }
+            t.swap(nt); pose.swap(np); M = newM;
+        }
+    };
+    static double seconds(const std::chrono::nanoseconds& t)
+    {
+        return t == std::chrono::nanoseconds::max() ? 1e10 : (double)t.count() * 1e-9;
+    }
+    static bool toArrays(const Contacts::ContactPhaseList& list, const std::vector<std::string>& names, ListArrays& a)
+    {
+        std::size_t M = 1;
+        for (const auto& nm : names) {
+            auto it = list.lists().find(nm);
+            if (it == list.lists().end()) return false;
+            if (it->second.size() > M) M = it->second.size();
+        }
+        a = ListArrays();
+        a.resize((int)M);
+        for (int c = 0; c < 2; ++c) {
+            const Contacts::ContactList& cl = list.lists().at(names[c]);
+            int m = 0;
+            for (auto it = cl.cbegin(); it != cl.cend(); ++it, ++m) {
+                const size_t e = (size_t)c * M + m;
+                a.t[2 * e] = seconds(it->activationTime);
+                a.t[2 * e + 1] = seconds(it->deactivationTime);
+                const Eigen::Vector3d p = it->pose.translation();
+                const Eigen::Quaterniond q = it->pose.quat();
+                float* s = a.pose.data() + 7 * e;
+                s[0] = (float)p[0]; s[1] = (float)p[1]; s[2] = (float)p[2];
+                s[3] = (float)q.w(); s[4] = (float)q.x(); s[5] = (float)q.y(); s[6] = (float)q.z();
+            }
+            a.n[c] = m;
+        }
+        return true;
+    }
+    bool toArrays(const Contacts::ContactPhaseList& list, ListArrays& a)
+    {
+        const std::vector<std::string> names{m_names[0], m_names[1]};
+        for (int c = 0; c < 2; ++c) {
+            auto it = list.lists().find(m_names[c]);
+            if (it == list.lists().end() || it->second.size() == 0) return err("[CentroidalMPC::setContactPhaseList] no contact list for " + m_names[c]);
+        }
+        return toArrays(list, names, a) ? true : err("[CentroidalMPC::setContactPhaseList] malformed contact phase list");
+    }
+
     bool err(const std::string& m) { m_err = m; std::fprintf(stderr, "%s\n", m.c_str()); return false; }
     bool ok(int rc, const char* where) { return rc == CMPC_OK ? true : err(std::string(where) + " " + cmpc_last_error(m_h)); }
 
@@ -246,6 +329,7 @@ private:
     int m_landKnot[2]{-1, -1};
     std::chrono::nanoseconds m_now{0};
     Contacts::ContactPhaseList m_list;
+    ListArrays m_arrays;
     CentroidalMPCOutput m_out;
 };
 

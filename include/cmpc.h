@@ -152,6 +152,57 @@ int cmpc_plant_step_device(cmpc_handle h, const float* dX, const float* dP, cons
  * iterations | status, from dX[B][n_x] and dInfo[B][8].  Device pointers; asynchronous on `stream` (NULL: the handle's). */
 int cmpc_compact_output_device(cmpc_handle h, const float* dX, const float* dInfo, float* dOut, void* stream);
 
+/* ---- 8f-1: contact schedules, batched ----
+ * What the reference does with BipedalLocomotion::Contacts::ContactPhaseList objects around the solve, for a batch.
+ * One foot of one problem = a list of at most M = max_contacts contacts sorted by activation time (contacts in
+ * alphabetical name order: left_foot, right_foot):
+ *     t[B][2][M][2]     activation, deactivation time [s] (double)
+ *     pose[B][2][M][7]  position x y z, orientation quaternion w x y z (float)
+ *     n[B][2]           contacts in use
+ * ContactList::getActiveContact(t) = the contact with activation <= t < deactivation; getNextContact(t) = the first
+ * one that activates after t (the two queries the reference makes, CentroidalMPCBlock.cpp:44, :61, :69). */
+
+/* updateContactPhaseList, CentroidalMPCBlock.cpp:32-110 (call site :594-607): out = the planner's future contacts
+ * (activation > now), preceded -- when the MPC's previous list has an active contact -- by that contact with the pose
+ * the MPC gave it and the timing of the planner's active contact (:79-82).  Where the planner has no active contact
+ * for such a foot the reference returns false (:69-77): ok[b] = 0 and the function returns CMPC_ERR_ARG after
+ * processing the whole batch.  Host buffers; no handle, no GPU. */
+int cmpc_contacts_merge(int batch, int max_contacts, double now, const double* plan_t, const float* plan_pose, const int* plan_n,
+                        const double* mpc_t, const float* mpc_pose, const int* mpc_n, double* out_t, float* out_pose, int* out_n,
+                        int* ok /* [B] or NULL */);
+/* same on the device (one thread per problem and foot); dOk[B] or NULL; asynchronous on `stream` (NULL: the handle's) */
+int cmpc_contacts_merge_device(cmpc_handle h, int max_contacts, double now, const double* dPlanT, const float* dPlanPose,
+                               const int* dPlanN, const double* dMpcT, const float* dMpcPose, const int* dMpcN, double* dOutT,
+                               float* dOutPose, int* dOutN, int* dOk, void* stream);
+
+/* setContactPhaseList, CentroidalMPCBlock.cpp:609: samples the lists at the knots now + k dt into the contact blocks of
+ * P[B][n_p] (R, upper, lower, enabled, nominalPos, currentPos; the other entries of P are left alone).  Rule: stage k
+ * is in contact iff a contact is active at its start; its orientation, box limits and the nominal position of knot
+ * k+1 come from the stage's owner = the active contact, else the next one to activate, else the last.  box_upper /
+ * box_lower [2][3]: bounding_box_{upper,lower}_limit of [CONTACT_i].  land[B][2] (or NULL) receives the landing knot of
+ * each foot: first knot in contact after a swing stage, N if still in the air at the end, -1 if it never lifts. */
+int cmpc_contacts_sample(int horizon, double dt, int batch, int max_contacts, double now, const double* t, const float* pose,
+                         const int* n, const float* box_upper, const float* box_lower, float* P, int* land);
+int cmpc_contacts_sample_device(cmpc_handle h, int max_contacts, double now, const double* dT, const float* dPose, const int* dN,
+                                const float* box_upper /* host */, const float* box_lower /* host */, float* dP, int* dLand,
+                                void* stream);
+/* the same into the handle's own parameter set (what the class facade's setContactPhaseList calls) */
+int cmpc_set_contact_lists(cmpc_handle h, int max_contacts, double now, const double* t, const float* pose, const int* n,
+                           const float* box_upper, const float* box_lower, int* land);
+
+/* getOutput().contactPhaseList, CentroidalMPCBlock.cpp:598, :626: the next contact (getNextContact(now)) of every foot
+ * that lands inside the horizon takes the optimised landing position x.pos[land]. */
+int cmpc_contacts_adjust(int horizon, int batch, int max_contacts, double now, const float* X, const int* land, const double* t,
+                         float* pose, const int* n);
+int cmpc_contacts_adjust_device(cmpc_handle h, int max_contacts, double now, const float* dX, const int* dLand, const double* dT,
+                                float* dPose, const int* dN, void* stream);
+
+/* setState on the device: dState[B][9] (com, dcom, h) and dWrench[B][N][6] (or NULL: left alone) into the rows of dP */
+int cmpc_write_state_device(cmpc_handle h, const float* dState, const float* dWrench, float* dP, void* stream);
+/* is_warm_start_enabled on the device: dX0 = dXprev shifted by one knot; the next cmpc_solve_device starts its barrier
+ * near the central path (as cmpc_set_initial_guess(NULL, 1) + cmpc_advance do for the handle's own buffers) */
+int cmpc_shift_solution_device(cmpc_handle h, const float* dXprev, float* dX0, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -5,7 +5,7 @@ The directory name contains '-', so import it with
     importlib.import_module("paper_romualdi_2022_icra_centroidal-mpc-walking_amd")
 (tests and bench.py do that through `cmpc_amd.py` at the repo root).
 """
-from . import _capi, config, contacts, distributed, layout, solver, synthetic  # noqa: F401
+from . import _capi, config, contacts, distributed, layout, rollout, solver, synthetic  # noqa: F401
 from .config import CentroidalMPCConfig, ContactConfig  # noqa: F401
 from .layout import Layout, cold_start, pack_parameters  # noqa: F401
 from .solver import BatchSolver, CentroidalMPC  # noqa: F401

@@ -39,7 +39,9 @@ EXPORTS = [
     "cmpc_eval_nlp_device", "cmpc_nlp_sparsity", "cmpc_set_state", "cmpc_set_reference",
     "cmpc_set_contacts", "cmpc_set_initial_guess", "cmpc_advance", "cmpc_get_solution",
     "cmpc_get_output", "cmpc_set_reference_from_planner", "cmpc_plant_step_device", "cmpc_test_poison_lds",
-    "cmpc_compact_output_device",
+    "cmpc_compact_output_device", "cmpc_contacts_merge", "cmpc_contacts_merge_device", "cmpc_contacts_sample",
+    "cmpc_contacts_sample_device", "cmpc_set_contact_lists", "cmpc_contacts_adjust", "cmpc_contacts_adjust_device",
+    "cmpc_write_state_device", "cmpc_shift_solution_device",
 ]
 
 _lib = None
@@ -87,5 +89,15 @@ def lib():
         L.cmpc_get_output.argtypes = [vp, fp, fp, fp, vp]
         L.cmpc_set_reference_from_planner.argtypes = [vp, fp, fp, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double]
         L.cmpc_plant_step_device.argtypes = [vp, fp, fp, fp, fp, fp, C.c_double, C.c_int, C.c_double, C.c_double, vp]
+        d, i = C.c_double, C.c_int
+        L.cmpc_contacts_merge.argtypes = [i, i, d, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+        L.cmpc_contacts_merge_device.argtypes = [vp, i, d, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+        L.cmpc_contacts_sample.argtypes = [i, d, i, i, d, vp, vp, vp, vp, vp, vp, vp]
+        L.cmpc_contacts_sample_device.argtypes = [vp, i, d, vp, vp, vp, vp, vp, vp, vp, vp]
+        L.cmpc_set_contact_lists.argtypes = [vp, i, d, vp, vp, vp, vp, vp, vp]
+        L.cmpc_contacts_adjust.argtypes = [i, i, i, d, vp, vp, vp, vp, vp]
+        L.cmpc_contacts_adjust_device.argtypes = [vp, i, d, vp, vp, vp, vp, vp, vp]
+        L.cmpc_write_state_device.argtypes = [vp, fp, fp, fp, vp]
+        L.cmpc_shift_solution_device.argtypes = [vp, fp, fp, vp]
         _lib = L
     return _lib

@@ -1,5 +1,6 @@
 // C ABI of libcmpc_hip.so (include/cmpc.h): handle management, host<->device plumbing, launches.
 #include "../../include/cmpc.h"
+#include "cmpc_contacts.h"
 #include "cmpc_device.h"
 
 #include <algorithm>
@@ -16,6 +17,14 @@ extern "C" int cmpc_launch_nlp_eval(const CmpcParams* prm, const float* dX, cons
                                     float lam_f, float* dF, float* dG, float* dGradF, float* dJac, float* dHess,
                                     hipStream_t stream);
 extern "C" int cmpc_launch_warm_shift(const CmpcParams* prm, const float* dXprev, float* dX0, hipStream_t stream);
+extern "C" int cmpc_launch_contacts_merge(int B, int M, double now, const double* plan_t, const float* plan_pose, const int* plan_n,
+                                          const double* mpc_t, const float* mpc_pose, const int* mpc_n, double* out_t, float* out_pose,
+                                          int* out_n, int* ok, hipStream_t stream);
+extern "C" int cmpc_launch_contacts_sample(int B, int N, int M, double dt, double now, const double* t, const float* pose, const int* n,
+                                           const float* box, float* P, int* land, hipStream_t stream);
+extern "C" int cmpc_launch_contacts_adjust(int B, int N, int M, double now, const float* X, const int* land, const double* t, float* pose,
+                                           const int* n, hipStream_t stream);
+extern "C" int cmpc_launch_write_state(int B, int N, const float* state, const float* wrench, float* P, hipStream_t stream);
 extern "C" int cmpc_launch_compact(int N, int B, const float* dX, const float* dInfo, float* dOut, hipStream_t stream);
 extern "C" int cmpc_launch_plant_step(int N, int B, float grav, const float* dCorners, const float* dX, const float* dP,
                                       const float* dStateIn, float* dStateOut, float* dZmp, float h, int nsub, float zx, float zy,
@@ -34,6 +43,9 @@ struct cmpc_handle_s {
     float* dInfo = nullptr;
     CmpcConsts* dConsts = nullptr;
     float* dScratch = nullptr;   // factor storage when the horizon's LDS image exceeds 160 KiB
+    float* dBox = nullptr;       // bounding-box limits upper[2][3] | lower[2][3] of the schedule sampler
+    float hBox[12] = {0};
+    bool box_set = false;
     long long scratch_stride = 0;
     std::vector<float> hP, hX0;  // host staging for the class-shaped setters
     bool have_solution = false, x0_set = false;
@@ -150,25 +162,37 @@ int cmpc_create(const cmpc_config* cfg, int batch, int device, cmpc_handle* out)
         delete h;
         return fail(nullptr, CMPC_ERR_ARG, "cmpc_create: horizon " + std::to_string(n) + " needs more than 160 KiB of LDS per problem");
     }
-    HIPCHK(h, hipSetDevice(device));
+    // a failure below releases whatever the handle already owns (cmpc_destroy copes with a partly built handle)
+#define HIPCHK_CREATE(call)                                                                                   \
+    do {                                                                                                      \
+        hipError_t e_ = (call);                                                                               \
+        if (e_ != hipSuccess) {                                                                               \
+            const std::string m_ = std::string("cmpc_create: " #call ": ") + hipGetErrorString(e_);           \
+            cmpc_destroy(h);                                                                                  \
+            return fail(nullptr, CMPC_ERR_HIP, m_);                                                           \
+        }                                                                                                     \
+    } while (0)
+    HIPCHK_CREATE(hipSetDevice(device));
     if (fg) {
         // the factor records rely on never-written zero blocks (layout: cmpc_solver.hip): zero once
-        HIPCHK(h, hipMalloc(&h->dScratch, sizeof(float) * (size_t)h->scratch_stride * (size_t)batch));
-        HIPCHK(h, hipMemset(h->dScratch, 0, sizeof(float) * (size_t)h->scratch_stride * (size_t)batch));
+        HIPCHK_CREATE(hipMalloc(&h->dScratch, sizeof(float) * (size_t)h->scratch_stride * (size_t)batch));
+        HIPCHK_CREATE(hipMemset(h->dScratch, 0, sizeof(float) * (size_t)h->scratch_stride * (size_t)batch));
     }
-    HIPCHK(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-    HIPCHK(h, hipEventCreate(&h->ev0));
-    HIPCHK(h, hipEventCreate(&h->ev1));
-    HIPCHK(h, hipMalloc(&h->dInfo, sizeof(float) * CMPC_INFO_N * (size_t)batch));
-    HIPCHK(h, hipMalloc(&h->dConsts, sizeof(CmpcConsts)));
+    HIPCHK_CREATE(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    HIPCHK_CREATE(hipEventCreate(&h->ev0));
+    HIPCHK_CREATE(hipEventCreate(&h->ev1));
+    HIPCHK_CREATE(hipMalloc(&h->dInfo, sizeof(float) * CMPC_INFO_N * (size_t)batch));
+    HIPCHK_CREATE(hipMalloc(&h->dConsts, sizeof(CmpcConsts)));
+    HIPCHK_CREATE(hipMalloc(&h->dBox, sizeof(float) * 12));
     {
         CmpcConsts q;
         fill_consts(h, q);
-        HIPCHK(h, hipMemcpy(h->dConsts, &q, sizeof(q), hipMemcpyHostToDevice));
+        HIPCHK_CREATE(hipMemcpy(h->dConsts, &q, sizeof(q), hipMemcpyHostToDevice));
     }
     // the memset and the copy above ran on the null stream; solves run on a non-blocking stream that does not
     // wait for it (a first solve racing the tail of a 350 MB memset was observed to fail): drain the device once
-    HIPCHK(h, hipDeviceSynchronize());
+    HIPCHK_CREATE(hipDeviceSynchronize());
+#undef HIPCHK_CREATE
     *out = h;
     return CMPC_OK;
 }
@@ -178,7 +202,7 @@ int cmpc_destroy(cmpc_handle h)
     if (!h) return CMPC_OK;
     hipSetDevice(h->device);
     if (h->stream) hipStreamSynchronize(h->stream);
-    hipFree(h->dP); hipFree(h->dX0); hipFree(h->dX); hipFree(h->dInfo); hipFree(h->dConsts); hipFree(h->dScratch);
+    hipFree(h->dP); hipFree(h->dX0); hipFree(h->dX); hipFree(h->dInfo); hipFree(h->dConsts); hipFree(h->dScratch); hipFree(h->dBox);
     if (h->ev0) hipEventDestroy(h->ev0);
     if (h->ev1) hipEventDestroy(h->ev1);
     if (h->stream) hipStreamDestroy(h->stream);
@@ -249,6 +273,11 @@ int cmpc_solve_device(cmpc_handle h, const float* dP, const float* dX0, float* d
     CmpcParams p;
     fill_params(h, p);
     p.P = dP; p.X0 = dX0; p.X = dX; p.info = dInfo ? dInfo : h->dInfo;
+    if (std::getenv("CMPC_FORCE_WARM")) h->warm = true;   // developer knob
+    if (h->warm) {  // the initial guess was produced by cmpc_shift_solution_device: start near the central path
+        p.mu_init = (float)h->mu_warm; p.mu_adapt = 0.f; p.t_floor = (float)h->floor_warm; p.warm = 1;
+        h->warm = false;
+    }
     HIPCHK(h, hipEventRecord(h->ev0, st));
     int rc = cmpc_launch_solver(&p, h->lds, st);
     if (rc != 0) return fail(h, CMPC_ERR_HIP, std::string("solver launch: ") + hipGetErrorString((hipError_t)rc));
@@ -422,6 +451,7 @@ int cmpc_set_initial_guess(cmpc_handle h, const float* x0, int shift_previous)
     if (rc) return rc;
     HIPCHK(h, hipSetDevice(h->device));
     const size_t nX = (size_t)h->B * h->L.nx;
+    h->warm = false;   // only a shifted previous solution starts the barrier at mu_warm
     if (x0) {
         HIPCHK(h, hipMemcpyAsync(h->dX0, x0, sizeof(float) * nX, hipMemcpyHostToDevice, h->stream));
     } else if (shift_previous && h->have_solution) {
@@ -452,7 +482,7 @@ int cmpc_advance(cmpc_handle h)
         CmpcParams p;
         fill_params(h, p);
         p.P = h->dP; p.X0 = h->dX0; p.X = h->dX; p.info = h->dInfo;
-        if (h->warm) { p.mu_init = (float)h->mu_warm; p.mu_adapt = 0.f; p.t_floor = (float)h->floor_warm; }
+        if (h->warm) { p.mu_init = (float)h->mu_warm; p.mu_adapt = 0.f; p.t_floor = (float)h->floor_warm; p.warm = 1; }
         if (const char* e = std::getenv("CMPC_MU_WARM")) { if (h->warm) { p.mu_init = (float)std::atof(e); p.mu_adapt = 0.f; p.t_floor = std::min(1e-2f, p.mu_init); } }
         HIPCHK(h, hipEventRecord(h->ev0, h->stream));
         int lrc = cmpc_launch_solver(&p, h->lds, h->stream);
@@ -574,6 +604,137 @@ int cmpc_compact_output_device(cmpc_handle h, const float* dX, const float* dInf
     HIPCHK(h, hipSetDevice(h->device));
     int rc = cmpc_launch_compact(h->cfg.horizon, h->B, dX, dInfo, dOut, stream ? (hipStream_t)stream : h->stream);
     if (rc != 0) return fail(h, CMPC_ERR_HIP, std::string("compact output launch: ") + hipGetErrorString((hipError_t)rc));
+    return CMPC_OK;
+}
+
+// ---- 8f-1: contact schedules, batched (logic: cmpc_contacts.h) ----
+int cmpc_contacts_merge(int batch, int max_contacts, double now, const double* plan_t, const float* plan_pose, const int* plan_n,
+                        const double* mpc_t, const float* mpc_pose, const int* mpc_n, double* out_t, float* out_pose, int* out_n, int* ok)
+{
+    if (batch < 1 || max_contacts < 1 || !plan_t || !plan_pose || !plan_n || !mpc_t || !mpc_pose || !mpc_n || !out_t || !out_pose || !out_n)
+        return fail(nullptr, CMPC_ERR_ARG, "cmpc_contacts_merge: bad argument");
+    const int M = max_contacts;
+    int all = CMPC_OK;
+    for (int b = 0; b < batch; ++b) {
+        bool good = true;
+        for (int c = 0; c < 2; ++c) {
+            const size_t e = (size_t)b * 2 + c, o = e * M;
+            if (plan_n[e] < 0 || plan_n[e] > M || mpc_n[e] < 0 || mpc_n[e] > M) return fail(nullptr, CMPC_ERR_ARG, "cmpc_contacts_merge: list length out of range");
+            good = cmpc_merge_foot(now, plan_t + 2 * o, plan_pose + 7 * o, plan_n[e], mpc_t + 2 * o, mpc_pose + 7 * o, mpc_n[e], M,
+                                   out_t + 2 * o, out_pose + 7 * o, out_n + e) && good;
+        }
+        if (ok) ok[b] = good ? 1 : 0;
+        if (!good) all = CMPC_ERR_ARG;
+    }
+    if (all != CMPC_OK) return fail(nullptr, CMPC_ERR_ARG, "cmpc_contacts_merge: the planner has no active contact where the MPC list has one");
+    return CMPC_OK;
+}
+
+int cmpc_contacts_sample(int horizon, double dt, int batch, int max_contacts, double now, const double* t, const float* pose, const int* n,
+                         const float* box_upper, const float* box_lower, float* P, int* land)
+{
+    if (horizon < 1 || !(dt > 0) || batch < 1 || max_contacts < 1 || !t || !pose || !n || !box_upper || !box_lower || !P)
+        return fail(nullptr, CMPC_ERR_ARG, "cmpc_contacts_sample: bad argument");
+    const CmpcIdx L{horizon};
+    for (int b = 0; b < batch; ++b)
+        for (int c = 0; c < 2; ++c) {
+            const size_t e = (size_t)b * 2 + c, o = e * max_contacts;
+            if (n[e] < 1 || n[e] > max_contacts) return fail(nullptr, CMPC_ERR_ARG, "cmpc_contacts_sample: every foot needs 1..max_contacts contacts");
+            const int lk = cmpc_sample_foot(horizon, dt, now, c, t + 2 * o, pose + 7 * o, n[e], box_upper, box_lower, P + (size_t)b * L.np());
+            if (land) land[e] = lk;
+        }
+    return CMPC_OK;
+}
+
+int cmpc_contacts_adjust(int horizon, int batch, int max_contacts, double now, const float* X, const int* land, const double* t, float* pose, const int* n)
+{
+    if (horizon < 1 || batch < 1 || max_contacts < 1 || !X || !land || !t || !pose || !n) return fail(nullptr, CMPC_ERR_ARG, "cmpc_contacts_adjust: bad argument");
+    const CmpcIdx L{horizon};
+    for (int b = 0; b < batch; ++b)
+        for (int c = 0; c < 2; ++c) {
+            const size_t e = (size_t)b * 2 + c, o = e * max_contacts;
+            if (land[e] < 0) continue;
+            const int nx = cmpc_next_contact(t + 2 * o, n[e], now);
+            if (nx < 0) continue;
+            for (int i = 0; i < 3; ++i) pose[7 * (o + nx) + i] = X[(size_t)b * L.nx() + L.oPos(c) + 3 * land[e] + i];
+        }
+    return CMPC_OK;
+}
+
+int cmpc_contacts_merge_device(cmpc_handle h, int max_contacts, double now, const double* dPlanT, const float* dPlanPose, const int* dPlanN,
+                               const double* dMpcT, const float* dMpcPose, const int* dMpcN, double* dOutT, float* dOutPose, int* dOutN,
+                               int* dOk, void* stream)
+{
+    if (!h || max_contacts < 1 || !dPlanT || !dPlanPose || !dPlanN || !dMpcT || !dMpcPose || !dMpcN || !dOutT || !dOutPose || !dOutN)
+        return fail(h, CMPC_ERR_ARG, "cmpc_contacts_merge_device: bad argument");
+    HIPCHK(h, hipSetDevice(h->device));
+    int rc = cmpc_launch_contacts_merge(h->B, max_contacts, now, dPlanT, dPlanPose, dPlanN, dMpcT, dMpcPose, dMpcN, dOutT, dOutPose, dOutN, dOk,
+                                        stream ? (hipStream_t)stream : h->stream);
+    if (rc != 0) return fail(h, CMPC_ERR_HIP, std::string("contact merge launch: ") + hipGetErrorString((hipError_t)rc));
+    return CMPC_OK;
+}
+
+int cmpc_contacts_sample_device(cmpc_handle h, int max_contacts, double now, const double* dT, const float* dPose, const int* dN,
+                                const float* box_upper, const float* box_lower, float* dP, int* dLand, void* stream)
+{
+    if (!h || max_contacts < 1 || !dT || !dPose || !dN || !box_upper || !box_lower || !dP) return fail(h, CMPC_ERR_ARG, "cmpc_contacts_sample_device: bad argument");
+    HIPCHK(h, hipSetDevice(h->device));
+    hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+    float box[12];
+    std::memcpy(box, box_upper, sizeof(float) * 6);
+    std::memcpy(box + 6, box_lower, sizeof(float) * 6);
+    if (!h->box_set || std::memcmp(box, h->hBox, sizeof(box)) != 0) {
+        std::memcpy(h->hBox, box, sizeof(box));
+        HIPCHK(h, hipMemcpyAsync(h->dBox, h->hBox, sizeof(box), hipMemcpyHostToDevice, st));
+        h->box_set = true;
+    }
+    int rc = cmpc_launch_contacts_sample(h->B, h->cfg.horizon, max_contacts, h->cfg.sampling_time, now, dT, dPose, dN, h->dBox, dP, dLand, st);
+    if (rc != 0) return fail(h, CMPC_ERR_HIP, std::string("contact sampling launch: ") + hipGetErrorString((hipError_t)rc));
+    return CMPC_OK;
+}
+
+int cmpc_contacts_adjust_device(cmpc_handle h, int max_contacts, double now, const float* dX, const int* dLand, const double* dT, float* dPose,
+                                const int* dN, void* stream)
+{
+    if (!h || max_contacts < 1 || !dX || !dLand || !dT || !dPose || !dN) return fail(h, CMPC_ERR_ARG, "cmpc_contacts_adjust_device: bad argument");
+    HIPCHK(h, hipSetDevice(h->device));
+    int rc = cmpc_launch_contacts_adjust(h->B, h->cfg.horizon, max_contacts, now, dX, dLand, dT, dPose, dN, stream ? (hipStream_t)stream : h->stream);
+    if (rc != 0) return fail(h, CMPC_ERR_HIP, std::string("contact adjustment launch: ") + hipGetErrorString((hipError_t)rc));
+    return CMPC_OK;
+}
+
+int cmpc_write_state_device(cmpc_handle h, const float* dState, const float* dWrench, float* dP, void* stream)
+{
+    if (!h || !dState || !dP) return fail(h, CMPC_ERR_ARG, "cmpc_write_state_device: null argument");
+    HIPCHK(h, hipSetDevice(h->device));
+    int rc = cmpc_launch_write_state(h->B, h->cfg.horizon, dState, dWrench, dP, stream ? (hipStream_t)stream : h->stream);
+    if (rc != 0) return fail(h, CMPC_ERR_HIP, std::string("state write launch: ") + hipGetErrorString((hipError_t)rc));
+    return CMPC_OK;
+}
+
+int cmpc_shift_solution_device(cmpc_handle h, const float* dXprev, float* dX0, void* stream)
+{
+    if (!h || !dXprev || !dX0) return fail(h, CMPC_ERR_ARG, "cmpc_shift_solution_device: null argument");
+    HIPCHK(h, hipSetDevice(h->device));
+    CmpcParams p;
+    fill_params(h, p);
+    int rc = cmpc_launch_warm_shift(&p, dXprev, dX0, stream ? (hipStream_t)stream : h->stream);
+    if (rc != 0) return fail(h, CMPC_ERR_HIP, "warm-start shift launch failed");
+    h->warm = true;   // the next cmpc_solve_device starts the barrier at mu_warm
+    return CMPC_OK;
+}
+
+// the handle's own contact blocks from contact lists (what the class facade's setContactPhaseList calls)
+int cmpc_set_contact_lists(cmpc_handle h, int max_contacts, double now, const double* t, const float* pose, const int* n,
+                           const float* box_upper, const float* box_lower, int* land)
+{
+    if (!h) return fail(h, CMPC_ERR_ARG, "cmpc_set_contact_lists: null handle");
+    int rc = ensure_buffers(h);
+    if (rc) return rc;
+    for (int c = 0; box_upper && box_lower && c < 6; ++c)
+        if (box_upper[c] < box_lower[c]) return fail(h, CMPC_ERR_ARG, "cmpc_set_contact_lists: bounding box upper < lower");
+    rc = cmpc_contacts_sample(h->cfg.horizon, h->cfg.sampling_time, h->B, max_contacts, now, t, pose, n, box_upper, box_lower, h->hP.data(), land);
+    if (rc) return fail(h, rc, g_err);
     return CMPC_OK;
 }
 

@@ -101,6 +101,7 @@ struct CmpcParams {
     float* info;                 // [B][CMPC_INFO_N] or null
     float mu_init, t_floor;      // starting barrier parameter and slack floor of this solve (cold: 0.1 / 1e-2)
     float mu_adapt;              // > 0: mu_init is replaced per problem by clamp(mu_adapt * ep0^2, 0.03, 0.5)
+    int warm;                    // the initial guess is a shifted previous solution: a problem that fails is restarted cold
     float* scratch;              // per-problem factor storage when it does not fit in LDS, else null
     long long scratch_stride;    // floats per problem
     int lds_words;               // 4-byte words of dynamic LDS the launch was given (set by cmpc_launch_solver)

@@ -1407,214 +1407,247 @@ __global__ __launch_bounds__(NT, FG ? 2 : 1) void cmpc_solve_kernel(CmpcParams k
         c.qmask[tid] = m;
     }
     __syncthreads();
-    // ---- initial iterate from x0 ----
-    {
-        const float* x0 = kp.X0 + (size_t)b * c.L.nx();
-        for (int e = tid; e < NS * (N + 1); e += NT) {
-            const int k = e / NS, i = e % NS;
-            float v;
-            if (k == 0) {  // initial-condition rows of g hold exactly
-                if (i < 9) v = c.sp[c.L.pCom0() + i];
-                else v = c.sp[c.L.pCur((i - 9) / 3) + (i - 9) % 3];
-            } else if (i < 9) v = x0[c.L.oCom() + 3 * (N + 1) * (i / 3) + 3 * k + i % 3];
-            else v = x0[c.L.oPos((i - 9) / 3) + 3 * k + (i - 9) % 3];
-            c.S[e] = v;
-            c.LAM[e] = 0.0;
-        }
-        for (int e = tid; e < NU * N; e += NT) {
-            const int k = e / NU, m = e % NU;
-            float v = 0.f;
-            if (m < NF) v = x0[c.L.oF(m / 12, (m % 12) / 3) + 3 * k + m % 3];
-            else {
-                const int q = m - 24, ct = q / 3, i = q % 3;
-                if (qfree(c, k, q)) {
-                    const float* R = c.sp + c.L.pR(ct) + 9 * k;
-                    const float lo = qlo(c, k, q), hi = qhi(c, k, q), push = 0.01f * (hi - lo);
-                    for (int a = 0; a < 3; ++a)
-                        v += Rm(R, a, i) * (x0[c.L.oPos(ct) + 3 * (k + 1) + a] - c.sp[c.L.pNom(ct) + 3 * (k + 1) + a]);
-                    v = fminf(fmaxf(v, lo + push), hi - push);
-                } else if (gam_of(c, ct, k) < 0.5f) v = qlo(c, k, q);
-            }
-            c.U[e] = v;
-        }
-        __syncthreads();
-        for (int e = tid; e < NI * N; e += NT) {
-            const int k = e / NI, i = e % NI;
-            float t = 1.f, z = 0.f;
-            if (row_active(c, k, i)) {
-                t = -row_val(c, prm, k, i, c.U + NU * k);
-                if (i < 32) t = fmaxf(t, kp.t_floor);
-                z = kp.mu_init / t;
-            }
-            c.T[e] = t; c.Z[e] = z;
-        }
-        __syncthreads();
-    }
-    int nrow = 0;
-    for (int k = 0; k < N; ++k)
-        for (int i = 32; i < NI; ++i) nrow += row_active(c, k, i) ? 1 : 0;
-    nrow += 32 * N;
-
-    int it = 0, status = 1, gn = 0;
+    // Two passes at most: a warm-started solve (shifted previous solution) that exhausts its iteration budget is started
+    // again from the cold start -- rare (a landing or lift-off tick, 1 in ~60000 solves of a walking roll-out) and cheaper than
+    // failing the tick, which is all the caller could do (CentroidalMPCBlock.cpp:615-619 aborts).
+    int status = 1, gn = 0, it_total = 0;
     float err = 0.f, ep = 0.f, mu_cur = 0.f, step_out = 0.f, step_prev = 0.f;
-    bool finishing = false;
-    for (it = 0; it < prm.max_iter + 1; ++it) {
-        if (it == prm.max_iter && !finishing) break;
-        // ---- residuals of the current iterate ----
-        PROF_DECL;
-        float l_ep = 0.f, l_ec = 0.f;
-        double l_mu = 0.0;
-        all_geo<NT>(c, prm, tid);
-        for (int e = tid; e < NS * N; e += NT) {
-            const double dv = defect(c, prm, e / NS, e % NS);
-            c.d[e] = (float)dv;
-            l_ep = fmaxf(l_ep, fabsf((float)dv));
-        }
-        for (int e = tid; e < NI * N; e += NT) {
-            const int k = e / NI, i = e % NI;
-            if (row_active(c, k, i)) {
-                const float t = c.T[e], z = c.Z[e];
-                l_ep = fmaxf(l_ep, fabsf(row_val(c, prm, k, i, c.U + NU * k) + t));
-                l_ec = fmaxf(l_ec, t * z);
-                l_mu += (double)t * z;
+    for (int pass = 0; pass < 2; ++pass) {
+        const float mu_init = pass ? 0.1f : kp.mu_init, t_floor = pass ? 1e-2f : kp.t_floor, mu_adapt = pass ? 3.5f : kp.mu_adapt;
+        step_out = step_prev = 0.f;
+        // ---- initial iterate from x0 ----
+        {
+            const float* x0 = kp.X0 + (size_t)b * c.L.nx();
+            const bool cold = pass > 0;   // second pass: the cold start of SURVEY 8d built in place (CoM at com0, feet at nominal, f_z = g/8)
+            for (int e = tid; e < NS * (N + 1); e += NT) {
+                const int k = e / NS, i = e % NS;
+                float v;
+                if (k == 0) {  // initial-condition rows of g hold exactly
+                    if (i < 9) v = c.sp[c.L.pCom0() + i];
+                    else v = c.sp[c.L.pCur((i - 9) / 3) + (i - 9) % 3];
+                } else if (cold) v = i < 3 ? c.sp[c.L.pCom0() + i] : (i < 9 ? 0.f : c.sp[c.L.pNom((i - 9) / 3) + 3 * k + (i - 9) % 3]);
+                else if (i < 9) v = x0[c.L.oCom() + 3 * (N + 1) * (i / 3) + 3 * k + i % 3];
+                else v = x0[c.L.oPos((i - 9) / 3) + 3 * k + (i - 9) % 3];
+                c.S[e] = v;
+                c.LAM[e] = 0.0;
             }
-        }
-        ep = block_max<NT>(l_ep, c.red, tid);
-        const float ec = block_max<NT>(l_ec, c.red, tid);
-        mu_cur = (float)(block_sum<NT>(l_mu, c.redd, tid) / (double)nrow);
-        if (it == 0 && kp.mu_adapt > 0.f) {
-            // cold start: the initial barrier parameter scales with the squared initial infeasibility (z = mu / t)
-            const float mu0 = fminf(fmaxf(kp.mu_adapt * ep * ep, 0.03f), 0.5f);
-            const float sc = mu0 / mu_cur;
-            for (int e = tid; e < NI * N; e += NT) c.Z[e] *= sc;
-            mu_cur = mu0;
+            for (int e = tid; e < NU * N; e += NT) {
+                const int k = e / NU, m = e % NU;
+                float v = 0.f;
+                if (m < NF) v = cold ? (m % 3 == 2 ? 0.125f * prm.grav : 0.f) : x0[c.L.oF(m / 12, (m % 12) / 3) + 3 * k + m % 3];
+                else {
+                    const int q = m - 24, ct = q / 3, i = q % 3;
+                    if (qfree(c, k, q)) {
+                        const float* R = c.sp + c.L.pR(ct) + 9 * k;
+                        const float lo = qlo(c, k, q), hi = qhi(c, k, q), push = 0.01f * (hi - lo);
+                        for (int a = 0; a < 3 && !cold; ++a)
+                            v += Rm(R, a, i) * (x0[c.L.oPos(ct) + 3 * (k + 1) + a] - c.sp[c.L.pNom(ct) + 3 * (k + 1) + a]);
+                        v = fminf(fmaxf(v, lo + push), hi - push);
+                    } else if (gam_of(c, ct, k) < 0.5f) v = qlo(c, k, q);
+                }
+                c.U[e] = v;
+            }
+            __syncthreads();
+            for (int e = tid; e < NI * N; e += NT) {
+                const int k = e / NI, i = e % NI;
+                float t = 1.f, z = 0.f;
+                if (row_active(c, k, i)) {
+                    t = -row_val(c, prm, k, i, c.U + NU * k);
+                    if (i < 32) t = fmaxf(t, t_floor);
+                    z = mu_init / t;
+                }
+                c.T[e] = t; c.Z[e] = z;
+            }
             __syncthreads();
         }
-        PROF(10);
-        // The step that produced this iterate was already below the step tolerance and its residuals are converged:
-        // stop here, before paying for a factorisation whose step would only confirm it (the error of the iterate is
-        // the size of that unneeded step, an order of magnitude or more below the last one taken).
-        // Its error is what the steps still to come would add: at most the last step, and -- once two steps are known --
-        // their geometric tail s rho / (1 - rho) with the observed contraction rho = s_k / s_{k-1}, taken no smaller
-        // than 0.2 (the convergence is superlinear only at the very end; floors of 0.1 ... 0.3 give the same worst parity error) and no larger than 0.9.
-        float est = step_out;
-        if (it > 1 && step_prev > 0.f) {
-            const float rho = fminf(fmaxf(step_out / step_prev, 0.2f), 0.9f);
-            est = fminf(est, step_out * rho / (1.f - rho));
-        }
-        if (it > 0 && !finishing && fmaxf(ep, ec) <= prm.tol && est <= prm.step_tol) {
-            err = fmaxf(ep, ec);
-            status = 0;
-            if (!prm.final_extrap) break;
-            finishing = true;
-        }
-        // ---- predictor (affine scaling): factorise; on a non-positive pivot fall back to the
-        // Gauss-Newton Hessian, then to a larger Levenberg shift ----
-        // once the complementarity products sit at the barrier floor the predictor has nothing to predict
-        // (sigma ~ 0, second-order term ~ 0): take plain centring Newton steps, one sweep pair instead of three
-        const bool centring = !finishing && mu_cur <= fmaxf(1.5f * prm.mu_min, 0.15f * prm.tol) && ec <= fmaxf(4.f * prm.mu_min, 0.4f * prm.tol);
-        bool exact = prm.exact_hessian != 0;
-        float reg = prm.reg;
-        int fail = 1;
-        for (int attempt = 0; attempt < 4; ++attempt) {
-            fail = riccati_backward<NT, NC, FG>(lds, c, prm, tid, fg_base, exact, reg, centring ? prm.mu_min : 0.f);
-            if (!fail) break;
+        int nrow = 0;
+        for (int k = 0; k < N; ++k)
+            for (int i = 32; i < NI; ++i) nrow += row_active(c, k, i) ? 1 : 0;
+        nrow += 32 * N;
+
+        int it = 0;
+        status = 1;
+        bool finishing = false;
+        for (it = 0; it < prm.max_iter + 1; ++it) {
+            if (it == prm.max_iter && !finishing) break;
+            // ---- residuals of the current iterate ----
+            PROF_DECL;
+            float l_ep = 0.f, l_ec = 0.f;
+            double l_mu = 0.0;
+            all_geo<NT>(c, prm, tid);
+            for (int e = tid; e < NS * N; e += NT) {
+                const double dv = defect(c, prm, e / NS, e % NS);
+                c.d[e] = (float)dv;
+                l_ep = fmaxf(l_ep, fabsf((float)dv));
+            }
+            for (int e = tid; e < NI * N; e += NT) {
+                const int k = e / NI, i = e % NI;
+                if (row_active(c, k, i)) {
+                    const float t = c.T[e], z = c.Z[e];
+                    l_ep = fmaxf(l_ep, fabsf(row_val(c, prm, k, i, c.U + NU * k) + t));
+                    l_ec = fmaxf(l_ec, t * z);
+                    l_mu += (double)t * z;
+                }
+            }
+            ep = block_max<NT>(l_ep, c.red, tid);
+            const float ec = block_max<NT>(l_ec, c.red, tid);
+            mu_cur = (float)(block_sum<NT>(l_mu, c.redd, tid) / (double)nrow);
+            if (it == 0 && mu_adapt > 0.f) {
+                // cold start: the initial barrier parameter scales with the squared initial infeasibility (z = mu / t)
+                const float mu0 = fminf(fmaxf(mu_adapt * ep * ep, 0.03f), 0.5f);
+                const float sc = mu0 / mu_cur;
+                for (int e = tid; e < NI * N; e += NT) c.Z[e] *= sc;
+                mu_cur = mu0;
+                __syncthreads();
+            }
+            if (it > 0 && ec > 100.f * mu_cur && ec > 0.1f) {
+                // Emergency re-centring.  Primal and dual step lengths differ; when a blocked primal step (ap ~ 0.2) meets a
+                // full dual step, the multipliers of rows that were about to become active grow while their slacks stay:
+                // products t z hundreds of times the average, and the predictor-corrector can fall into a two-cycle (seen on
+                // warm starts when a new swing phase enters the last stage of the horizon: max t z / mu ~ 600, 40 iterations
+                // without progress).  Pull those multipliers back to 10 mu / t.  Only products of order one count (ec > 0.1):
+                // near the barrier floor a few lagging rows are legitimately 100 x the mean and must be left alone
+                // (re-centring them there cost config 2 five of 4096 problems).
+                double l2 = 0.0;
+                for (int e = tid; e < NI * N; e += NT)
+                    if (row_active(c, e / NI, e % NI)) {
+                        const float t = c.T[e];
+                        float z = c.Z[e];
+                        if (t * z > 10.f * mu_cur) { z = 10.f * mu_cur / t; c.Z[e] = z; }
+                        l2 += (double)t * z;
+                    }
+                mu_cur = (float)(block_sum<NT>(l2, c.redd, tid) / (double)nrow);
+                ++gn;   // (counted with the Gauss-Newton fallbacks in info[3])
+            }
+            PROF(10);
+            // The step that produced this iterate was already below the step tolerance and its residuals are converged:
+            // stop here, before paying for a factorisation whose step would only confirm it (the error of the iterate is
+            // the size of that unneeded step, an order of magnitude or more below the last one taken).
+            // Its error is what the steps still to come would add: at most the last step, and -- once two steps are known --
+            // their geometric tail s rho / (1 - rho) with the observed contraction rho = s_k / s_{k-1}, taken no smaller
+            // than 0.2 (the convergence is superlinear only at the very end; floors of 0.1 ... 0.3 give the same worst parity error) and no larger than 0.9.
+            float est = step_out;
+            if (it > 1 && step_prev > 0.f) {
+                const float rho = fminf(fmaxf(step_out / step_prev, 0.2f), 0.9f);
+                est = fminf(est, step_out * rho / (1.f - rho));
+            }
+            if (it > 0 && !finishing && fmaxf(ep, ec) <= prm.tol && est <= prm.step_tol) {
+                err = fmaxf(ep, ec);
+                status = 0;
+                if (!prm.final_extrap) break;
+                finishing = true;
+            }
+            // ---- predictor (affine scaling): factorise; on a non-positive pivot fall back to the
+            // Gauss-Newton Hessian, then to a larger Levenberg shift ----
+            // once the complementarity products sit at the barrier floor the predictor has nothing to predict
+            // (sigma ~ 0, second-order term ~ 0): take plain centring Newton steps, one sweep pair instead of three
+            const bool centring = !finishing && mu_cur <= fmaxf(1.5f * prm.mu_min, 0.15f * prm.tol) && ec <= fmaxf(4.f * prm.mu_min, 0.4f * prm.tol);
+            bool exact = prm.exact_hessian != 0;
+            float reg = prm.reg;
+            int fail = 1;
+            for (int attempt = 0; attempt < 4; ++attempt) {
+                fail = riccati_backward<NT, NC, FG>(lds, c, prm, tid, fg_base, exact, reg, centring ? prm.mu_min : 0.f);
+                if (!fail) break;
+                __syncthreads();
+                ++gn; exact = false;
+                if (attempt > 0) reg *= 1e3f;
+            }
+            if (fail) { if (!finishing) status = 2; break; }   // (a failed extrapolation step leaves the converged iterate)
+            PROF(11);
+            float ap, ad, sigma = 0.f, mu_t = prm.mu_min;
+            if (centring) {
+                for (int e = tid; e < NI * N; e += NT) c.dZ[e] = row_active(c, e / NI, e % NI) ? prm.mu_min : 0.f;
+                __syncthreads();
+                phase_forward<NT, NC, FG>(lds, N, fg_base, false);
+                PROF(15);
+            } else {
+            phase_forward<NT, NC, FG>(lds, N, fg_base, true);
+            PROF(12);
+            if (finishing) {
+                // last step: affine-scaling extrapolation of the central path to mu = 0 (primal only)
+                step_lengths<NT>(c, tid, 0.999f, ap, ad);
+                for (int e = tid; e < NS * (N + 1); e += NT) c.S[e] += ap * c.dS[e];
+                for (int e = tid; e < NU * N; e += NT) c.U[e] += ap * c.dU[e];
+                __syncthreads();
+                ++it;
+                break;
+            }
+            step_lengths<NT>(c, tid, 1.f, ap, ad);
+            double l_aff = 0.0;
+            for (int e = tid; e < NI * N; e += NT)
+                if (row_active(c, e / NI, e % NI)) l_aff += (double)(c.T[e] + ap * c.dT[e]) * (double)(c.Z[e] + ad * c.dZ[e]);
+            const float mu_aff = (float)(block_sum<NT>(l_aff, c.redd, tid) / (double)nrow);
+            sigma = mu_aff / mu_cur;
+            sigma = sigma * sigma * sigma;
+            mu_t = fmaxf(fmaxf(sigma, prm.sigma_min) * mu_cur, prm.mu_min);
+            // ---- corrector ----
+            for (int e = tid; e < NI * N; e += NT) {
+                const float cmu = row_active(c, e / NI, e % NI) ? mu_t - c.dT[e] * c.dZ[e] : 0.f;  // complementarity target
+                c.dZ[e] = cmu;
+                c.dT[e] = cmu / c.T[e];   // row coefficient change, read by the corrector sweep (dT is rebuilt by the forward sweep)
+            }
             __syncthreads();
-            ++gn; exact = false;
-            if (attempt > 0) reg *= 1e3f;
-        }
-        if (fail) { if (!finishing) status = 2; break; }   // (a failed extrapolation step leaves the converged iterate)
-        PROF(11);
-        float ap, ad, sigma = 0.f, mu_t = prm.mu_min;
-        if (centring) {
-            for (int e = tid; e < NI * N; e += NT) c.dZ[e] = row_active(c, e / NI, e % NI) ? prm.mu_min : 0.f;
-            __syncthreads();
+            PROF(13);
+            phase_delta<NT, NC, FG>(lds, N, fg_base);
+            PROF(14);
             phase_forward<NT, NC, FG>(lds, N, fg_base, false);
             PROF(15);
-        } else {
-        phase_forward<NT, NC, FG>(lds, N, fg_base, true);
-        PROF(12);
-        if (finishing) {
-            // last step: affine-scaling extrapolation of the central path to mu = 0 (primal only)
-            step_lengths<NT>(c, tid, 0.999f, ap, ad);
+            }
+            step_lengths<NT>(c, tid, fmaxf(0.99f, 1.f - mu_t), ap, ad);
+            // ---- costates, then the iterate ----
+            phase_costate<NT, NC, FG>(lds, N, fg_base, ap, exact);
+            PROF(16);
             for (int e = tid; e < NS * (N + 1); e += NT) c.S[e] += ap * c.dS[e];
             for (int e = tid; e < NU * N; e += NT) c.U[e] += ap * c.dU[e];
-            __syncthreads();
-            ++it;
-            break;
+            for (int e = tid; e < NI * N; e += NT) {
+                const float tn = c.T[e] + ap * c.dT[e];
+                float zn = c.Z[e] + ad * c.dZ[e];
+                c.T[e] = tn; c.Z[e] = zn;
+            }
+            // ---- convergence: the Newton step itself is the error estimate.  Flat directions of the cost
+            // (e.g. the internal force along the line joining the feet) are kept quiet by the Levenberg
+            // shift `reg`.  The stationarity residual of a float32-stored iterate cannot go below ~1e-3
+            // (one ulp of com_z moves its gradient by 2 w_z^2 ulp ~ 5e-3), so it is not the test. ----
+            // The step is measured on what the cost and the dynamics see: the states, the deviation of
+            // each corner force from its foot's mean, the force rate, the landing offsets.  A constant
+            // internal force along the line joining two stance feet changes none of them (the NLP does
+            // not determine it; it only drifts slowly towards the barrier's analytic centre).
+            // Force steps count relative to the largest corner-force component of the iterate (the parity tolerance is
+            // relative; forces are ~1-3 N/kg here), states and landing offsets absolutely (metres, m/s: order one or less).
+            float l_st = 0.f, l_sf = 0.f, l_fm = 1.f;
+            for (int e = tid; e < NS * (N + 1); e += NT) l_st = fmaxf(l_st, fabsf(c.dS[e]));
+            for (int e = tid; e < NU * N; e += NT) {
+                const int k = e / NU, m = e % NU;
+                const float du = c.dU[e];
+                if (m < NF) {
+                    const float* f = c.dU + NU * k + 12 * (m / 12) + m % 3;
+                    const float mean = 0.25f * (f[0] + f[3] + f[6] + f[9]);
+                    l_sf = fmaxf(l_sf, fabsf(du - gam_of(c, m / 12, k) * mean));
+                    if (k > 0) l_sf = fmaxf(l_sf, fabsf(du - c.dU[e - NU]));
+                    l_fm = fmaxf(l_fm, fabsf(c.U[e]));
+                } else l_st = fmaxf(l_st, fabsf(du));
+            }
+            const float fm = block_max<NT>(l_fm, c.red, tid);
+            const float step = ap * block_max<NT>(fmaxf(l_st, l_sf / fm), c.red, tid);
+            step_prev = step_out;
+            step_out = step;
+            err = fmaxf(ep, ec);
+    #ifdef CMPC_PROFILE
+            if (tid == 0 && b == 0 && it < 64) {
+                float* tr = g_trace + 8 * it;
+                tr[0] = mu_cur; tr[1] = ep; tr[2] = ec; tr[3] = step; tr[4] = ap; tr[5] = ad; tr[6] = sigma; tr[7] = mu_t;
+            }
+    #endif
+            PROF(17);
+            if (err <= prm.tol && step <= prm.step_tol) {
+                status = 0;
+                if (!prm.final_extrap) { ++it; break; }
+                finishing = true;
+            }
         }
-        step_lengths<NT>(c, tid, 1.f, ap, ad);
-        double l_aff = 0.0;
-        for (int e = tid; e < NI * N; e += NT)
-            if (row_active(c, e / NI, e % NI)) l_aff += (double)(c.T[e] + ap * c.dT[e]) * (double)(c.Z[e] + ad * c.dZ[e]);
-        const float mu_aff = (float)(block_sum<NT>(l_aff, c.redd, tid) / (double)nrow);
-        sigma = mu_aff / mu_cur;
-        sigma = sigma * sigma * sigma;
-        mu_t = fmaxf(fmaxf(sigma, prm.sigma_min) * mu_cur, prm.mu_min);
-        // ---- corrector ----
-        for (int e = tid; e < NI * N; e += NT) {
-            const float cmu = row_active(c, e / NI, e % NI) ? mu_t - c.dT[e] * c.dZ[e] : 0.f;  // complementarity target
-            c.dZ[e] = cmu;
-            c.dT[e] = cmu / c.T[e];   // row coefficient change, read by the corrector sweep (dT is rebuilt by the forward sweep)
-        }
+        it_total += it;
+        if (status == 0 || !kp.warm) break;
         __syncthreads();
-        PROF(13);
-        phase_delta<NT, NC, FG>(lds, N, fg_base);
-        PROF(14);
-        phase_forward<NT, NC, FG>(lds, N, fg_base, false);
-        PROF(15);
-        }
-        step_lengths<NT>(c, tid, fmaxf(0.99f, 1.f - mu_t), ap, ad);
-        // ---- costates, then the iterate ----
-        phase_costate<NT, NC, FG>(lds, N, fg_base, ap, exact);
-        PROF(16);
-        for (int e = tid; e < NS * (N + 1); e += NT) c.S[e] += ap * c.dS[e];
-        for (int e = tid; e < NU * N; e += NT) c.U[e] += ap * c.dU[e];
-        for (int e = tid; e < NI * N; e += NT) {
-            const float tn = c.T[e] + ap * c.dT[e];
-            float zn = c.Z[e] + ad * c.dZ[e];
-            c.T[e] = tn; c.Z[e] = zn;
-        }
-        // ---- convergence: the Newton step itself is the error estimate.  Flat directions of the cost
-        // (e.g. the internal force along the line joining the feet) are kept quiet by the Levenberg
-        // shift `reg`.  The stationarity residual of a float32-stored iterate cannot go below ~1e-3
-        // (one ulp of com_z moves its gradient by 2 w_z^2 ulp ~ 5e-3), so it is not the test. ----
-        // The step is measured on what the cost and the dynamics see: the states, the deviation of
-        // each corner force from its foot's mean, the force rate, the landing offsets.  A constant
-        // internal force along the line joining two stance feet changes none of them (the NLP does
-        // not determine it; it only drifts slowly towards the barrier's analytic centre).
-        // Force steps count relative to the largest corner-force component of the iterate (the parity tolerance is
-        // relative; forces are ~1-3 N/kg here), states and landing offsets absolutely (metres, m/s: order one or less).
-        float l_st = 0.f, l_sf = 0.f, l_fm = 1.f;
-        for (int e = tid; e < NS * (N + 1); e += NT) l_st = fmaxf(l_st, fabsf(c.dS[e]));
-        for (int e = tid; e < NU * N; e += NT) {
-            const int k = e / NU, m = e % NU;
-            const float du = c.dU[e];
-            if (m < NF) {
-                const float* f = c.dU + NU * k + 12 * (m / 12) + m % 3;
-                const float mean = 0.25f * (f[0] + f[3] + f[6] + f[9]);
-                l_sf = fmaxf(l_sf, fabsf(du - gam_of(c, m / 12, k) * mean));
-                if (k > 0) l_sf = fmaxf(l_sf, fabsf(du - c.dU[e - NU]));
-                l_fm = fmaxf(l_fm, fabsf(c.U[e]));
-            } else l_st = fmaxf(l_st, fabsf(du));
-        }
-        const float fm = block_max<NT>(l_fm, c.red, tid);
-        const float step = ap * block_max<NT>(fmaxf(l_st, l_sf / fm), c.red, tid);
-        step_prev = step_out;
-        step_out = step;
-        err = fmaxf(ep, ec);
-#ifdef CMPC_PROFILE
-        if (tid == 0 && b == 0 && it < 64) {
-            float* tr = g_trace + 8 * it;
-            tr[0] = mu_cur; tr[1] = ep; tr[2] = ec; tr[3] = step; tr[4] = ap; tr[5] = ad; tr[6] = sigma; tr[7] = mu_t;
-        }
-#endif
-        PROF(17);
-        if (err <= prm.tol && step <= prm.step_tol) {
-            status = 0;
-            if (!prm.final_extrap) { ++it; break; }
-            finishing = true;
-        }
     }
     // ---- export x in the reference layout ----
     {
@@ -1635,7 +1668,7 @@ __global__ __launch_bounds__(NT, FG ? 2 : 1) void cmpc_solve_kernel(CmpcParams k
         }
         if (kp.info && tid == 0) {
             float* inf = kp.info + (size_t)b * CMPC_INFO_N;
-            inf[0] = (float)it; inf[1] = err; inf[2] = mu_cur; inf[3] = (float)gn; inf[4] = ep; inf[5] = (float)status;
+            inf[0] = (float)it_total; inf[1] = err; inf[2] = mu_cur; inf[3] = (float)gn; inf[4] = ep; inf[5] = (float)status;
             inf[6] = (float)(__builtin_amdgcn_s_memtime() - t_start); inf[7] = step_out;
         }
         if (prm.dev[2] != 0.f) {  // developer probe: where the hardware put each wave (overwrites x[0..3]; HW_ID: wave slot

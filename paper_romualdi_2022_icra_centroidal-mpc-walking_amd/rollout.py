@@ -1,0 +1,136 @@
+"""Receding-horizon walking roll-out of a whole batch, resident in HBM: every tick is what the reference's two blocks do
+between them -- merge the planner's footsteps with the MPC-adjusted current contact (updateContactPhaseList,
+CentroidalMPCBlock.cpp:594-607), sample the list into the MPC's parameters (setContactPhaseList :609), feed the measured
+state (setState :407), warm-start from the shifted previous solution (is_warm_start_enabled), solve (advance :615), write
+the optimised landing position back into the list (getOutput :626) and integrate the centroidal dynamics under the
+first-knot forces until the next tick (WholeBodyQPBlock.cpp:1083-1150) -- as seven launches on one stream through the
+C ABI (include/cmpc.h); torch only owns the buffers.  SURVEY 8f-1 .. 8f-4 chained."""
+from __future__ import annotations
+
+import numpy as np
+
+from .contacts import PlannedContact, pack_lists
+from .layout import Layout
+from .solver import BatchSolver
+
+FOOT_Y = 0.08
+
+
+def walking_plan(cfg, steps=6, step_length=0.1, swing=0.48, double_support=0.12, first_lift=0.36):
+    """A periodic straight walk (absolute times from zero): the left foot lifts first at `first_lift`."""
+    names = [c.contact_name for c in cfg.contacts]
+    feet = {0: [PlannedContact(0.0, 0.0, (0.0, FOOT_Y, 0.0))], 1: [PlannedContact(0.0, 0.0, (0.0, -FOOT_Y, 0.0))]}
+    t, side = first_lift, 0
+    for s in range(steps):
+        other = feet[1 - side][-1]
+        feet[side][-1].deactivation_time = t
+        x = other.position[0] + step_length * (0.5 if s == 0 else 1.0)
+        feet[side].append(PlannedContact(t + swing, 0.0, (x, FOOT_Y if side == 0 else -FOOT_Y, 0.0)))
+        t += swing + double_support
+        side = 1 - side
+    for lst in feet.values():
+        lst[-1].deactivation_time = 1e9
+    return {names[0]: feet[0], names[1]: feet[1]}
+
+
+class WalkingRollout:
+    def __init__(self, cfg, batch, plan=None, device=0, substeps=6, com_speed=None, **solver_opts):
+        import torch
+        self.torch = torch
+        self.cfg, self.B = cfg, batch
+        self.L = Layout(cfg.N)
+        self.dev = torch.device("cuda", device)
+        self.solver = BatchSolver(cfg, batch, device=device, **solver_opts)
+        plan = plan or walking_plan(cfg)
+        t, pose, n = pack_lists(cfg, [plan])
+        M = t.shape[2] + 1     # the merged list holds at most the current contact + the planner's future contacts
+        tt = np.zeros((1, 2, M, 2)); pp = np.zeros((1, 2, M, 7), np.float32); pp[..., 3] = 1.0
+        tt[:, :, :M - 1] = t; pp[:, :, :M - 1] = pose
+        rep = lambda a: torch.from_numpy(np.ascontiguousarray(np.broadcast_to(a, (batch,) + a.shape[1:]))).to(self.dev)
+        self.plan = (rep(tt), rep(pp), rep(n))
+        self.M = M
+        self.substeps = substeps
+        # mean walking speed of the plan, for the CoM reference
+        if com_speed is None:
+            last = max(c.position[0] for lst in plan.values() for c in lst)
+            t_last = max(c.activation_time for lst in plan.values() for c in lst)
+            com_speed = last / t_last if t_last > 0 else 0.0
+        self.com_speed = com_speed
+
+    def run(self, ticks, com0, dcom0, h0, push=None, push_ticks=0, warm=True, dump=None):
+        """com0/dcom0/h0 [B,3] numpy; push [B,3] (mass-normalised force held for the first `push_ticks` ticks).
+        Returns a dict of per-tick numpy records."""
+        torch, L, cfg, B, N = self.torch, self.L, self.cfg, self.B, self.cfg.N
+        dt = cfg.sampling_time
+        dev = self.dev
+        s = self.solver
+        dP = torch.zeros((B, L.np), dtype=torch.float32, device=dev)
+        dX0 = torch.zeros((B, L.nx), dtype=torch.float32, device=dev)
+        dX = torch.zeros_like(dX0)
+        dInfo = torch.zeros((B, 8), dtype=torch.float32, device=dev)
+        state = torch.from_numpy(np.concatenate([com0, dcom0, h0], 1).astype(np.float32)).to(dev)
+        wrench = torch.zeros((B, N, 6), dtype=torch.float32, device=dev)
+        dpush = torch.from_numpy(np.asarray(push, np.float32)).to(dev) if push is not None else None
+        kk = torch.arange(N + 1, dtype=torch.float32, device=dev)
+        rec = dict(iterations_mean=[], iterations_max=[], converged=[], merge_ok=[], com=[], land=[], landing_offset=[], solve_ms=[], zmp=[])
+        mpc_prev = None
+        box_up = np.array([c.bounding_box_upper_limit for c in cfg.contacts])
+        box_lo = np.array([c.bounding_box_lower_limit for c in cfg.contacts])
+        for i in range(ticks):
+            now = i * dt
+            if mpc_prev is None:
+                lists = tuple(a.clone() for a in self.plan)
+                ok = torch.ones((B,), dtype=torch.int32, device=dev)
+            else:
+                lists, ok = s.contacts_merge_device(now, self.plan, mpc_prev)
+            land = s.contacts_sample_device(now, lists, dP)
+            # references at the knots (CentroidalMPCBlock.cpp:525-577 resamples the planner's; here a straight line)
+            ref = dP[:, L.p_comref:L.p_comref + 3 * (N + 1)].view(B, N + 1, 3)
+            ref[:, :, 0] = self.com_speed * (now + kk * dt)[None, :]
+            ref[:, :, 1] = 0.0
+            ref[:, :, 2] = 0.7
+            wrench.zero_()
+            if dpush is not None and i < push_ticks:
+                wrench[:, :max(push_ticks - i, 1), :3] = dpush[:, None, :]
+            s.write_state_device(state, dP, wrench)
+            if mpc_prev is None or not warm:
+                # cold start: CoM at com0, feet at nominal, f_z = g/8 per corner
+                dX0.zero_()
+                dX0[:, L.com:L.com + 3 * (N + 1)] = state[:, 0:3].repeat(1, N + 1)
+                for c in range(2):
+                    dX0[:, L.pos[c]:L.pos[c] + 3 * (N + 1)] = dP[:, L.p_nom[c]:L.p_nom[c] + 3 * (N + 1)]
+                    for j in range(4):
+                        dX0[:, L.f[c][j] + 2:L.f[c][j] + 3 * N:3] = 9.80665 / 8.0
+            else:
+                s.shift_solution_device(dX, dX0)
+            if dump is not None and i == dump[0]:   # developer hook: (tick, path) -> the tick's P and X0
+                np.savez(dump[1], P=dP.cpu().numpy(), X0=dX0.cpu().numpy())
+            s.solve_device(dP, dX0, dX, dInfo)
+            s.contacts_adjust_device(now, dX, land, lists)
+            mpc_prev = lists
+            state, zmp = s.plant_step_device(dX, dP, state, step=dt / self.substeps, substeps=self.substeps)
+            torch.cuda.synchronize()
+            info = dInfo.cpu().numpy()
+            rec["iterations_mean"].append(float(info[:, 0].mean()))
+            rec["iterations_max"].append(int(info[:, 0].max()))
+            rec["converged"].append(bool((info[:, 5] == 0).all()))
+            rec.setdefault("failed_info", []).append(info[info[:, 5] != 0])
+            rec["merge_ok"].append(bool(ok.cpu().numpy().all()))
+            rec["solve_ms"].append(s.last_solve_ms())
+            rec["com"].append(state[:, 0:3].cpu().numpy())
+            rec["zmp"].append(zmp.cpu().numpy())
+            ln = land.cpu().numpy()
+            rec["land"].append(ln)
+            # landing position against the nominal one of the same knot, in the foot frame (the bounding box the NLP imposes)
+            Xh, Ph = dX.cpu().numpy(), dP.cpu().numpy()
+            off = np.zeros((B, 2, 3))
+            for c in range(2):
+                for b in range(B):
+                    k = ln[b, c]
+                    if 0 < k <= N:
+                        R = Ph[b, L.p_R[c] + 9 * (k - 1):L.p_R[c] + 9 * k].reshape(3, 3).T   # vec(R) column-major
+                        d = Xh[b, L.pos[c] + 3 * k:L.pos[c] + 3 * k + 3] - Ph[b, L.p_nom[c] + 3 * k:L.p_nom[c] + 3 * k + 3]
+                        off[b, c] = R.T @ d
+            rec["landing_offset"].append(off)
+        rec["box_upper"], rec["box_lower"] = box_up, box_lo
+        return rec

@@ -165,6 +165,64 @@ class BatchSolver:
         return dStateOut, dZmp
 
 
+    # ---- SURVEY 8f-1 / 8f-2 on the device (torch CUDA tensors; everything stays in HBM) ----
+    def _launch(self, dev, fn):
+        """runs fn(raw_stream) on the solver's stream, ordered after torch's current stream and joined back into it"""
+        import torch
+        if self._stream is None:
+            self._stream = torch.cuda.Stream(dev)
+        cur = torch.cuda.current_stream(dev)
+        self._stream.wait_stream(cur)
+        rc = fn(self._stream.cuda_stream)
+        if rc != 0:
+            raise RuntimeError(f"libcmpc_hip call failed ({rc}): {self.last_error}")
+        cur.wait_stream(self._stream)
+
+    def contacts_merge_device(self, now, plan, mpc, out=None):
+        """updateContactPhaseList (CentroidalMPCBlock.cpp:32-110) for the batch: plan / mpc / out = (t[B,2,M,2] float64,
+        pose[B,2,M,7] float32, n[B,2] int32) CUDA tensors.  Returns (out, ok[B] int32)."""
+        import torch
+        pt, pp, pn = plan
+        mt, mp, mn = mpc
+        M = pt.shape[2]
+        if out is None:
+            out = (torch.zeros_like(pt), torch.zeros_like(pp), torch.zeros_like(pn))
+        ok = torch.empty((self.batch,), dtype=torch.int32, device=pt.device)
+        self._launch(pt.device, lambda st: self._lib.cmpc_contacts_merge_device(
+            self._h, M, float(now), pt.data_ptr(), pp.data_ptr(), pn.data_ptr(), mt.data_ptr(), mp.data_ptr(), mn.data_ptr(),
+            out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), ok.data_ptr(), st))
+        return out, ok
+
+    def contacts_sample_device(self, now, lists, dP, land=None):
+        """setContactPhaseList for the batch: samples `lists` at now + k dt into the contact blocks of dP[B,np]; returns
+        land[B,2] (landing knots)."""
+        import torch
+        t, pose, n = lists
+        if land is None:
+            land = torch.empty((self.batch, 2), dtype=torch.int32, device=dP.device)
+        up = np.ascontiguousarray([c.bounding_box_upper_limit for c in self.cfg.contacts], np.float32)
+        lo = np.ascontiguousarray([c.bounding_box_lower_limit for c in self.cfg.contacts], np.float32)
+        self._launch(dP.device, lambda st: self._lib.cmpc_contacts_sample_device(
+            self._h, t.shape[2], float(now), t.data_ptr(), pose.data_ptr(), n.data_ptr(), up.ctypes.data, lo.ctypes.data, dP.data_ptr(),
+            land.data_ptr(), st))
+        return land
+
+    def contacts_adjust_device(self, now, dX, land, lists):
+        """getOutput().contactPhaseList: the next contact of every foot landing inside the horizon takes x.pos[land] (in place)."""
+        t, pose, n = lists
+        self._launch(dX.device, lambda st: self._lib.cmpc_contacts_adjust_device(
+            self._h, t.shape[2], float(now), dX.data_ptr(), land.data_ptr(), t.data_ptr(), pose.data_ptr(), n.data_ptr(), st))
+
+    def write_state_device(self, dState, dP, dWrench=None):
+        """setState for the batch: dState[B,9] (+ dWrench[B,N,6]) into the rows of dP."""
+        self._launch(dP.device, lambda st: self._lib.cmpc_write_state_device(
+            self._h, dState.data_ptr(), dWrench.data_ptr() if dWrench is not None else None, dP.data_ptr(), st))
+
+    def shift_solution_device(self, dXprev, dX0):
+        """is_warm_start_enabled: dX0 = dXprev shifted by one knot; the next solve_device starts near the central path."""
+        self._launch(dX0.device, lambda st: self._lib.cmpc_shift_solution_device(self._h, dXprev.data_ptr(), dX0.data_ptr(), st))
+
+
 class CentroidalMPCOutput:
     """What getOutput() exposes downstream (WholeBodyQPBlock.cpp:824-829, 1319-1335): per contact
     the first-knot corner forces (world frame, mass-normalised) and pose, plus the step-adjusted

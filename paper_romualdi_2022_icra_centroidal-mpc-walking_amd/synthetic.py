@@ -9,7 +9,7 @@ from __future__ import annotations
 import numpy as np
 
 from . import config as _cfg
-from .contacts import PlannedContact, sample_schedule
+from .contacts import PlannedContact, pack_lists, sample_schedule, sample_schedule_batch
 from .layout import Layout, cold_start, pack_parameters
 
 ROBOT_MASS = 56.0  # kg, stated constant
@@ -101,8 +101,8 @@ def config5_footstep_candidates(B=8192, N=30, seed=3):
     cfg = _cfg.ergocub_gazebo_v1(N, 0.06)
     rng = np.random.default_rng(seed)
     dt, t_end = cfg.sampling_time, N * cfg.sampling_time
-    parts = []
-    for _ in range(B):
+    lists = []
+    for _ in range(B):  # the random draws only (their order defines the batch); the sampling below is vectorised
         step_T = rng.uniform(0.6, 0.9)
         ds = rng.uniform(0.12, 0.24)
         swing_left = bool(rng.integers(2))
@@ -125,9 +125,9 @@ def config5_footstep_candidates(B=8192, N=30, seed=3):
             for a, b in zip(lst[:-1], lst[1:]):
                 if a.deactivation_time <= a.activation_time:
                     a.deactivation_time = b.activation_time - (step_T - ds)
-        parts.append(sample_schedule(cfg, {cfg.contacts[0].contact_name: feet[True],
-                                           cfg.contacts[1].contact_name: feet[False]}))
-    sched = {k: np.stack([p[k] for p in parts]) for k in parts[0]}
+        lists.append({cfg.contacts[0].contact_name: feet[True], cfg.contacts[1].contact_name: feet[False]})
+    sched, _ = sample_schedule_batch(cfg, *pack_lists(cfg, lists))
+    sched = {k: v.astype(np.float64) for k, v in sched.items()}
     com0, dcom0, h0 = _perturbed_state(rng, B, (0.0, 0.0, 0.7))
     # CoM reference: constant-velocity drift towards the mean of the last nominal foot positions
     goal = 0.5 * (sched["nominal"][:, 0, -1] + sched["nominal"][:, 1, -1])
