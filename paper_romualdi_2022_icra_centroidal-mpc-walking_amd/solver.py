@@ -16,7 +16,7 @@ import numpy as np
 
 from . import _capi
 from .config import GRAVITY, CentroidalMPCConfig, from_ini
-from .contacts import PlannedContact, sample_schedule
+from .contacts import PlannedContact, pack_lists, sample_schedule, sample_schedule_batch
 from .layout import Layout
 
 
@@ -246,6 +246,7 @@ class CentroidalMPC:
         self._out: Optional[CentroidalMPCOutput] = None
         self.last_error = ""
         self._valid = False
+        self._now = 0.0
 
     # -- initialize(handler): handler = CentroidalMPCConfig, ini text, or dict of options
     def initialize(self, handler, **solver_opts) -> bool:
@@ -254,6 +255,7 @@ class CentroidalMPC:
             if not isinstance(cfg, CentroidalMPCConfig):
                 raise TypeError("initialize() needs a CentroidalMPCConfig or the text of a centroidal_mpc.ini")
             self.cfg = cfg
+            self._now = 0.0
             self._solver = BatchSolver(cfg, self._batch, self._device, **solver_opts)
             self._lib = self._solver._lib
             self._h = self._solver._h
@@ -311,23 +313,30 @@ class CentroidalMPC:
         return self._ok(self._lib.cmpc_set_reference_from_planner(self._h, c.ctypes.data, h.ctypes.data, c.shape[1], float(in_dt),
                                                                   float(t_offset), float(robot_mass), float(com_height)))
 
-    def set_contact_phase_list(self, lists, t0: float = 0.0) -> bool:
-        """lists: one dict {contact_name: [PlannedContact,...]} for every problem of the batch (or a
-        single dict shared by all), sampled by contacts.sample_schedule; or a dict of ready
-        tensors with keys R, upper, lower, enabled, nominal, current."""
+    def set_contact_phase_list(self, lists, t0: Optional[float] = None) -> bool:
+        """lists: one dict {contact_name: [PlannedContact,...]} for every problem of the batch (or a single dict shared
+        by all), with absolute times; or the packed arrays (t, pose, n) of contacts.pack_lists; or a dict of ready
+        tensors with keys R, upper, lower, enabled, nominal, current.  Lists are sampled at the knots now + k dt, where
+        `now` is the class's own clock: zero at initialize(), + dt per successful advance() -- the reference's caller
+        never passes the time, it advances its own clock the same way (CentroidalMPCBlock.cpp:631).  t0 overrides it."""
         if not self._need_init():
             return False
         B = self._batch
+        now = self._now if t0 is None else float(t0)
         try:
             if isinstance(lists, dict) and "R" in lists:
                 t = lists
             else:
-                if isinstance(lists, dict):
-                    one = sample_schedule(self.cfg, lists, t0)
-                    t = {k: np.broadcast_to(v, (B,) + v.shape) for k, v in one.items()}
+                if isinstance(lists, tuple):
+                    packed = lists
+                elif isinstance(lists, dict):
+                    packed = pack_lists(self.cfg, [lists])
                 else:
-                    parts = [sample_schedule(self.cfg, l, t0) for l in lists]
-                    t = {k: np.stack([p[k] for p in parts]) for k in parts[0]}
+                    packed = pack_lists(self.cfg, list(lists))
+                t, land = sample_schedule_batch(self.cfg, *packed, now)     # vectorised over the batch
+                if packed[0].shape[0] == 1 and B > 1:
+                    t = {k: np.broadcast_to(v, (B,) + v.shape[1:]) for k, v in t.items()}
+                self._lists = packed
             self._sched = t
             a = {k: np.ascontiguousarray(t[k], np.float32) for k in ("R", "upper", "lower", "enabled", "nominal", "current")}
         except Exception as e:
@@ -359,6 +368,7 @@ class CentroidalMPC:
         if not self._ok(self._lib.cmpc_get_output(self._h, f0.ctypes.data, p0.ctypes.data, pn.ctypes.data, kn.ctypes.data)):
             return False
         self._out = CentroidalMPCOutput([c.contact_name for c in self.cfg.contacts], f0, p0, pn, kn)
+        self._now += self.cfg.sampling_time
         self._valid = True
         return True
 
