@@ -10,7 +10,7 @@
  *     advance                 :615   -> cmpc_solve / cmpc_solve_device   (replaces CasADi Opti -> IPOPT)
  *     getOutput               :622   -> cmpc_get_solution / cmpc_get_output
  * and the NLP callbacks IPOPT would call (generated code config/robots/ergoCubGazeboV1/tmp.c:
- * nlp_fg :12430, nlp_jac_fg :71962, nlp_hess_l :58926) -> cmpc_eval_nlp_device.
+ * nlp_fg :12430, nlp_jac_fg :71962, nlp_hess_l :58926) -> cmpc_eval_nlp_device; nlp_grad :24791 -> cmpc_eval_nlp_grad_device.
  *
  * Conventions: plain C, no exceptions; every function returns 0 on success or a negative
  * cmpc_status; cmpc_last_error() gives the text.  The caller owns every buffer it passes; the
@@ -108,6 +108,11 @@ int cmpc_eval_nlp_device(cmpc_handle h, const float* dX, const float* dP, const 
                          float lam_f, float* dF, float* dG, float* dGradF, float* dJac,
                          float* dHess, void* stream);
 int cmpc_nlp_sparsity(int horizon, int* jac_row, int* jac_col, int* hess_row, int* hess_col);
+/* nlp_grad (tmp.c:24791): gradient of gamma = lam_f f + lam_g^T g with respect to x (dGradX[B][n_x]) and to the
+ * parameters (dGradP[B][n_p]; zero for limA/limB, currentPos, com0/dcom0/h0, which only enter the bounds).  Either
+ * output may be NULL. */
+int cmpc_eval_nlp_grad_device(cmpc_handle h, const float* dX, const float* dP, const float* dLamG, float lam_f,
+                              float* dGradX, float* dGradP, void* stream);
 
 /* ---- class-shaped setters (host buffers -> the handle's own device P, X0) ----
  * batch-major float32; NULL keeps the previous value (zeros initially).

@@ -46,6 +46,10 @@ int cmpc_nlp_jac(const cmpc_nlp_cfg* c, const double* x, const double* p, int* r
 int cmpc_nlp_hess(const cmpc_nlp_cfg* c, const double* x, const double* p, double lam_f,
                   const double* lam_g, int* row, int* col, double* val);
 
+/* nlp_grad: gradient of lam_f f + lam_g^T g w.r.t. x (gx[nx]) and p (gp[np]); either may be NULL */
+void cmpc_nlp_grad(const cmpc_nlp_cfg* c, const double* x, const double* p, double lam_f, const double* lam_g,
+                   double* gx, double* gp);
+
 /* ---- reference interior-point solver (ipm_ref.c): see that file's header ---- */
 typedef struct {
     int max_iter;       /* Newton iteration budget */

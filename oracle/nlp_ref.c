@@ -13,6 +13,7 @@
 #include "cmpc_oracle.h"
 
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 typedef struct {
@@ -379,4 +380,104 @@ int cmpc_nlp_hess(const cmpc_nlp_cfg* cfg, const double* x, const double* p, dou
         }
     }
     return n;
+}
+
+/* nlp_grad (tmp.c:24791-58842): gradient of gamma = lam_f f + lam_g^T g with respect to x and to p.
+ *   grad_gamma_x = lam_f grad f + J^T lam_g                        (from the two functions above)
+ *   grad_gamma_p: closed forms per parameter block.  limA, limB, currentPos, com0, dcom0, h0 do not enter f or g
+ *   (CasADi's Opti turns them into bounds), so their entries are zero. */
+void cmpc_nlp_grad(const cmpc_nlp_cfg* cfg, const double* x, const double* p, double lam_f, const double* lam_g,
+                   double* gx, double* gp)
+{
+    layout L;
+    const int N = cfg->N;
+    const double dt = cfg->dt;
+    int c, j, k, i, a, m, n;
+    layout_init(&L, N);
+    if (gx) {
+        const int nnzj = 243 * N + 15;
+        int* row = (int*)malloc(sizeof(int) * (size_t)nnzj * 2);
+        int* col = row + nnzj;
+        double* val = (double*)malloc(sizeof(double) * (size_t)nnzj);
+        cmpc_nlp_grad_f(cfg, x, p, gx);
+        for (i = 0; i < L.nx; ++i) gx[i] *= lam_f;
+        n = cmpc_nlp_jac(cfg, x, p, row, col, val);
+        for (i = 0; i < n; ++i) gx[col[i]] += val[i] * lam_g[row[i]];
+        free(row);
+        free(val);
+    }
+    if (!gp) return;
+    memset(gp, 0, sizeof(double) * (size_t)L.np);
+    /* cost: references and nominal positions enter as (x - p)^2 */
+    for (k = 0; k <= N; ++k) {
+        double w = wz(cfg, k);
+        for (i = 0; i < 3; ++i)
+            gp[L.p_href + 3 * k + i] = -lam_f * 2.0 * cfg->w_h * (x[L.o_h + 3 * k + i] - p[L.p_href + 3 * k + i]);
+        for (i = 0; i < 2; ++i)
+            gp[L.p_comref + 3 * k + i] = -lam_f * 2.0 * cfg->w_com[i] * (x[L.o_com + 3 * k + i] - p[L.p_comref + 3 * k + i]);
+        gp[L.p_comref + 3 * k + 2] = -lam_f * 2.0 * w * w * (x[L.o_com + 3 * k + 2] - p[L.p_comref + 3 * k + 2]);
+        for (c = 0; c < CMPC_NC; ++c)
+            for (i = 0; i < 3; ++i)
+                gp[L.p_nom[c] + 3 * k + i] = -lam_f * 2.0 * cfg->w_pos * (x[L.o_pos[c] + 3 * k + i] - p[L.p_nom[c] + 3 * k + i]);
+    }
+    for (k = 0; k < N; ++k) {
+        const double* com = x + L.o_com + 3 * k;
+        const double* ld = lam_g + L.g_dcom + 3 * k;
+        const double* lh = lam_g + L.g_h + 3 * k;
+        for (i = 0; i < 3; ++i) {
+            gp[L.p_fext + 3 * k + i] = -dt * ld[i];
+            gp[L.p_text + 3 * k + i] = -dt * lh[i];
+        }
+        for (c = 0; c < CMPC_NC; ++c) {
+            const double* R = p + L.p_R[c] + 9 * k; /* col-major: R(row, col) = R[3 col + row] */
+            const double* pos = x + L.o_pos[c] + 3 * k;
+            const double* posn = x + L.o_pos[c] + 3 * (k + 1);
+            const double* vel = x + L.o_vel[c] + 3 * k;
+            const double* nomn = p + L.p_nom[c] + 3 * (k + 1);
+            const double* lp = lam_g + L.g_pos[c] + 3 * k;
+            const double* lb = lam_g + L.g_bbox[c] + 3 * k;
+            const double gam = p[L.p_gam[c] + k];
+            double* gR = gp + L.p_R[c] + 9 * k;
+            double dgam = 0.0, mean[3] = {0, 0, 0}, esum[3] = {0, 0, 0}, d[3];
+            for (j = 0; j < CMPC_NCORN; ++j)
+                for (i = 0; i < 3; ++i) mean[i] += 0.25 * x[L.o_f[c][j] + 3 * k + i];
+            for (j = 0; j < CMPC_NCORN; ++j) {
+                const double* fc = x + L.o_f[c][j] + 3 * k;
+                const double* cn = cfg->corners[c][j];
+                const double* lf = lam_g + L.g_fric[c] + 16 * k + 4 * j;
+                double r[3], t[3], fxl[3], coef[3] = {0, 0, 0};
+                for (i = 0; i < 3; ++i) {
+                    r[i] = R[i] * cn[0] + R[3 + i] * cn[1] + R[6 + i] * cn[2] + pos[i] - com[i];
+                    esum[i] += fc[i] - gam * mean[i];
+                }
+                cross(r, fc, t);
+                cross(fc, lh, fxl);
+                /* rows g_dcom, g_h: -dt gam (f, r x f) */
+                for (i = 0; i < 3; ++i) dgam += -dt * (ld[i] * fc[i] + lh[i] * t[i]);
+                /* lam_h . (r x f) = r . (f x lam_h), r = R cn + ...: d/dR(row, col) = cn[col] (f x lam_h)[row] */
+                for (m = 0; m < 3; ++m)
+                    for (a = 0; a < 3; ++a) gR[3 * m + a] += -dt * gam * cn[m] * fxl[a];
+                /* friction rows: sum_face lam (sx, sy, -mu)_m (R^T f)_m, (R^T f)_m = sum_a R(a, m) f_a */
+                for (i = 0; i < 4; ++i) {
+                    coef[0] += lf[i] * FR_SX[i];
+                    coef[1] += lf[i] * FR_SY[i];
+                    coef[2] += -lf[i] * cfg->mu;
+                }
+                for (m = 0; m < 3; ++m)
+                    for (a = 0; a < 3; ++a) gR[3 * m + a] += coef[m] * fc[a];
+            }
+            /* symmetry cost: sum_j sum_i w_sym (f_ji - gam mean_i)^2 */
+            for (i = 0; i < 3; ++i) dgam += -lam_f * 2.0 * cfg->w_sym * mean[i] * esum[i];
+            /* foot dynamics row: pos+ - (pos + dt (1 - gam) vel) */
+            for (i = 0; i < 3; ++i) dgam += dt * lp[i] * vel[i];
+            gp[L.p_gam[c] + k] = dgam;
+            /* bounding-box rows: (R^T d)_i, d = pos+ - nominal+ */
+            for (i = 0; i < 3; ++i) d[i] = posn[i] - nomn[i];
+            for (i = 0; i < 3; ++i)
+                for (a = 0; a < 3; ++a) {
+                    gR[3 * i + a] += lb[i] * d[a];
+                    gp[L.p_nom[c] + 3 * (k + 1) + a] += -lb[i] * R[3 * i + a];
+                }
+        }
+    }
 }

@@ -136,6 +136,20 @@ def nlp_hess(cfg, x, p, lam_f, lam_g):
     return row, col, val
 
 
+def nlp_grad(cfg, x, p, lam_f, lam_g):
+    """nlp_grad (tmp.c:24791): -> (grad_gamma_x[nx], grad_gamma_p[np]) of gamma = lam_f f + lam_g^T g."""
+    nx, npar = dims(cfg)[:2]
+    x = np.ascontiguousarray(x, np.float64)
+    p = np.ascontiguousarray(p, np.float64)
+    lam_g = np.ascontiguousarray(lam_g, np.float64)
+    gx, gp = np.zeros(nx), np.zeros(npar)
+    fn = lib().cmpc_nlp_grad
+    fn.restype = None
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]
+    fn(C.addressof(cfg), x.ctypes.data, p.ctypes.data, float(lam_f), lam_g.ctypes.data, gx.ctypes.data, gp.ctypes.data)
+    return gx, gp
+
+
 def ipm_opts(max_iter=60, tol=1e-9, mu_init=0.1, mu_min=1e-10, exact_hessian=1, verbose=0):
     o = IpmOpts()
     o.max_iter, o.tol, o.mu_init, o.mu_min, o.exact_hessian, o.verbose = max_iter, tol, mu_init, mu_min, exact_hessian, verbose

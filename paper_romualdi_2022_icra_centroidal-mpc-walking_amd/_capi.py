@@ -41,7 +41,7 @@ EXPORTS = [
     "cmpc_get_output", "cmpc_set_reference_from_planner", "cmpc_plant_step_device", "cmpc_test_poison_lds",
     "cmpc_compact_output_device", "cmpc_contacts_merge", "cmpc_contacts_merge_device", "cmpc_contacts_sample",
     "cmpc_contacts_sample_device", "cmpc_set_contact_lists", "cmpc_contacts_adjust", "cmpc_contacts_adjust_device",
-    "cmpc_write_state_device", "cmpc_shift_solution_device",
+    "cmpc_write_state_device", "cmpc_shift_solution_device", "cmpc_eval_nlp_grad_device",
 ]
 
 _lib = None
@@ -99,5 +99,6 @@ def lib():
         L.cmpc_contacts_adjust_device.argtypes = [vp, i, d, vp, vp, vp, vp, vp, vp]
         L.cmpc_write_state_device.argtypes = [vp, fp, fp, fp, vp]
         L.cmpc_shift_solution_device.argtypes = [vp, fp, fp, vp]
+        L.cmpc_eval_nlp_grad_device.argtypes = [vp, fp, fp, fp, C.c_float, fp, fp, vp]
         _lib = L
     return _lib

@@ -16,6 +16,8 @@ extern "C" int cmpc_launch_solver(const CmpcParams* prm, size_t lds_bytes, hipSt
 extern "C" int cmpc_launch_nlp_eval(const CmpcParams* prm, const float* dX, const float* dP, const float* dLamG,
                                     float lam_f, float* dF, float* dG, float* dGradF, float* dJac, float* dHess,
                                     hipStream_t stream);
+extern "C" int cmpc_launch_nlp_grad(const CmpcParams* prm, const float* dX, const float* dP, const float* dLamG, float lam_f, float* dGradX,
+                                    float* dGradP, hipStream_t stream);
 extern "C" int cmpc_launch_warm_shift(const CmpcParams* prm, const float* dXprev, float* dX0, hipStream_t stream);
 extern "C" int cmpc_launch_contacts_merge(int B, int M, double now, const double* plan_t, const float* plan_pose, const int* plan_n,
                                           const double* mpc_t, const float* mpc_pose, const int* mpc_n, double* out_t, float* out_pose,
@@ -549,6 +551,17 @@ int cmpc_eval_nlp_device(cmpc_handle h, const float* dX, const float* dP, const 
     return CMPC_OK;
 }
 
+int cmpc_eval_nlp_grad_device(cmpc_handle h, const float* dX, const float* dP, const float* dLamG, float lam_f, float* dGradX, float* dGradP,
+                              void* stream)
+{
+    if (!h || !dX || !dP || !dLamG) return fail(h, CMPC_ERR_ARG, "cmpc_eval_nlp_grad_device: null argument");
+    HIPCHK(h, hipSetDevice(h->device));
+    CmpcParams p;
+    fill_params(h, p);
+    int rc = cmpc_launch_nlp_grad(&p, dX, dP, dLamG, lam_f, dGradX, dGradP, stream ? (hipStream_t)stream : h->stream);
+    if (rc != 0) return fail(h, CMPC_ERR_HIP, std::string("nlp grad launch: ") + hipGetErrorString((hipError_t)rc));
+    return CMPC_OK;
+}
 
 // ---- 8f-3: planner references -> MPC knots (CentroidalMPCBlock.cpp:525-577): angular momentum / mass, CoM height
 // override, linear spline from the planner's knots (period in_dt, first knot t_offset in the past) to the N+1 MPC

@@ -286,6 +286,176 @@ __global__ __launch_bounds__(256) void cmpc_nlp_eval_kernel(CmpcParams kp, const
     }
 }
 
+// nlp_grad (tmp.c:24791-58842): gradient of gamma = lam_f f + lam_g^T g with respect to x and to p, batched.  One
+// workgroup per problem, x / p / lam_g staged in LDS, every output element one thread's closed form (J^T lam_g is
+// written out per x-block instead of scattering the Jacobian's non-zeros).  Parameter blocks that do not enter f or g
+// (limA, limB, currentPos, com0, dcom0, h0: CasADi's Opti turns them into bounds) get zeros, as in the reference.
+__global__ __launch_bounds__(256) void cmpc_nlp_grad_kernel(CmpcParams kp, const float* __restrict__ X, const float* __restrict__ P,
+                                                            const float* __restrict__ LamG, float lam_f, float* __restrict__ GradX,
+                                                            float* __restrict__ GradP)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, NT = 256;
+    const int b = blockIdx.x;
+    const int N = kp.N;
+    CmpcConsts& K = *reinterpret_cast<CmpcConsts*>(smem);
+    {
+        const int* src = reinterpret_cast<const int*>(kp.kc);
+        int* dst = reinterpret_cast<int*>(smem);
+        for (int e = tid; e < (int)(sizeof(CmpcConsts) / 4); e += NT) dst[e] = src[e];
+    }
+    const CmpcIdx L{N};
+    GLay G;
+    glay_init(G, N);
+    float* x = reinterpret_cast<float*>(smem + ((sizeof(CmpcConsts) + 15) & ~15));
+    float* p = x + ((L.nx() + 3) & ~3);
+    float* lam = p + ((L.np() + 3) & ~3);
+    for (int e = tid; e < L.nx(); e += NT) x[e] = X[(size_t)b * L.nx() + e];
+    for (int e = tid; e < L.np(); e += NT) p[e] = P[(size_t)b * L.np() + e];
+    for (int e = tid; e < L.ng(); e += NT) lam[e] = LamG[(size_t)b * L.ng() + e];
+    __syncthreads();
+    const float dt = K.dt;
+    auto gam = [&](int c, int k) { return p[L.pGam(c) + k]; };
+    auto rvec = [&](int c, int j, int k, float* r) {
+        const float* R = p + L.pR(c) + 9 * k;
+        const float* cn = K.corners + 12 * c + 3 * j;
+        for (int i = 0; i < 3; ++i)
+            r[i] = R[i] * cn[0] + R[3 + i] * cn[1] + R[6 + i] * cn[2] + x[L.oPos(c) + 3 * k + i] - x[L.oCom() + 3 * k + i];
+    };
+    auto fcsum = [&](int c, int k, float* Fc) {
+        for (int i = 0; i < 3; ++i)
+            Fc[i] = x[L.oF(c, 0) + 3 * k + i] + x[L.oF(c, 1) + 3 * k + i] + x[L.oF(c, 2) + 3 * k + i] + x[L.oF(c, 3) + 3 * k + i];
+    };
+    auto crossc = [](const float* a, const float* bb, int i) { return a[(i + 1) % 3] * bb[(i + 2) % 3] - a[(i + 2) % 3] * bb[(i + 1) % 3]; };
+    // d f / d (force component): symmetry + rate terms (as in the grad f branch of cmpc_nlp_eval_kernel)
+    auto gradf_force = [&](int c, int k, int i, int e) {
+        const float g = gam(c, k);
+        float mean = 0.f;
+        for (int l = 0; l < 4; ++l) mean += 0.25f * x[L.oF(c, l) + 3 * k + i];
+        const float es = x[e] - g * mean, esum = 4.f * mean * (1.f - g);
+        float v = 2.f * K.w_sym * (es - 0.25f * g * esum);
+        if (k > 0) v += K.D[i] * (x[e] - x[e - 3]);
+        if (k + 1 < N) v -= K.D[i] * (x[e + 3] - x[e]);
+        return v;
+    };
+
+    if (GradX) {
+        float* gx = GradX + (size_t)b * L.nx();
+        for (int e = tid; e < L.nx(); e += NT) {
+            float v;
+            if (e < L.oPos(0)) {  // com | dcom | h : 3 x (N+1) each
+                const int blk = e / (3 * (N + 1)), e2 = e % (3 * (N + 1)), k = e2 / 3, i = e2 % 3;
+                const int grow = blk == 0 ? G.g_com : (blk == 1 ? G.g_dcom : G.g_h);
+                v = k == 0 ? lam[G.g_init + 3 * blk + i] : lam[grow + 3 * (k - 1) + i];
+                if (k < N) v -= lam[grow + 3 * k + i];
+                if (blk == 0) {
+                    v += lam_f * (i == 0 ? 2.f * K.w_com0 : (i == 1 ? 2.f * K.w_com1 : K.wz2[k])) * (x[e] - p[L.pComref() + e2]);
+                    if (k < N) {  // rows g_h: -dt [Fsum]x  ->  -dt (lam_h x Fsum)
+                        float F0[3], F1[3], Fs[3];
+                        fcsum(0, k, F0);
+                        fcsum(1, k, F1);
+                        for (int a = 0; a < 3; ++a) Fs[a] = gam(0, k) * F0[a] + gam(1, k) * F1[a];
+                        v -= dt * crossc(lam + G.g_h + 3 * k, Fs, i);
+                    }
+                } else if (blk == 1) {
+                    if (k < N) v -= dt * lam[G.g_com + 3 * k + i];
+                } else v += lam_f * 2.f * K.w_h * (x[e] - p[L.pHref() + e2]);
+            } else {
+                const int c = e < L.oPos(1) ? 0 : 1;
+                const int e2 = e - L.oPos(c);
+                if (e2 < 3 * (N + 1)) {  // pos
+                    const int k = e2 / 3, a = e2 % 3;
+                    v = lam_f * 2.f * K.w_pos * (x[e] - p[L.pNom(c) + e2]);
+                    if (k == 0) v += lam[G.g_init + 9 + 3 * c + a];
+                    else {
+                        const float* R = p + L.pR(c) + 9 * (k - 1);
+                        const float* lb = lam + G.g_bbox[c] + 3 * (k - 1);
+                        v += lam[G.g_pos[c] + 3 * (k - 1) + a] + lb[0] * R[a] + lb[1] * R[3 + a] + lb[2] * R[6 + a];
+                    }
+                    if (k < N) {
+                        float Fc[3];
+                        fcsum(c, k, Fc);
+                        v += -lam[G.g_pos[c] + 3 * k + a] + dt * gam(c, k) * crossc(lam + G.g_h + 3 * k, Fc, a);
+                    }
+                } else if (e2 < 3 * (N + 1) + 3 * N) {  // vel
+                    const int e3 = e2 - 3 * (N + 1), k = e3 / 3;
+                    v = -dt * (1.f - gam(c, k)) * lam[G.g_pos[c] + e3];
+                } else {  // corner forces
+                    const int e3 = e2 - 3 * (N + 1) - 3 * N, j = e3 / (3 * N), k = (e3 % (3 * N)) / 3, a = e3 % 3;
+                    const float g = gam(c, k);
+                    const float* R = p + L.pR(c) + 9 * k;
+                    const float* lf = lam + G.g_fric[c] + 16 * k + 4 * j;
+                    float rr[3];
+                    rvec(c, j, k, rr);
+                    v = lam_f * gradf_force(c, k, a, e) - dt * g * (lam[G.g_dcom + 3 * k + a] + crossc(lam + G.g_h + 3 * k, rr, a));
+                    const float cx = lf[0] - lf[1] - lf[2] + lf[3], cy = lf[0] + lf[1] - lf[2] - lf[3], cz = -K.mu_fr * (lf[0] + lf[1] + lf[2] + lf[3]);
+                    v += cx * R[a] + cy * R[3 + a] + cz * R[6 + a];
+                }
+            }
+            gx[e] = v;
+        }
+    }
+    if (GradP) {
+        float* gp = GradP + (size_t)b * L.np();
+        for (int e = tid; e < L.np(); e += NT) {
+            float v = 0.f;
+            if (e < L.pCom0()) {
+                const int c = e < L.pR(1) ? 0 : 1;
+                const int e2 = e - L.pR(c);
+                if (e2 < 9 * N) {  // R(a, m) at 9 k + 3 m + a
+                    const int k = e2 / 9, m = (e2 % 9) / 3, a = e2 % 3;
+                    const float g = gam(c, k);
+                    const float* lh = lam + G.g_h + 3 * k;
+                    for (int j = 0; j < 4; ++j) {
+                        const float* f = x + L.oF(c, j) + 3 * k;
+                        const float* lf = lam + G.g_fric[c] + 16 * k + 4 * j;
+                        const float coef = m == 0 ? (lf[0] - lf[1] - lf[2] + lf[3]) : (m == 1 ? (lf[0] + lf[1] - lf[2] - lf[3]) : -K.mu_fr * (lf[0] + lf[1] + lf[2] + lf[3]));
+                        v += -dt * g * K.corners[12 * c + 3 * j + m] * crossc(f, lh, a) + coef * f[a];
+                    }
+                    v += lam[G.g_bbox[c] + 3 * k + m] * (x[L.oPos(c) + 3 * (k + 1) + a] - p[L.pNom(c) + 3 * (k + 1) + a]);
+                } else if (e2 < 15 * N) {
+                    v = 0.f;   // limA, limB
+                } else if (e2 < 16 * N) {  // Gamma
+                    const int k = e2 - 15 * N;
+                    const float g = gam(c, k);
+                    const float* ld = lam + G.g_dcom + 3 * k;
+                    const float* lh = lam + G.g_h + 3 * k;
+                    float mean[3] = {0.f, 0.f, 0.f}, esum[3];
+                    for (int j = 0; j < 4; ++j)
+                        for (int i = 0; i < 3; ++i) mean[i] += 0.25f * x[L.oF(c, j) + 3 * k + i];
+                    for (int i = 0; i < 3; ++i) esum[i] = 4.f * mean[i] * (1.f - g);
+                    for (int j = 0; j < 4; ++j) {
+                        const float* f = x + L.oF(c, j) + 3 * k;
+                        float rr[3];
+                        rvec(c, j, k, rr);
+                        for (int i = 0; i < 3; ++i) v -= dt * (ld[i] * f[i] + lh[i] * crossc(rr, f, i));
+                    }
+                    for (int i = 0; i < 3; ++i)
+                        v += -lam_f * 2.f * K.w_sym * mean[i] * esum[i] + dt * lam[G.g_pos[c] + 3 * k + i] * x[L.oVel(c) + 3 * k + i];
+                } else if (e2 < 16 * N + 3 * (N + 1)) {  // nominalPos
+                    const int e3 = e2 - 16 * N, k = e3 / 3, a = e3 % 3;
+                    v = -lam_f * 2.f * K.w_pos * (x[L.oPos(c) + e3] - p[e]);
+                    if (k > 0) {
+                        const float* R = p + L.pR(c) + 9 * (k - 1);
+                        const float* lb = lam + G.g_bbox[c] + 3 * (k - 1);
+                        v -= lb[0] * R[a] + lb[1] * R[3 + a] + lb[2] * R[6 + a];
+                    }
+                }   // currentPos: 0
+            } else if (e >= L.pComref() && e < L.pHref()) {
+                const int e2 = e - L.pComref(), k = e2 / 3, i = e2 % 3;
+                v = -lam_f * (i == 0 ? 2.f * K.w_com0 : (i == 1 ? 2.f * K.w_com1 : K.wz2[k])) * (x[L.oCom() + e2] - p[e]);
+            } else if (e >= L.pHref() && e < L.pFext()) {
+                v = -lam_f * 2.f * K.w_h * (x[L.oH() + e - L.pHref()] - p[e]);
+            } else if (e >= L.pFext() && e < L.pText()) {
+                v = -dt * lam[G.g_dcom + e - L.pFext()];
+            } else if (e >= L.pText()) {
+                v = -dt * lam[G.g_h + e - L.pText()];
+            }   // com0, dcom0, h0: 0
+            gp[e] = v;
+        }
+    }
+}
+
 // warm start: previous solution shifted by one knot (last knot repeated); is_warm_start_enabled of
 // the reference (ergoCubGazeboV1/centroidal_mpc.ini:9)
 __global__ __launch_bounds__(256) void cmpc_warm_shift_kernel(int N, int B, const float* __restrict__ Xp, float* __restrict__ X0)
@@ -443,6 +613,16 @@ extern "C" int cmpc_launch_nlp_eval(const CmpcParams* prm, const float* dX, cons
     const size_t lds = ((sizeof(CmpcConsts) + 15) & ~(size_t)15) + 4 * (size_t)(((L.nx + 3) & ~3) + ((L.np + 3) & ~3) + ((L.ng + 3) & ~3) + 8);
     hipLaunchKernelGGL(cmpc_nlp_eval_kernel, dim3(prm->B), dim3(256), lds, stream, *prm, dX, dP, dLamG, lam_f, dF, dG, dGradF, dJac, dHess,
                        g_cache.dJ, g_cache.dH, g_cache.nnzj, g_cache.nnzh);
+    return (int)hipGetLastError();
+}
+
+extern "C" int cmpc_launch_nlp_grad(const CmpcParams* prm, const float* dX, const float* dP, const float* dLamG, float lam_f, float* dGradX,
+                                    float* dGradP, hipStream_t stream)
+{
+    CmpcLayout L;
+    cmpc_layout_init(L, prm->N);
+    const size_t lds = ((sizeof(CmpcConsts) + 15) & ~(size_t)15) + 4 * (size_t)(((L.nx + 3) & ~3) + ((L.np + 3) & ~3) + ((L.ng + 3) & ~3) + 8);
+    hipLaunchKernelGGL(cmpc_nlp_grad_kernel, dim3(prm->B), dim3(256), lds, stream, *prm, dX, dP, dLamG, lam_f, dGradX, dGradP);
     return (int)hipGetLastError();
 }
 

@@ -3,8 +3,8 @@
 Run in the build container (needs oracle/_ref, i.e. /root/reference):
     python tests/golden/make_nlp_golden.py
 Inputs: seeded random (x, p, lam_f, lam_g) -- random Gamma and R exercise every term -- plus one
-physically meaningful standing state.  Outputs: f, g, grad f, jac g (CCS nnz), hess L (CCS nnz)
-evaluated by oracle/_ref/libnlp_{tmp,jit}.so (= tmp.c / jit_tmpComMiH.c compiled as is), and the
+physically meaningful standing state.  Outputs: f, g, grad f, jac g (CCS nnz), hess L (CCS nnz) and nlp_grad's
+grad_gamma_x / grad_gamma_p (tmp.c:24791), evaluated by oracle/_ref/libnlp_{tmp,jit}.so (= tmp.c / jit_tmpComMiH.c compiled as is), and the
 CCS sparsity tables (tmp.c:66-67).  These are data (vectors), not reference source.
 """
 import os
@@ -51,7 +51,7 @@ def main():
     for which in ("tmp", "jit"):
         ref = ref_nlp.RefNLP(which)
         rng = np.random.default_rng(20221 if which == "tmp" else 20222)
-        X, P, LF, LG, F, G, GF, JN, HN = [], [], [], [], [], [], [], [], []
+        X, P, LF, LG, F, G, GF, JN, HN, GX, GP = [], [], [], [], [], [], [], [], [], [], []
         _, _, jc, jr = ref.sparsity("nlp_jac_fg", "out", 3)
         _, _, hc, hr = ref.sparsity("nlp_hess_l", "out", 0)
         jcol = np.repeat(np.arange(ref_nlp.NX), np.diff(jc))
@@ -66,6 +66,9 @@ def main():
             lg = rng.normal(size=ref_nlp.NG)
             f, gf, g, J = ref.jac_fg(x, p)
             H = ref.hess_l(x, p, lf, lg)
+            f2, g2, gx, gp = ref.grad(x, p, lf, lg)
+            assert f2 == f and (g2 == g).all()
+            GX.append(gx); GP.append(gp)
             X.append(x); P.append(p); LF.append(lf); LG.append(lg)
             F.append(f); G.append(g); GF.append(gf)
             JN.append(J[jr, jcol]); HN.append(H[hr, hcol])
@@ -73,7 +76,7 @@ def main():
             os.path.join(out_dir, f"nlp_{which}.npz"),
             N=N, dt=0.1, x=np.array(X), p=np.array(P), lam_f=np.array(LF), lam_g=np.array(LG),
             f=np.array(F), g=np.array(G), grad_f=np.array(GF), jac_nnz=np.array(JN),
-            hess_nnz=np.array(HN), jac_colind=jc, jac_row=jr, hess_colind=hc, hess_row=hr)
+            hess_nnz=np.array(HN), grad_gamma_x=np.array(GX), grad_gamma_p=np.array(GP), jac_colind=jc, jac_row=jr, hess_colind=hc, hess_row=hr)
         print(which, "written")
 
 

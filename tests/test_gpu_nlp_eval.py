@@ -78,3 +78,45 @@ def test_callbacks_match_oracle_at_n20():
         r, c, v = ol.nlp_hess(oc, x, p, 0.7, LamG[b].astype(np.float64))
         Hd = np.zeros((L.nx, L.nx)); np.add.at(Hd, (r, c), v)
         _close(H[b], Hd[hr, hc])
+
+
+def _grad(cfg, X, P, lam_f, LamG):
+    import ctypes as C
+
+    import torch
+    B = X.shape[0]
+    L = cm.Layout(cfg.N)
+    s = cm.BatchSolver(cfg, B)
+    dX, dP, dL = (torch.from_numpy(np.ascontiguousarray(a, np.float32)).cuda() for a in (X, P, LamG))
+    GX = torch.empty(B, L.nx, device="cuda"); GP = torch.empty(B, L.np, device="cuda")
+    rc = cm._capi.lib().cmpc_eval_nlp_grad_device(s._h, dX.data_ptr(), dP.data_ptr(), dL.data_ptr(), C.c_float(lam_f), GX.data_ptr(),
+                                                  GP.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    assert rc == 0, s.last_error
+    torch.cuda.synchronize()
+    return GX.cpu().numpy().astype(np.float64), GP.cpu().numpy().astype(np.float64)
+
+
+@pytest.mark.parametrize("which", ["tmp", "jit"])
+def test_nlp_grad_matches_reference_generated_code(which, golden_dir):
+    """nlp_grad (tmp.c:24791): grad_gamma_x and grad_gamma_p against the vectors made from the reference's compiled code."""
+    d = np.load(os.path.join(golden_dir, f"nlp_{which}.npz"))
+    cfg = cm.config.generated_code_weights(which)
+    for t in range(d["x"].shape[0]):   # lam_f differs per sample: one launch each
+        GX, GP = _grad(cfg, d["x"][t:t + 1], d["p"][t:t + 1], float(d["lam_f"][t]), d["lam_g"][t:t + 1])
+        _close(GX[0], d["grad_gamma_x"][t]); _close(GP[0], d["grad_gamma_p"][t])
+        assert (GP[0][d["grad_gamma_p"][t] == 0] == 0).all()
+
+
+def test_nlp_grad_matches_oracle_at_n20_and_n30():
+    from oracle import oracle_lib as ol, problem_nlp
+    for gen in (cm.synthetic.config3_external_push, cm.synthetic.config5_footstep_candidates):
+        cfg, P, X0 = gen(4)
+        rng = np.random.default_rng(6)
+        X = (X0 + 0.05 * rng.normal(size=X0.shape)).astype(np.float32)
+        P32 = P.astype(np.float32)
+        LamG = rng.normal(size=(4, cm.Layout(cfg.N).ng)).astype(np.float32)
+        GX, GP = _grad(cfg, X, P32, -0.6, LamG)
+        oc = problem_nlp.oracle_cfg(cfg)
+        for b in range(4):
+            gx, gp = ol.nlp_grad(oc, X[b].astype(np.float64), P32[b].astype(np.float64), -0.6, LamG[b].astype(np.float64))
+            _close(GX[b], gx); _close(GP[b], gp)

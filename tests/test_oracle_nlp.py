@@ -49,6 +49,11 @@ def test_restatement_matches_golden(which, golden_dir):
         pat = np.zeros((nx, nx), bool); pat[r, c] = True
         ref = np.zeros((nx, nx), bool); ref[d["hess_row"], hcol] = True
         assert (pat == ref).all()  # casadi_s4, tmp.c:66
+        # nlp_grad (tmp.c:24791): gradient of lam_f f + lam_g^T g w.r.t. x and w.r.t. the parameters
+        gx, gp = ol.nlp_grad(cfg, x, p, d["lam_f"][t], d["lam_g"][t])
+        np.testing.assert_allclose(gx, d["grad_gamma_x"][t], rtol=0, atol=1e-12 * np.abs(d["grad_gamma_x"][t]).max())
+        np.testing.assert_allclose(gp, d["grad_gamma_p"][t], rtol=0, atol=1e-12 * np.abs(d["grad_gamma_p"][t]).max())
+        assert ((gp != 0) == (d["grad_gamma_p"][t] != 0)).all()   # limA/limB, currentPos, com0/dcom0/h0 never enter f, g
 
 
 @pytest.mark.parametrize("which", ["tmp", "jit"])
@@ -73,6 +78,10 @@ def test_restatement_matches_compiled_reference(which):
         np.testing.assert_allclose(_dense((ng, nx), *ol.nlp_jac(cfg, x, p)), J0, atol=1e-12)
         np.testing.assert_allclose(_dense((nx, nx), *ol.nlp_hess(cfg, x, p, lf, lg)), H0,
                                    atol=1e-12 * np.abs(H0).max())
+        _, _, gx0, gp0 = ref.grad(x, p, lf, lg)
+        gx1, gp1 = ol.nlp_grad(cfg, x, p, lf, lg)
+        np.testing.assert_allclose(gx1, gx0, atol=1e-12 * np.abs(gx0).max())
+        np.testing.assert_allclose(gp1, gp0, atol=1e-12 * np.abs(gp0).max())
 
 
 def test_dims_generalise_in_N():
