@@ -23,12 +23,68 @@ from . import oracle_lib as ol
 INF = 1e19
 
 
+class RestatementFunctions:
+    """f, g, grad f, jac g, hess L from oracle/nlp_ref.c (any horizon)."""
+
+    def __init__(self, cfg):
+        self.cfg = cfg
+
+    def fg(self, x, p):
+        return ol.nlp_fg(self.cfg, x, p)
+
+    def grad_f(self, x, p):
+        return ol.nlp_grad_f(self.cfg, x, p)
+
+    def jac(self, x, p):
+        return ol.nlp_jac(self.cfg, x, p)
+
+    def hess(self, x, p, lam_f, lam_g):
+        return ol.nlp_hess(self.cfg, x, p, lam_f, lam_g)
+
+
+class ReferenceFunctions:
+    """The same five functions from the reference's own CasADi-generated code compiled as is (oracle/_ref:
+    tmp.c / jit_tmpComMiH.c; N = 12, dt = 0.1 and the weights are baked in): with these the solver below computes the
+    argmin of the reference's NLP exactly as IPOPT would see it."""
+
+    def __init__(self, which):
+        from . import ref_nlp
+        self.ref = ref_nlp.RefNLP(which)
+
+    def fg(self, x, p):
+        return self.ref.fg(x, p)
+
+    def grad_f(self, x, p):
+        return self.ref.jac_fg(x, p)[1]
+
+    def jac(self, x, p):
+        J = self.ref.jac_fg(x, p)[3]
+        r, c = np.nonzero(self._pattern())
+        return r, c, J[r, c]
+
+    def _pattern(self):
+        if not hasattr(self, "_pat"):
+            _, _, colind, row = self.ref.sparsity("nlp_jac_fg", "out", 3)
+            pat = np.zeros((651, 555), bool)
+            pat[row, np.repeat(np.arange(555), np.diff(colind))] = True
+            self._pat = pat
+        return self._pat
+
+    def hess(self, x, p, lam_f, lam_g):
+        H = self.ref.hess_l(x, p, lam_f, lam_g)
+        r, c = np.nonzero(H)
+        return r, c, H[r, c]
+
+
 def solve(cfg, p, lbg, ubg, x0, tol=1e-9, max_iter=200, mu0=0.1, verbose=False,
           delta_w=1e-6, delta_c=1e-9, fun=None):
     """Returns dict(x, lam_g, iters, f, kkt, status).
 
-    fun: optional object with fg/grad_f/jac/hess (defaults to oracle/nlp_ref.c through ctypes).
+    fun: object with fg/grad_f/jac/hess (default: RestatementFunctions(cfg), i.e. oracle/nlp_ref.c through ctypes;
+    ReferenceFunctions(which) runs the solver on the reference's own compiled code).
     """
+    if fun is None:
+        fun = RestatementFunctions(cfg)
     nx, npar, ng, _, _ = ol.dims(cfg)
     p = np.asarray(p, np.float64)
     lbg = np.asarray(lbg, np.float64)
@@ -45,11 +101,11 @@ def solve(cfg, p, lbg, ubg, x0, tol=1e-9, max_iter=200, mu0=0.1, verbose=False,
     nE, nI = len(E), len(I)
 
     def evalc(x):
-        f, g = ol.nlp_fg(cfg, x, p)
+        f, g = fun.fg(x, p)
         return f, g
 
     def jac(x):
-        r, c, v = ol.nlp_jac(cfg, x, p)
+        r, c, v = fun.jac(x, p)
         return sp.csr_matrix((v, (r, c)), shape=(ng, nx))
 
     f, g = evalc(x)
@@ -75,7 +131,7 @@ def solve(cfg, p, lbg, ubg, x0, tol=1e-9, max_iter=200, mu0=0.1, verbose=False,
     for it in range(max_iter):
         J = jac(x)
         JE, JI = J[E], J[I]
-        gf = ol.nlp_grad_f(cfg, x, p)
+        gf = fun.grad_f(x, p)
         sl = np.where(hasL, s - lb, 1.0)
         su = np.where(hasU, ub - s, 1.0)
         rE = g[E] - lbg[E]
@@ -101,7 +157,7 @@ def solve(cfg, p, lbg, ubg, x0, tol=1e-9, max_iter=200, mu0=0.1, verbose=False,
         lam_full = np.zeros(ng)
         lam_full[E] = lamE
         lam_full[I] = lamI
-        hr, hc, hv = ol.nlp_hess(cfg, x, p, 1.0, lam_full)
+        hr, hc, hv = fun.hess(x, p, 1.0, lam_full)
         H = sp.csr_matrix((hv, (hr, hc)), shape=(nx, nx))
         Sig = np.where(hasL, zL / sl, 0.0) + np.where(hasU, zU / su, 0.0)
         bar = np.where(hasU, mu / su, 0.0) - np.where(hasL, mu / sl, 0.0)

@@ -146,3 +146,40 @@ def standing_known_answer(N=12, dt=0.1, which="tmp"):
     dcom0 = np.array([[0.02, 0.0, 0.0]])
     ref = np.broadcast_to(np.array([0.0, 0.0, 0.7]), (1, N + 1, 3)).copy()
     return _finish(cfg, sched, com0, dcom0, np.zeros((1, 3)), ref, np.zeros((1, N + 1, 3)))
+
+
+def walking_push_n12(which="tmp", B=2, seed=41):
+    """N = 12, dt = 0.1 with the weights baked into the reference's generated code (`which`: tmp.c or
+    jit_tmpComMiH.c): a swing phase inside the horizon (left Gamma = 1x3, 0x5, 1x4, next footstep +0.1 m) and an
+    external push over the first two knots -- the step adjustment is active.  Small on purpose: these problems are
+    solved on the reference's own compiled functions (oracle/_ref) to make golden vectors."""
+    N, dt = 12, 0.1
+    cfg = _cfg.generated_code_weights(which, N, dt)
+    rng = np.random.default_rng(seed)
+    sched = _tile(sample_schedule(cfg, _walking_lists(cfg, 3, 5)), B)
+    com0, dcom0, h0 = _perturbed_state(rng, B, (0.0, 0.0, 0.7))
+    ref = np.broadcast_to(np.array([0.0, 0.0, 0.7]), (B, N + 1, 3)).copy()
+    f_ext = np.zeros((B, N, 3))
+    f_ext[:, :2, :2] = (rng.uniform(-40.0, 40.0, (B, 2)) / ROBOT_MASS)[:, None, :]
+    return _finish(cfg, sched, com0, dcom0, h0, ref, np.zeros((B, N + 1, 3)), f_ext)
+
+
+def yawed_steps_n12(which="tmp", B=2, seed=42):
+    """N = 12, dt = 0.1, generated-code weights: two yawed footsteps (R != I in the friction and bounding-box rows)."""
+    N, dt = 12, 0.1
+    cfg = _cfg.generated_code_weights(which, N, dt)
+    rng = np.random.default_rng(seed)
+    lists = []
+    for _ in range(B):
+        y1, y2 = rng.uniform(-0.25, 0.25, 2)
+        left = [PlannedContact(-1.0, 0.2, (0.0, FOOT_Y, 0.0), rng.uniform(-0.1, 0.1)), PlannedContact(0.6, 10.0, (0.12, FOOT_Y + 0.02, 0.0), y1)]
+        right = [PlannedContact(-1.0, 0.8, (0.0, -FOOT_Y, 0.0), rng.uniform(-0.1, 0.1)), PlannedContact(1.1, 10.0, (0.2, -FOOT_Y - 0.01, 0.0), y2)]
+        lists.append({cfg.contacts[0].contact_name: left, cfg.contacts[1].contact_name: right})
+    sched, _ = sample_schedule_batch(cfg, *pack_lists(cfg, lists))
+    sched = {k: v.astype(np.float64) for k, v in sched.items()}
+    com0, dcom0, h0 = _perturbed_state(rng, B, (0.0, 0.0, 0.7))
+    s = np.linspace(0.0, 1.0, N + 1)[None, :, None]
+    ref = np.zeros((B, N + 1, 3))
+    ref[:, :, 0] = 0.1 * s[:, :, 0]
+    ref[:, :, 2] = 0.7
+    return _finish(cfg, sched, com0, dcom0, h0, ref, np.zeros((B, N + 1, 3)))

@@ -54,6 +54,20 @@ def test_matches_golden(name, golden_dir):
     s.close()
 
 
+@pytest.mark.parametrize("name,which", [("walk", "tmp"), ("walk", "jit"), ("yaw", "tmp"), ("yaw", "jit")])
+def test_matches_argmin_computed_on_the_reference_code(name, which, golden_dir):
+    """N = 12, dt = 0.1 goldens solved on the reference's own compiled NLP functions (swing + push, yawed footsteps; both
+    baked weight sets; tests/golden/make_argmin_ref_golden.py), every knot of every quantity."""
+    d = np.load(os.path.join(golden_dir, f"argmin_ref_{name}_{which}.npz"))
+    cfg = cm.config.generated_code_weights(which, 12, 0.1)
+    B = d["P"].shape[0]
+    s = cm.BatchSolver(cfg, B)
+    X, info, rc = s.solve_host(d["P"], d["X0"])
+    assert rc == 0 and (info[:, 5] == 0).all(), (rc, info[:, 5], s.last_error)
+    parity.assert_within(cfg.N, parity.worst_errors(cfg.N, d["P"], X, d["x_star"]))
+    s.close()
+
+
 def test_known_answer_objective():
     """f* = 8.16487469 for the standing problem (float32 inputs: 8.1648620)."""
     from oracle import oracle_lib as ol, problem_nlp

@@ -105,3 +105,68 @@ def test_hip_arithmetic_model_meets_tolerance(name, golden_dir):
     for b in range(d["P"].shape[0]):
         e = parity.errors(cfg.N, d["P"][b], X[b], d["x_star"][b])
         assert e["com"] < 5e-5 and e["force0"] < 5e-5 and e["pos"] < 5e-5, e
+
+
+# ---- argmin vectors computed on the reference's own compiled NLP functions (tests/golden/make_argmin_ref_golden.py) ----
+REF_CASES = [("walk", "tmp"), ("walk", "jit"), ("yaw", "tmp"), ("yaw", "jit")]
+REF_GEN = {"walk": cm.synthetic.walking_push_n12, "yaw": cm.synthetic.yawed_steps_n12}
+
+
+@pytest.mark.parametrize("name,which", REF_CASES)
+def test_reference_solved_goldens_satisfy_kkt_on_the_reference_code(name, which, golden_dir):
+    """Swing + push and yawed-footstep problems at N = 12 with both baked weight sets: first- and second-order optimality
+    of the stored argmin, evaluated with the reference's compiled code where it is present (oracle/_ref) and with the
+    restatement (nlp_ref.c) always."""
+    d = np.load(os.path.join(golden_dir, f"argmin_ref_{name}_{which}.npz"))
+    cfg, P, X0 = REF_GEN[name](which)
+    np.testing.assert_array_equal(P.astype(np.float32), d["P"])      # the committed generator makes these inputs
+    np.testing.assert_array_equal(X0.astype(np.float32), d["X0"])
+    oc = problem_nlp.oracle_cfg(cfg)
+    nx, _, ng, _, _ = ol.dims(oc)
+    try:
+        from oracle import ref_nlp
+        ref = ref_nlp.RefNLP(which)
+    except (ImportError, FileNotFoundError):
+        ref = None
+    for b in range(d["P"].shape[0]):
+        p = d["P"][b].astype(np.float64)
+        x, lam = d["x_star"][b], d["lam_g"][b]
+        lb, ub = problem_nlp.bounds(cfg, p)
+        evaluators = [lambda: (ol.nlp_fg(oc, x, p), ol.nlp_grad_f(oc, x, p), ol.nlp_jac(oc, x, p), ol.nlp_hess(oc, x, p, 1.0, lam))]
+        results = []
+        (f, g), gf, (r, c, v), (hr, hc, hv) = evaluators[0]()
+        J = np.zeros((ng, nx)); np.add.at(J, (r, c), v)
+        H = np.zeros((nx, nx)); np.add.at(H, (hr, hc), hv)
+        results.append((f, g, gf, J, H))
+        if ref is not None:
+            f0, gf0, g0, J0 = ref.jac_fg(x, p)
+            results.append((f0, g0, gf0, J0, ref.hess_l(x, p, 1.0, lam)))
+        for f, g, gf, J, H in results:
+            scale = max(1.0, np.abs(lam).max())
+            assert abs(f - d["f_star"][b]) <= 1e-10 * abs(f)
+            assert np.abs(gf + J.T @ lam).max() <= 1e-8 * scale                 # stationarity
+            assert (g >= lb - 1e-8).all() and (g <= ub + 1e-8).all()             # feasibility
+            ineq = ub - lb > 1e-12
+            assert (np.abs(lam[ineq] * np.minimum(g[ineq] - lb[ineq], ub[ineq] - g[ineq])) <= 1e-7 * scale).all()
+            at_ub = np.abs(g - ub) <= 1e-7
+            assert (lam[ineq & ~at_ub] <= 1e-7 * scale).all()                    # a positive multiplier only on an active upper bound
+            active = (~ineq) | (np.abs(lam) > 1e-7 * scale)
+            _, sv, Vt = np.linalg.svd(J[active], full_matrices=True)
+            Z = Vt[int((sv > 1e-9 * sv[0]).sum()):].T
+            red = Z.T @ H @ Z
+            assert np.linalg.eigvalsh(0.5 * (red + red.T)).min() > -1e-8        # a minimiser, not a saddle
+
+
+@pytest.mark.parametrize("name,which", REF_CASES)
+def test_structured_solver_reaches_the_reference_solved_argmin(name, which, golden_dir):
+    d = np.load(os.path.join(golden_dir, f"argmin_ref_{name}_{which}.npz"))
+    cfg = REF_GEN[name](which)[0]
+    oc = problem_nlp.oracle_cfg(cfg)
+    P, X0 = d["P"].astype(np.float64), d["X0"].astype(np.float64)
+    X, info = ol.ref_solve_batch(oc, P, X0, ol.ipm_opts(tol=1e-9, mu_min=1e-10))
+    assert (info[:, 5] == 0).all()
+    for b in range(P.shape[0]):
+        e = parity.errors(cfg.N, P[b], X[b], d["x_star"][b])
+        assert e["com"] < 1e-6 and e["forces"] < 2e-5 and e["pos"] < 5e-6 and e["dcom"] < 1e-5, e   # (landing positions: w_pos = 200 here, 10x softer than the shipped configs)
+        f, _ = ol.nlp_fg(oc, X[b], P[b])
+        assert abs(f - d["f_star"][b]) <= 1e-7 * abs(f)
