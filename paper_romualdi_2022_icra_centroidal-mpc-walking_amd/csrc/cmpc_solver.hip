@@ -40,7 +40,7 @@
 #define RLD 36     // leading dim of the row-major float panels (16-byte aligned rows)
 #define NPAN 46    // panel rows: 15 (Qus^T) + 30 (I) + 1 (qu)
 #define GEO 36     // floats of stage geometry: r[24] | Fc[6] | Fsum[3] | pad
-#define NTRI 780   // lower-triangular entries of a 39x39
+#define NTRI 256   // entries of the lower-triangle index table (the users need 210: 2x2 tiles of a 39x39)
 // Per-stage factor record (floats), in LDS or -- FG kernels -- in HBM scratch.  Phase 3 leaves column m of
 // L^{-1} and column j of Ws = L^{-1} Qus in the registers of one lane, so both are stored transposed, one
 // 16-byte-aligned row per lane:
@@ -58,6 +58,9 @@
 #define REC_WT 576
 #define REC_ZERO 572
 #define REC_N CMPC_REC_N
+// Workgroups per CU the HBM-factor variants are compiled for (register budget 512 / that per lane): three for N = 20, whose
+// LDS image (53 KB) fits three times into a CU (measured at N = 12, where 2 and 3 both fit: +22 % with three, spills included);
+// two for the run-time-N variant (N = 30: 64 KB)
 
 namespace {
 
@@ -117,17 +120,24 @@ __device__ inline void make_ctx(Ctx& c, char* smem, int N, float* fg_base)
     c.sig = dp; dp += NI; c.gco = dp; dp += NI; dp += 2 * NI;  // (second descriptor set)
     c.redd = dp; dp += 8;
     float* fp = reinterpret_cast<float*>(dp);
+    // workspace of the backward sweep: QuuF | Pan | G | P0 | Qb (5667 floats).  The step arrays dS | dU | dT | dZ live in
+    // the same bytes: they are written by the forward sweep and dead again when the next factorisation starts, while the
+    // workspace is dead as soon as riccati_backward returns (10.7 KB at N = 20: what brings the HBM-factor image of N = 20
+    // under a third of a CU's LDS).  NS (N+1) + NU N + 2 NI N <= 5335 floats for N <= CMPC_NMAX.
     c.QuuF = fp; fp += NU * RLD;
     c.Pan = fp; fp += NPAN * RLD;
+    c.G = fp; fp += (NXA * GLD + 3) & ~3;                   // (sizes rounded to 16 bytes: ybuf and the LDS factor records
+    c.P0 = fp; fp += (NXA * PLD + 3) & ~3; c.Qb = fp; fp += NS * 16;   //  behind them are read with ds_read_b128)
+    {
+        float* vp = c.QuuF;
+        c.dS = vp; vp += NS * (N + 1); c.dU = vp; vp += NU * N; c.dT = vp; vp += NI * N; c.dZ = vp;
+    }
     c.ybuf = fp; fp += 96;          // 16-byte aligned vector staging of the sweeps
     if (!FG) { c.Lf = fp; fp += (size_t)REC_N * N; } else c.Lf = fg_base;
     c.sp = fp; fp += (c.L.np() + 3) & ~3;
     c.S = fp; fp += NS * (N + 1); c.U = fp; fp += NU * N; c.T = fp; fp += NI * N; c.Z = fp; fp += NI * N;
-    c.dS = fp; fp += NS * (N + 1); c.dU = fp; fp += NU * N; c.dT = fp; fp += NI * N; c.dZ = fp; fp += NI * N;
     c.d = fp; fp += NS * N;
     c.geoA = fp; fp += GEO * N;
-    c.P0 = fp; fp += NXA * PLD; c.Qb = fp; fp += NS * 16;   // value function (in place); Qss of the stage in flight
-    c.G = fp; fp += NXA * GLD;
     c.Bval = fp; fp += 3 * NU; c.Aval = fp; fp += 3 * NS + 3;
     c.arow = fp; fp += 96 + 12; fp += DSET_F;  // (second descriptor set)
     c.fpv = fp; fp += 40; c.fpn = fp; fp += 40; c.red = fp; fp += 8;
@@ -135,7 +145,7 @@ __device__ inline void make_ctx(Ctx& c, char* smem, int N, float* fg_base)
     c.Arow = reinterpret_cast<int*>(fp); fp += 3 * NS + 3; fp += DSET_I;  // (second descriptor set)
     c.flag = reinterpret_cast<int*>(fp); fp += 4;
     c.qmask = reinterpret_cast<int*>(fp); fp += CMPC_NMAX;
-    c.tri = reinterpret_cast<unsigned short*>(fp); fp += NTRI / 2;
+    c.tri = reinterpret_cast<unsigned short*>(fp); fp += NTRI / 2;   // (i, j) of the first NTRI lower-triangle entries
 }
 
 __device__ inline void use_desc_set(Ctx& c, int s)
@@ -1354,7 +1364,7 @@ __device__ __attribute__((noinline)) void phase_costate(lds_t lds, int Nrt, floa
 // FG: the per-stage factors (Linv, Ws: 915 floats per stage) live in global scratch instead of LDS
 // (horizons whose LDS image would exceed 160 KiB)
 template <int NT, int NC, bool FG>
-__global__ __launch_bounds__(NT, FG ? 2 : 1) void cmpc_solve_kernel(CmpcParams kp)
+__global__ __launch_bounds__(NT, FG ? (NC == 20 ? 3 : 2) : 1) void cmpc_solve_kernel(CmpcParams kp)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int b = blockIdx.x;
@@ -1688,8 +1698,8 @@ extern "C" size_t cmpc_solver_lds_bytes(int N, int factors_global)
     const size_t nlam = (size_t)NS * (N + 1) + (((size_t)NS * (N + 1)) & 1);
     const size_t dbl = nlam + 90 + 40 + 40 + 16 + 40 + 4 * NI + 8;
     const size_t flt = (size_t)NU * RLD + (size_t)NPAN * RLD + 96 + ((L.np + 3) & ~3)
-                       + 2 * ((size_t)NS * (N + 1) + (size_t)NU * N + 2 * (size_t)NI * N) + (size_t)NS * N
-                       + (size_t)GEO * N + NXA * PLD + NS * 16 + NXA * GLD + 2 * DSET_F + 40 + 40 + 8
+                       + ((size_t)NS * (N + 1) + (size_t)NU * N + 2 * (size_t)NI * N) + (size_t)NS * N
+                       + (size_t)GEO * N + ((NXA * PLD + 3) & ~3) + NS * 16 + ((NXA * GLD + 3) & ~3) + 2 * DSET_F + 40 + 40 + 8
                        + 2 * DSET_I + 4 + CMPC_NMAX + NTRI / 2 + (factors_global ? 0 : (size_t)REC_N * N);
     return ((sizeof(CmpcConsts) + 15) & ~(size_t)15) + dbl * 8 + flt * 4;
 }
