@@ -463,17 +463,17 @@ __device__ inline double readlane_d(double x, int lane)
 // numbers and accumulate in those zeroed float slots; they are folded into dd when the block becomes the
 // pivot block.  The pivot block is broadcast (v_readlane), factorised in float64 by every lane, and applied:
 // three columns of L per step, then one rank-3 update of the trailing columns.
-__device__ inline double rsqrt_d(double x)
+// 1 / x in float64 from the v_rcp_f32 seed and one Newton step (seed error 1e-7 -> 1e-14).  Pivots are far from the
+// float32 range limits: no scaling.
+__device__ inline double rcp_d(double x)
 {
-    // v_rsq_f32 seed (pivots are far from denormal: no range scaling), one Newton step in float64: ~1e-14 relative.
-    // A non-positive pivot gives NaN (or inf), which every later entry of the block inherits: tested once per block.
-    double r = (double)__builtin_amdgcn_rsqf((float)x);
-    return r * (1.5 - 0.5 * x * r * r);
+    const double r = (double)__builtin_amdgcn_rcpf((float)x);
+    return r * (2.0 - x * r);
 }
 // The row lives in 15 register pairs (vv[j / 2][j % 2] = entry j) so that the trailing update can use packed FMAs.
 typedef float float2v __attribute__((ext_vector_type(2)));
 #define VE(j) vv[(j) >> 1][(j) & 1]
-__device__ inline bool chol_solve_fused(float2v (&vv)[NU / 2], double (&dd)[3], int lane, int fixedmask)
+__device__ __forceinline__ bool chol_solve_fused(float2v (&vv)[NU / 2], double (&dd)[3], int lane, int fixedmask)
 {
     const int myblk = lane / 3, jm = lane - 3 * myblk;
     bool bad = false;
@@ -494,23 +494,29 @@ __device__ inline bool chol_solve_fused(float2v (&vv)[NU / 2], double (&dd)[3], 
         const double d00 = readlane_d(dd[0], j0);
         const double d10 = readlane_d(dd[0], j0 + 1), d11 = readlane_d(dd[1], j0 + 1);
         const double d20 = readlane_d(dd[0], j0 + 2), d21 = readlane_d(dd[1], j0 + 2), d22 = readlane_d(dd[2], j0 + 2);
-        const double r00 = rsqrt_d(d00);
-        const double l00 = d00 * r00, l10 = d10 * r00, l20 = d20 * r00;
-        const double p1 = d11 - l10 * l10;
-        const double r11 = rsqrt_d(p1);
-        const double l11 = p1 * r11, l21 = (d21 - l20 * l10) * r11;
-        const double p2 = d22 - l20 * l20 - l21 * l21;
-        const double r22 = rsqrt_d(p2);
-        const double l22 = p2 * r22;
-        bad = bad || !(l22 > 0.0);  // the last link of the chain: a non-positive pivot anywhere before it arrives here as NaN
+        // Float64 only where cancellation decides the answer: the Schur pivots p1, p2 of the block (barrier terms ~1e9 next to
+        // cost curvature ~20) through two accurate reciprocals.  The entries of L are float32 numbers anyway (rows are stored
+        // and applied in float32): they come from the float32 casts of the pivots and v_rsq_f32.
+        const double i00 = rcp_d(d00);
+        const double m10 = d10 * i00, m20 = d20 * i00;
+        const double p1 = d11 - m10 * d10;
+        const double t21 = d21 - m10 * d20;
+        const double i11 = rcp_d(p1);
+        const double m21 = t21 * i11;
+        const double p2 = (d22 - m20 * d20) - m21 * t21;
+        const float p0f = (float)d00, p1f = (float)p1, p2f = (float)p2;
+        const float r00 = __builtin_amdgcn_rsqf(p0f), r11 = __builtin_amdgcn_rsqf(p1f), r22 = __builtin_amdgcn_rsqf(p2f);
+        const float l10 = (float)d10 * r00, l20 = (float)d20 * r00, l21 = (float)t21 * r11;
+        // a non-positive pivot: v_rsq_f32 of a negative number is NaN, of zero inf; p1 and p2 inherit a bad d00 through i00
+        bad = bad || !(p0f > 0.f) || !(p1f > 0.f) || !(p2f > 0.f);
         // rows below the block and panel rows: x = v[j0..j0+2] L_bb^{-T}
-        float x0 = VE(j0) * (float)r00;
-        float x1 = (VE(j0 + 1) - x0 * (float)l10) * (float)r11;
-        float x2 = (VE(j0 + 2) - x0 * (float)l20 - x1 * (float)l21) * (float)r22;
-        if (inblk) {  // the block's own rows of L, from the float64 factor
-            x0 = (float)(jmo == 0 ? l00 : (jmo == 1 ? l10 : l20));
-            x1 = jmo == 0 ? 0.f : (float)(jmo == 1 ? l11 : l21);
-            x2 = jmo == 2 ? (float)l22 : 0.f;
+        float x0 = VE(j0) * r00;
+        float x1 = (VE(j0 + 1) - x0 * l10) * r11;
+        float x2 = (VE(j0 + 2) - x0 * l20 - x1 * l21) * r22;
+        if (inblk) {  // the block's own rows of L: (l00 0 0), (l10 l11 0), (l20 l21 l22)
+            x0 = jmo == 0 ? p0f * r00 : (jmo == 1 ? l10 : l20);
+            x1 = jmo == 0 ? 0.f : (jmo == 1 ? p1f * r11 : l21);
+            x2 = jmo == 2 ? p2f * r22 : 0.f;
         }
         VE(j0) = x0; VE(j0 + 1) = x1; VE(j0 + 2) = x2;
         // rank-3 update of the trailing columns: a leading odd column alone, then two columns per packed FMA.  Each
@@ -543,7 +549,7 @@ __device__ inline bool chol_solve_fused(float2v (&vv)[NU / 2], double (&dd)[3], 
 
 // phase 3 of a backward stage, kept out of line so that its ~40 VGPRs of matrix rows and its
 // stream of v_readlane broadcasts get a register allocation of their own
-__device__ inline void stage_factor(const float* QuuF, const double* QuuD, float* Pan, float* rec,
+__device__ __forceinline__ void stage_factor(const float* QuuF, const double* QuuD, float* Pan, float* rec,
                                           float D0, float D1, float D2, int* flag, int tid, int fixedmask)
 {
     const int lane = tid & 63, wv = tid >> 6;
