@@ -944,13 +944,11 @@ __device__ inline void stage_post_body(const Ctx& c, const CmpcConsts& prm, int 
                         v = -(double)prm.D[m % 3] * ((double)u[m] - (double)c.U[NU * (k - 1) + m]) - v;
                     }
                 }
-                c.pn[i] = v;
+                c.pv[i] = v;   // (the value gradient of stage k+1 was last read in phase 2: written in place, one barrier less)
             }
         }
         __syncthreads();
         PROF(4);
-    if (tid < NXA) c.pv[tid] = c.pn[tid];
-    __syncthreads();
 }
 
 // ---- out-of-line phases: each rebuilds the LDS map from the LDS base it is handed (an address-space-3
