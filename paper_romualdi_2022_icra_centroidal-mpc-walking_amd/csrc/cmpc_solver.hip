@@ -881,7 +881,7 @@ __device__ inline void stage_qss_body(const Ctx& c, const CmpcConsts& prm, int t
             if (t < NS) c.qs[t] = grad_track(c, prm, k, t) + At_vec<double>(c, prm, k, t, c.Pd);
 }
 
-template <int NT>
+template <int NT, bool LEAN>
 __device__ inline void stage_post_body(const Ctx& c, const CmpcConsts& prm, int tid, int k, float* Pnew, const float* Qb)
 {
     const bool pk = k > 0;
@@ -900,6 +900,23 @@ __device__ inline void stage_post_body(const Ctx& c, const CmpcConsts& prm, int 
                 const float4* rj0 = reinterpret_cast<const float4*>(c.Pan + j0 * RLD);
                 const float4* rj1 = reinterpret_cast<const float4*>(c.Pan + (j0 + 1) * RLD);
                 float a00 = 0.f, a01 = 0.f, a10 = 0.f, a11 = 0.f;
+                if (LEAN) {
+                    // The 168-register variants (three workgroups per CU) take the 32 row loads in two rounds: hoisted all
+                    // at once they need the callee-saved registers, and saving those at every call of this function was
+                    // 18 GB of scratch traffic per 4096-problem batch (columns 30, 31 of the panel are stored as zeros).
+#pragma unroll 1
+                    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int q4 = 4 * h + q;
+                            const float4 x0 = ri0[q4], x1 = ri1[q4], y0 = rj0[q4], y1 = rj1[q4];
+                            a00 += (x0.x * y0.x + x0.y * y0.y) + (x0.z * y0.z + x0.w * y0.w);
+                            a01 += (x0.x * y1.x + x0.y * y1.y) + (x0.z * y1.z + x0.w * y1.w);
+                            a10 += (x1.x * y0.x + x1.y * y0.y) + (x1.z * y0.z + x1.w * y0.w);
+                            a11 += (x1.x * y1.x + x1.y * y1.y) + (x1.z * y1.z + x1.w * y1.w);
+                        }
+                    }
+                } else {
 #pragma unroll
                 for (int q4 = 0; q4 < 8; ++q4) {
                     const float4 x0 = ri0[q4], x1 = ri1[q4], y0 = rj0[q4], y1 = rj1[q4];
@@ -909,6 +926,7 @@ __device__ inline void stage_post_body(const Ctx& c, const CmpcConsts& prm, int 
                         a00 += x0.z * y0.z + x0.w * y0.w; a01 += x0.z * y1.z + x0.w * y1.w;
                         a10 += x1.z * y0.z + x1.w * y0.w; a11 += x1.z * y1.z + x1.w * y1.w;
                     }
+                }
                 }
                 auto put = [&](int i, int j, float acc) {
                     if (j > i || i >= ncol) return;
@@ -999,7 +1017,7 @@ template <int NT, int NC, bool FG>
 __device__ __attribute__((noinline)) void stage_post(lds_t lds, int Nrt, float* fg_base, int k)
 {
     CMPC_PHASE_PROLOGUE;
-    stage_post_body<NT>(c, prm, tid, k, c.P0, c.Qb);
+    stage_post_body<NT, FG && NC == 20>(c, prm, tid, k, c.P0, c.Qb);
 }
 
 // ---- Riccati backward sweep (matrices + right-hand side of the affine step, or of a centring step with target
@@ -1514,14 +1532,15 @@ __global__ __launch_bounds__(NT, FG ? (NC == 20 ? 3 : 2) : 1) void cmpc_solve_ke
                 mu_cur = mu0;
                 __syncthreads();
             }
-            if (it > 0 && ec > 100.f * mu_cur && ec > 0.1f) {
+            if (kp.warm && pass == 0 && it > 0 && ec > 100.f * mu_cur && ec > 0.1f) {
                 // Emergency re-centring.  Primal and dual step lengths differ; when a blocked primal step (ap ~ 0.2) meets a
                 // full dual step, the multipliers of rows that were about to become active grow while their slacks stay:
                 // products t z hundreds of times the average, and the predictor-corrector can fall into a two-cycle (seen on
                 // warm starts when a new swing phase enters the last stage of the horizon: max t z / mu ~ 600, 40 iterations
                 // without progress).  Pull those multipliers back to 10 mu / t.  Only products of order one count (ec > 0.1):
                 // near the barrier floor a few lagging rows are legitimately 100 x the mean and must be left alone
-                // (re-centring them there cost config 2 five of 4096 problems).
+                // (re-centring them there cost config 2 five of 4096 problems).  Warm starts only: cold starts pass through such
+            // iterates on their own (5 of 40960 config-2 problems trip the test and then need 20 iterations instead of 12).
                 double l2 = 0.0;
                 for (int e = tid; e < NI * N; e += NT)
                     if (row_active(c, e / NI, e % NI)) {
