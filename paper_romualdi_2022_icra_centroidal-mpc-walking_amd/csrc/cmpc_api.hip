@@ -46,6 +46,8 @@ struct cmpc_handle_s {
     CmpcConsts* dConsts = nullptr;
     float* dScratch = nullptr;   // factor storage when the horizon's LDS image exceeds 160 KiB
     float* dBox = nullptr;       // bounding-box limits upper[2][3] | lower[2][3] of the schedule sampler
+    float* dDuals = nullptr;     // costates, slacks, multipliers of the last solve (warm start with duals; allocated on first use)
+    int warm_duals = 0;          // 0: primal shift only (default); 1: + costates; 2: + multipliers
     float hBox[12] = {0};
     bool box_set = false;
     long long scratch_stride = 0;
@@ -140,6 +142,8 @@ int cmpc_create(const cmpc_config* cfg, int batch, int device, cmpc_handle* out)
     if (!(h->cfg.gravity > 0)) h->cfg.gravity = 9.80665;
     h->B = batch;
     h->device = device;
+    if (const char* e = std::getenv("CMPC_WARM_DUALS")) h->warm_duals = std::atoi(e);   // developer knob
+    if (const char* e = std::getenv("CMPC_MU_WARM")) { h->mu_warm = std::atof(e); h->floor_warm = std::min(1e-2, h->mu_warm); }   // developer knob
     cmpc_layout_init(h->L, cfg->horizon);
     h->lds = cmpc_solver_lds_bytes(cfg->horizon, 0);
     // factors in HBM scratch when the LDS image would not fit -- or, by choice, to halve the image so that
@@ -186,6 +190,11 @@ int cmpc_create(const cmpc_config* cfg, int batch, int device, cmpc_handle* out)
     HIPCHK_CREATE(hipMalloc(&h->dInfo, sizeof(float) * CMPC_INFO_N * (size_t)batch));
     HIPCHK_CREATE(hipMalloc(&h->dConsts, sizeof(CmpcConsts)));
     HIPCHK_CREATE(hipMalloc(&h->dBox, sizeof(float) * 12));
+    if (h->warm_duals) {
+        const size_t nd = (size_t)batch * (CMPC_NS * (cfg->horizon + 1) + 2 * CMPC_NI * cfg->horizon);
+        HIPCHK_CREATE(hipMalloc(&h->dDuals, sizeof(float) * nd));
+        HIPCHK_CREATE(hipMemset(h->dDuals, 0, sizeof(float) * nd));
+    }
     {
         CmpcConsts q;
         fill_consts(h, q);
@@ -204,7 +213,7 @@ int cmpc_destroy(cmpc_handle h)
     if (!h) return CMPC_OK;
     hipSetDevice(h->device);
     if (h->stream) hipStreamSynchronize(h->stream);
-    hipFree(h->dP); hipFree(h->dX0); hipFree(h->dX); hipFree(h->dInfo); hipFree(h->dConsts); hipFree(h->dScratch); hipFree(h->dBox);
+    hipFree(h->dP); hipFree(h->dX0); hipFree(h->dX); hipFree(h->dInfo); hipFree(h->dConsts); hipFree(h->dScratch); hipFree(h->dBox); hipFree(h->dDuals);
     if (h->ev0) hipEventDestroy(h->ev0);
     if (h->ev1) hipEventDestroy(h->ev1);
     if (h->stream) hipStreamDestroy(h->stream);
@@ -265,6 +274,7 @@ static void fill_params(cmpc_handle h, CmpcParams& p)
     p.mu_init = h->cfg.mu_init > 0 ? (float)h->cfg.mu_init : 0.1f;
     p.mu_adapt = h->cfg.mu_init > 0 ? 0.f : 3.5f;
     p.t_floor = 1e-2f;
+    p.duals = h->dDuals; p.warm_duals = h->warm_duals;
 }
 
 int cmpc_solve_device(cmpc_handle h, const float* dP, const float* dX0, float* dX, float* dInfo, void* stream)

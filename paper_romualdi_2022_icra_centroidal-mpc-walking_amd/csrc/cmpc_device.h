@@ -102,6 +102,8 @@ struct CmpcParams {
     float mu_init, t_floor;      // starting barrier parameter and slack floor of this solve (cold: 0.1 / 1e-2)
     float mu_adapt;              // > 0: mu_init is replaced per problem by clamp(mu_adapt * ep0^2, 0.03, 0.5)
     int warm;                    // the initial guess is a shifted previous solution: a problem that fails is restarted cold
+    float* duals;                // [B][NS (N+1) + 2 NI N] costates | slacks | multipliers of the last solve (written at exit; read, shifted
+    int warm_duals;              //  by one knot, at the start of a warm solve if warm_duals != 0); may be null
     float* scratch;              // per-problem factor storage when it does not fit in LDS, else null
     long long scratch_stride;    // floats per problem
     int lds_words;               // 4-byte words of dynamic LDS the launch was given (set by cmpc_launch_solver)

@@ -1451,6 +1451,8 @@ __global__ __launch_bounds__(NT, FG ? (NC == 20 ? 3 : 2) : 1) void cmpc_solve_ke
         {
             const float* x0 = kp.X0 + (size_t)b * c.L.nx();
             const bool cold = pass > 0;   // second pass: the cold start of SURVEY 8d built in place (CoM at com0, feet at nominal, f_z = g/8)
+            const bool use_duals = kp.warm && kp.warm_duals && kp.duals;
+            const float* dprev = kp.duals ? kp.duals + (size_t)b * (NS * (N + 1) + 2 * NI * N) : nullptr;
             for (int e = tid; e < NS * (N + 1); e += NT) {
                 const int k = e / NS, i = e % NS;
                 float v;
@@ -1461,7 +1463,9 @@ __global__ __launch_bounds__(NT, FG ? (NC == 20 ? 3 : 2) : 1) void cmpc_solve_ke
                 else if (i < 9) v = x0[c.L.oCom() + 3 * (N + 1) * (i / 3) + 3 * k + i % 3];
                 else v = x0[c.L.oPos((i - 9) / 3) + 3 * k + (i - 9) % 3];
                 c.S[e] = v;
-                c.LAM[e] = 0.0;
+                // costates: zero, or -- warm start with duals -- the previous solve's shifted by one knot (they only enter the
+                // first iteration's exact-Hessian term; every iteration recomputes them)
+                c.LAM[e] = (use_duals && !cold) ? (double)dprev[NS * (k < N ? k + 1 : N) + i] : 0.0;
             }
             for (int e = tid; e < NU * N; e += NT) {
                 const int k = e / NU, m = e % NU;
@@ -1487,6 +1491,12 @@ __global__ __launch_bounds__(NT, FG ? (NC == 20 ? 3 : 2) : 1) void cmpc_solve_ke
                     t = -row_val(c, prm, k, i, c.U + NU * k);
                     if (i < 32) t = fmaxf(t, t_floor);
                     z = mu_init / t;
+                    if (use_duals && !cold && kp.warm_duals > 1) {
+                        // multiplier of the same row one knot later in the previous solve, where it is the larger (an active
+                        // row keeps its multiplier; inactive ones keep the centred value mu / t)
+                        const int kk = k + 1 < N ? k + 1 : N - 1;
+                        z = fmaxf(z, dprev[NS * (N + 1) + NI * N + NI * kk + i]);
+                    }
                 }
                 c.T[e] = t; c.Z[e] = z;
             }
@@ -1698,6 +1708,12 @@ __global__ __launch_bounds__(NT, FG ? (NC == 20 ? 3 : 2) : 1) void cmpc_solve_ke
                 const float v = gam_of(c, ct, k) < 0.5f ? (c.S[NS * (k + 1) + 9 + q] - c.S[NS * k + 9 + q]) / prm.dt : 0.f;
                 x[c.L.oVel(ct) + 3 * k + i] = v;
             }
+        }
+        if (kp.duals) {
+            __syncthreads();   // (the warm-start reads of this block's own record above are long done; other blocks own other rows)
+            float* dq = kp.duals + (size_t)b * (NS * (N + 1) + 2 * NI * N);
+            for (int e = tid; e < NS * (N + 1); e += NT) dq[e] = (float)c.LAM[e];
+            for (int e = tid; e < NI * N; e += NT) { dq[NS * (N + 1) + e] = c.T[e]; dq[NS * (N + 1) + NI * N + e] = c.Z[e]; }
         }
         if (kp.info && tid == 0) {
             float* inf = kp.info + (size_t)b * CMPC_INFO_N;
