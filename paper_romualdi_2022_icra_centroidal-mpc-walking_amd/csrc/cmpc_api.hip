@@ -161,7 +161,7 @@ int cmpc_create(const cmpc_config* cfg, int batch, int device, cmpc_handle* out)
     }
     if (fg) {
         h->lds = cmpc_solver_lds_bytes(cfg->horizon, 1);
-        h->scratch_stride = (long long)CMPC_REC_N * cfg->horizon;
+        h->scratch_stride = ((long long)CMPC_REC_N + 2 * CMPC_NI) * cfg->horizon;   // factor records | slacks | multipliers
     }
     if (h->lds > 160 * 1024) {
         const int n = cfg->horizon;

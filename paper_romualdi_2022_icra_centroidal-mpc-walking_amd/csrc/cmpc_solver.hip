@@ -58,9 +58,9 @@
 #define REC_WT 576
 #define REC_ZERO 572
 #define REC_N CMPC_REC_N
-// Workgroups per CU the HBM-factor variants are compiled for (register budget 512 / that per lane): three for N = 20, whose
-// LDS image (53 KB) fits three times into a CU (measured at N = 12, where 2 and 3 both fit: +22 % with three, spills included);
-// two for the run-time-N variant (N = 30: 64 KB)
+// Workgroups per CU the HBM-factor variants are compiled for (register budget 512 / that per lane): three for the compile-time
+// horizons N = 20 and N = 30, whose LDS images (45 / 52 KB) fit three times into a CU (measured at N = 12, where 2 and 3 both
+// fit: +22 % with three); two for the run-time-N variant
 
 namespace {
 
@@ -135,7 +135,12 @@ __device__ inline void make_ctx(Ctx& c, char* smem, int N, float* fg_base)
     c.ybuf = fp; fp += 96;          // 16-byte aligned vector staging of the sweeps
     if (!FG) { c.Lf = fp; fp += (size_t)REC_N * N; } else c.Lf = fg_base;
     c.sp = fp; fp += (c.L.np() + 3) & ~3;
-    c.S = fp; fp += NS * (N + 1); c.U = fp; fp += NU * N; c.T = fp; fp += NI * N; c.Z = fp; fp += NI * N;
+    c.S = fp; fp += NS * (N + 1); c.U = fp; fp += NU * N;
+    // slacks and multipliers: only ever touched by element-wise loops over all rows and by the descriptor builder that runs
+    // under the factorisation, never on a critical path -> with the factors in HBM they live there too (behind the records):
+    // 7 KB (N = 20) / 10.5 KB (N = 30) of LDS less, which is what lets three workgroups of horizon 30 share a CU
+    if (!FG) { c.T = fp; fp += NI * N; c.Z = fp; fp += NI * N; }
+    else { c.T = fg_base + (size_t)REC_N * N; c.Z = c.T + NI * N; }
     c.d = fp; fp += NS * N;
     c.geoA = fp; fp += GEO * N;
     c.Bval = fp; fp += 3 * NU; c.Aval = fp; fp += 3 * NS + 3;
@@ -1017,7 +1022,7 @@ template <int NT, int NC, bool FG>
 __device__ __attribute__((noinline)) void stage_post(lds_t lds, int Nrt, float* fg_base, int k)
 {
     CMPC_PHASE_PROLOGUE;
-    stage_post_body<NT, FG && NC == 20>(c, prm, tid, k, c.P0, c.Qb);
+    stage_post_body<NT, FG && (NC > 0)>(c, prm, tid, k, c.P0, c.Qb);
 }
 
 // ---- Riccati backward sweep (matrices + right-hand side of the affine step, or of a centring step with target
@@ -1386,7 +1391,7 @@ __device__ __attribute__((noinline)) void phase_costate(lds_t lds, int Nrt, floa
 // FG: the per-stage factors (Linv, Ws: 915 floats per stage) live in global scratch instead of LDS
 // (horizons whose LDS image would exceed 160 KiB)
 template <int NT, int NC, bool FG>
-__global__ __launch_bounds__(NT, FG ? (NC == 20 ? 3 : 2) : 1) void cmpc_solve_kernel(CmpcParams kp)
+__global__ __launch_bounds__(NT, FG ? (NC > 0 ? 3 : 2) : 1) void cmpc_solve_kernel(CmpcParams kp)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int b = blockIdx.x;
@@ -1737,7 +1742,7 @@ extern "C" size_t cmpc_solver_lds_bytes(int N, int factors_global)
     const size_t nlam = (size_t)NS * (N + 1) + (((size_t)NS * (N + 1)) & 1);
     const size_t dbl = nlam + 90 + 40 + 40 + 16 + 40 + 4 * NI + 8;
     const size_t flt = (size_t)NU * RLD + (size_t)NPAN * RLD + 96 + ((L.np + 3) & ~3)
-                       + ((size_t)NS * (N + 1) + (size_t)NU * N + 2 * (size_t)NI * N) + (size_t)NS * N
+                       + ((size_t)NS * (N + 1) + (size_t)NU * N + (factors_global ? 0 : 2 * (size_t)NI * N)) + (size_t)NS * N
                        + (size_t)GEO * N + ((NXA * PLD + 3) & ~3) + NS * 16 + ((NXA * GLD + 3) & ~3) + 2 * DSET_F + 40 + 40 + 8
                        + 2 * DSET_I + 4 + CMPC_NMAX + NTRI / 2 + (factors_global ? 0 : (size_t)REC_N * N);
     return ((sizeof(CmpcConsts) + 15) & ~(size_t)15) + dbl * 8 + flt * 4;
@@ -1761,7 +1766,7 @@ extern "C" int cmpc_launch_solver(const CmpcParams* prm, size_t lds_bytes, hipSt
     kern = cmpc_solve_kernel<NT, 20, false>;
 #else
     if (prm->scratch) {
-        kern = prm->N == 20 ? cmpc_solve_kernel<NT, 20, true> : cmpc_solve_kernel<NT, 0, true>;
+        kern = prm->N == 20 ? cmpc_solve_kernel<NT, 20, true> : (prm->N == 30 ? cmpc_solve_kernel<NT, 30, true> : cmpc_solve_kernel<NT, 0, true>);
     } else {
         switch (prm->N) {  // horizons of the shipped configurations get compile-time layouts
             case 10: kern = cmpc_solve_kernel<NT, 10, false>; break;
