@@ -58,9 +58,9 @@
 #define REC_WT 576
 #define REC_ZERO 572
 #define REC_N CMPC_REC_N
-// Workgroups per CU the HBM-factor variants are compiled for (register budget 512 / that per lane): three for the compile-time
-// horizons N = 20 and N = 30, whose LDS images (45 / 52 KB) fit three times into a CU (measured at N = 12, where 2 and 3 both
-// fit: +22 % with three); two for the run-time-N variant
+// The HBM-factor variants are compiled for three workgroups per CU (168 registers per lane): their LDS image fits three times into
+// a CU up to N = 30 (45 KB at N = 20, 52 KB at N = 30).  Measured at N = 12, B = 8192, where 2, 3 and 4 all fit: 22.4 / 17.1 /
+// 17.8 ms -- at four (128 registers) the spills of the factorisation and the sweeps cost more than the fourth workgroup brings.
 
 namespace {
 
@@ -1022,7 +1022,7 @@ template <int NT, int NC, bool FG>
 __device__ __attribute__((noinline)) void stage_post(lds_t lds, int Nrt, float* fg_base, int k)
 {
     CMPC_PHASE_PROLOGUE;
-    stage_post_body<NT, FG && (NC > 0)>(c, prm, tid, k, c.P0, c.Qb);
+    stage_post_body<NT, FG>(c, prm, tid, k, c.P0, c.Qb);
 }
 
 // ---- Riccati backward sweep (matrices + right-hand side of the affine step, or of a centring step with target
@@ -1391,7 +1391,7 @@ __device__ __attribute__((noinline)) void phase_costate(lds_t lds, int Nrt, floa
 // FG: the per-stage factors (Linv, Ws: 915 floats per stage) live in global scratch instead of LDS
 // (horizons whose LDS image would exceed 160 KiB)
 template <int NT, int NC, bool FG>
-__global__ __launch_bounds__(NT, FG ? (NC > 0 ? 3 : 2) : 1) void cmpc_solve_kernel(CmpcParams kp)
+__global__ __launch_bounds__(NT, FG ? 3 : 1) void cmpc_solve_kernel(CmpcParams kp)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int b = blockIdx.x;
