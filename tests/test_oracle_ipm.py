@@ -170,3 +170,24 @@ def test_structured_solver_reaches_the_reference_solved_argmin(name, which, gold
         assert e["com"] < 1e-6 and e["forces"] < 2e-5 and e["pos"] < 5e-6 and e["dcom"] < 1e-5, e   # (landing positions: w_pos = 200 here, 10x softer than the shipped configs)
         f, _ = ol.nlp_fg(oc, X[b], P[b])
         assert abs(f - d["f_star"][b]) <= 1e-7 * abs(f)
+
+
+@pytest.mark.parametrize("gen,seed", [(cm.synthetic.config2_perturbed_com, 9101), (cm.synthetic.config3_external_push, 9102),
+                                      (cm.synthetic.config5_footstep_candidates, 9103)])
+def test_structured_solver_equals_the_independent_solver_on_fresh_problems(gen, seed):
+    """The GPU batch tests compare hundreds of problems with ipm_ref.c, the CPU statement of the same stage-structured
+    algorithm.  That comparison is only as independent as ipm_ref.c is right: here it is checked, on seeds no golden holds,
+    against the generic IPOPT-style solver that knows nothing about stages (sparse KKT on x, p, lbg/ubg as the reference
+    states them)."""
+    B = 6
+    cfg, P, X0 = gen(B, seed=seed)
+    P, X0 = P.astype(np.float32).astype(np.float64), X0.astype(np.float32).astype(np.float64)
+    oc = problem_nlp.oracle_cfg(cfg)
+    Xs, info = ol.ref_solve_batch(oc, P, X0, ol.ipm_opts(tol=1e-9, mu_min=1e-10), nthreads=4)
+    assert (info[:, 5] == 0).all()
+    for b in range(B):
+        lb, ub = problem_nlp.bounds(cfg, P[b])
+        r = ipm_generic.solve(oc, P[b], lb, ub, X0[b], tol=1e-9, max_iter=400)
+        assert r["status"] == 0
+        e = parity.errors(cfg.N, P[b], Xs[b], r["x"])
+        assert e["com"] < 1e-6 and e["dcom"] < 1e-5 and e["force0"] < 1e-6 and e["forces"] < 2e-5 and e["pos"] < 5e-6, e
