@@ -29,6 +29,8 @@
 // workgroup barriers; the per-stage factors they read are stored transposed, a row per lane.
 #include "cmpc_device.h"
 
+#include <cstdlib>
+
 #define NS CMPC_NS
 #define NF CMPC_NF
 #define NQ CMPC_NQ
@@ -769,17 +771,19 @@ __device__ inline void stage_pre_body(const Ctx& c, const CmpcConsts& prm, int t
     const bool pk = k > 0;
     const float* u = c.U + NU * k;
     PROF_DECL;
-        // ---- phase 1: G = P [B;E] (39 x 30): thread <-> column, its three non-zeros in registers, rows strided over 8 ----
+        // ---- phase 1: G = P [B;E] (39 x 30): thread <-> column, its three non-zeros in registers, rows strided over RG
+        // row groups (8 with 256 threads, 16 with 512) ----
         {
+            constexpr int RG = NT / 32, RR = (NXA + RG - 1) / RG;
             const int nrow = havep ? NXA : NS;
-            if (tid < 8 * NU) {
+            if (tid < RG * NU) {
                 const int i = tid % NU, r0 = tid / NU;
                 const int b0 = c.Brow[3 * i], b1 = c.Brow[3 * i + 1], b2 = c.Brow[3 * i + 2];
                 const float w0 = c.Bval[3 * i], w1 = c.Bval[3 * i + 1], w2 = c.Bval[3 * i + 2];
                 const bool addp = havep && i < NF;
 #pragma unroll
-                for (int rr = 0; rr < 5; ++rr) {
-                    const int r = r0 + 8 * rr;
+                for (int rr = 0; rr < RR; ++rr) {
+                    const int r = r0 + RG * rr;
                     if (r < nrow) {
                         const float* Pr = Pcur + r * PLD;
                         float v = Pr[b0] * w0 + Pr[b1] * w1 + Pr[b2] * w2;
@@ -795,11 +799,14 @@ __device__ inline void stage_pre_body(const Ctx& c, const CmpcConsts& prm, int t
         // its 3x3 diagonal blocks and the 450 of the panel rows Qus^T.  Wave 2: the diagonal blocks of Quu in float64
         // (cost, barrier and Levenberg terms).  Wave 3: qu in float64. ----
         PROF2_DECL;
-        if (tid < 128) {
-            quu_qus_triples<2>(c, prm, k, havep, tid);   // triples 0..255; wave 2 takes 256..284 after its float64 blocks
+        // (512 threads: waves 0-3 one round of triples, wave 4 the diagonal blocks, wave 5 Pd and qu; waves 6-7 idle here)
+        constexpr int T2 = NT >= 512 ? 256 : 128;    // threads on the float32 triples
+        if (tid < T2) {
+            if (NT >= 512) quu_qus_triples<1>(c, prm, k, havep, tid);
+            else quu_qus_triples<2>(c, prm, k, havep, tid);   // triples 0..255; the next wave takes 256..284 after its float64 blocks
             PROF2(5);
-        } else if (tid < 192) {
-          const int t = tid - 128;
+        } else if (tid < T2 + 64) {
+          const int t = tid - T2;
           if (t < 60) {
             // lower entry w of diagonal block t / 6: (row, col) = (0,0) (1,0) (1,1) (2,0) (2,1) (2,2)
             const int b = t / 6, w = t - 6 * b;
@@ -829,10 +836,11 @@ __device__ inline void stage_pre_body(const Ctx& c, const CmpcConsts& prm, int t
             PROF4(7);
           }
           if (t < 285 - 256) quu_qus_triples<1>(c, prm, k, havep, 256 + t);
-        } else if (tid >= 192) {
-          // wave 3: Pd = P [d; 0] + pv (float64), then qu, which reads it (same wave: LDS order suffices)
-          if (tid < 192 + NXA) {
-            const int r = tid - 192;
+        } else if (tid < T2 + 128) {
+          // next wave: Pd = P [d; 0] + pv (float64), then qu, which reads it (same wave: LDS order suffices)
+          constexpr int T3 = T2 + 64;
+          if (tid < T3 + NXA) {
+            const int r = tid - T3;
             double acc = c.pv[r];
             if (r < NS || havep) {
 #pragma unroll
@@ -841,9 +849,9 @@ __device__ inline void stage_pre_body(const Ctx& c, const CmpcConsts& prm, int t
             c.Pd[r] = acc;
           }
           wave_lds_sync();
-          if (tid < 192 + NU) {
+          if (tid < T3 + NU) {
             // qu (float64 -> float: it vanishes at convergence, so float keeps its relative accuracy)
-            const int iq = tid - 192;
+            const int iq = tid - T3;
             double g;
             if (iq < NF) {
                 g = grad_sym(c, prm, k, iq);
@@ -894,10 +902,14 @@ __device__ inline void stage_post_body(const Ctx& c, const CmpcConsts& prm, int 
     PROF_DECL;
         // ---- phase 4: P = [Qss 0; 0 D] - W^T W  (rows of the panel are W^T rows; p rows pre-scaled by -D) ----
         {
-            // 2x2 output tiles: thread <-> tile (bi, bj), bj <= bi, of the 39x39 (or 15x15) lower triangle
+            // 2x2 output tiles: thread <-> tile (bi, bj), bj <= bi, of the 39x39 (or 15x15) lower triangle.  With 512 threads
+            // a tile belongs to a pair of lanes: each takes half of the 30-term dot products (four of the eight float4
+            // columns), the halves meet through one DPP swap, each lane stores one row of the tile.
             const int nb = pk ? 20 : 8;
-            if (tid < nb * (nb + 1) / 2) {
-                const unsigned short t = c.tri[tid];
+            constexpr bool SPLIT = NT >= 512;
+            const int tile = SPLIT ? (tid >> 1) : tid, khalf = SPLIT ? (tid & 1) : 0;
+            if (tile < nb * (nb + 1) / 2) {
+                const unsigned short t = c.tri[tile];
                 const int bi = t >> 8, bj = t & 255;
                 const int i0 = 2 * bi, j0 = 2 * bj, ncol = pk ? NXA : NS;
                 const float4* ri0 = reinterpret_cast<const float4*>(c.Pan + i0 * RLD);
@@ -905,7 +917,22 @@ __device__ inline void stage_post_body(const Ctx& c, const CmpcConsts& prm, int 
                 const float4* rj0 = reinterpret_cast<const float4*>(c.Pan + j0 * RLD);
                 const float4* rj1 = reinterpret_cast<const float4*>(c.Pan + (j0 + 1) * RLD);
                 float a00 = 0.f, a01 = 0.f, a10 = 0.f, a11 = 0.f;
-                if (LEAN) {
+                if (SPLIT) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int q4 = 4 * khalf + q;
+                        const float4 x0 = ri0[q4], x1 = ri1[q4], y0 = rj0[q4], y1 = rj1[q4];
+                        a00 += (x0.x * y0.x + x0.y * y0.y) + (x0.z * y0.z + x0.w * y0.w);
+                        a01 += (x0.x * y1.x + x0.y * y1.y) + (x0.z * y1.z + x0.w * y1.w);
+                        a10 += (x1.x * y0.x + x1.y * y0.y) + (x1.z * y0.z + x1.w * y0.w);
+                        a11 += (x1.x * y1.x + x1.y * y1.y) + (x1.z * y1.z + x1.w * y1.w);
+                    }
+                    // the other half from the neighbouring lane (quad_perm [1,0,3,2])
+                    a00 += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(a00), 0xB1, 0xF, 0xF, true));
+                    a01 += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(a01), 0xB1, 0xF, 0xF, true));
+                    a10 += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(a10), 0xB1, 0xF, 0xF, true));
+                    a11 += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(a11), 0xB1, 0xF, 0xF, true));
+                } else if (LEAN) {
                     // The 168-register variants (three workgroups per CU) take the 32 row loads in two rounds: hoisted all
                     // at once they need the callee-saved registers, and saving those at every call of this function was
                     // 18 GB of scratch traffic per 4096-problem batch (columns 30, 31 of the panel are stored as zeros).
@@ -942,12 +969,14 @@ __device__ inline void stage_post_body(const Ctx& c, const CmpcConsts& prm, int 
                     Pnew[i * PLD + j] = r;
                     Pnew[j * PLD + i] = r;
                 };
-                put(i0, j0, a00); put(i0, j0 + 1, a01); put(i0 + 1, j0, a10); put(i0 + 1, j0 + 1, a11);
+                if (!SPLIT || khalf == 0) { put(i0, j0, a00); put(i0, j0 + 1, a01); }
+                if (!SPLIT || khalf == 1) { put(i0 + 1, j0, a10); put(i0 + 1, j0 + 1, a11); }
             }
             // gradient of the value function (float64)
             const int ncol = pk ? NXA : NS;
-            if (tid >= 216 && tid < 216 + NXA) {  // threads beyond the 210 tile owners
-                const int i = tid - 216;
+            constexpr int TG = SPLIT ? 448 : 216;    // threads beyond the tile owners (210, or 420 with split tiles)
+            if (tid >= TG && tid < TG + NXA) {
+                const int i = tid - TG;
                 double v = 0.0;
                 if (i < ncol) {
                     // W^T lq: lq vanishes at convergence, so the dot product itself is fine in float32
@@ -1760,22 +1789,33 @@ extern "C" int cmpc_trace_read(float* out) { return (int)hipMemcpyFromSymbol(out
 
 extern "C" int cmpc_launch_solver(const CmpcParams* prm, size_t lds_bytes, hipStream_t stream)
 {
-    constexpr int NT = 256;
+    constexpr int NT = 256;     // HBM-factor variants: three workgroups per CU
+    constexpr int NR = 512;     // resident variants (one workgroup per CU): eight waves, the phases every thread takes part in scale
+    static const bool wide = !(std::getenv("CMPC_THREADS") && std::atoi(std::getenv("CMPC_THREADS")) == 256);   // developer knob
+    int nthreads = NT;
     void (*kern)(CmpcParams) = nullptr;
 #ifdef CMPC_ONLY_N20  // developer builds: one instantiation
-    kern = cmpc_solve_kernel<NT, 20, false>;
+    kern = cmpc_solve_kernel<NR, 20, false>; nthreads = NR; (void)wide;
 #else
     if (prm->scratch) {
         kern = prm->N == 20 ? cmpc_solve_kernel<NT, 20, true> : (prm->N == 30 ? cmpc_solve_kernel<NT, 30, true> : cmpc_solve_kernel<NT, 0, true>);
     } else {
-        switch (prm->N) {  // horizons of the shipped configurations get compile-time layouts
-            case 10: kern = cmpc_solve_kernel<NT, 10, false>; break;
-            case 12: kern = cmpc_solve_kernel<NT, 12, false>; break;
-            case 13: kern = cmpc_solve_kernel<NT, 13, false>; break;  // ergoCubSN000
-            case 15: kern = cmpc_solve_kernel<NT, 15, false>; break;  // iCubGazeboV3
-            case 20: kern = cmpc_solve_kernel<NT, 20, false>; break;  // ergoCubGazeboV1
-            case 22: kern = cmpc_solve_kernel<NT, 22, false>; break;  // ergoCubSN001
-            default: kern = cmpc_solve_kernel<NT, 0, false>; break;
+        if (wide) {
+            nthreads = NR;
+            switch (prm->N) {  // horizons of the shipped configurations get compile-time layouts
+                case 10: kern = cmpc_solve_kernel<NR, 10, false>; break;
+                case 12: kern = cmpc_solve_kernel<NR, 12, false>; break;
+                case 13: kern = cmpc_solve_kernel<NR, 13, false>; break;  // ergoCubSN000
+                case 15: kern = cmpc_solve_kernel<NR, 15, false>; break;  // iCubGazeboV3
+                case 20: kern = cmpc_solve_kernel<NR, 20, false>; break;  // ergoCubGazeboV1
+                case 22: kern = cmpc_solve_kernel<NR, 22, false>; break;  // ergoCubSN001
+                default: kern = cmpc_solve_kernel<NR, 0, false>; break;
+            }
+        } else {
+            switch (prm->N) {
+                case 20: kern = cmpc_solve_kernel<NT, 20, false>; break;
+                default: kern = cmpc_solve_kernel<NT, 0, false>; break;
+            }
         }
     }
 #endif
@@ -1783,6 +1823,6 @@ extern "C" int cmpc_launch_solver(const CmpcParams* prm, size_t lds_bytes, hipSt
     if (e != hipSuccess) return (int)e;
     CmpcParams kp = *prm;
     kp.lds_words = (int)(lds_bytes / 4);
-    hipLaunchKernelGGL(kern, dim3(prm->B), dim3(NT), lds_bytes, stream, kp);
+    hipLaunchKernelGGL(kern, dim3(prm->B), dim3(nthreads), lds_bytes, stream, kp);
     return (int)hipGetLastError();
 }
