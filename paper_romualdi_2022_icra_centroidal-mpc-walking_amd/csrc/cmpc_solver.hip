@@ -73,8 +73,9 @@ __device__ float g_trace[64 * 8];  // per iteration of workgroup 0: mu, ep, ec, 
 #define PROF_DECL long long pt_ = __builtin_amdgcn_s_memtime()
 #define PROF(slot) do { long long n_ = __builtin_amdgcn_s_memtime(); if (threadIdx.x == 0 && blockIdx.x == 0) g_prof[slot] += n_ - pt_; pt_ = n_; } while (0)
 #define PROF2_DECL long long pt2_ = __builtin_amdgcn_s_memtime()
-#define PROF3(slot) do { long long n_ = __builtin_amdgcn_s_memtime(); if (threadIdx.x == 192 && blockIdx.x == 0) g_prof[slot] += n_ - pt2_; pt2_ = n_; } while (0)
-#define PROF4(slot) do { long long n_ = __builtin_amdgcn_s_memtime(); if (threadIdx.x == 128 && blockIdx.x == 0) g_prof[slot] += n_ - pt2_; pt2_ = n_; } while (0)
+// (first lane of the wave that builds qu / the diagonal blocks in phase 2: the wave numbers depend on the thread count NT)
+#define PROF3(slot) do { long long n_ = __builtin_amdgcn_s_memtime(); if (threadIdx.x == (NT >= 512 ? 320 : 192) && blockIdx.x == 0) g_prof[slot] += n_ - pt2_; pt2_ = n_; } while (0)
+#define PROF4(slot) do { long long n_ = __builtin_amdgcn_s_memtime(); if (threadIdx.x == (NT >= 512 ? 256 : 128) && blockIdx.x == 0) g_prof[slot] += n_ - pt2_; pt2_ = n_; } while (0)
 #define PROF2(slot) do { long long n_ = __builtin_amdgcn_s_memtime(); if (threadIdx.x == 0 && blockIdx.x == 0) g_prof[slot] += n_ - pt2_; pt2_ = n_; } while (0)
 #else
 #define PROF_DECL
