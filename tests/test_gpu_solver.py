@@ -135,6 +135,33 @@ def test_config4_shard_of_8192():
     parity.assert_within(cfg.N, worst)
 
 
+@pytest.mark.parametrize("N,dt,B", [(13, 0.1, 16), (15, 0.1, 16), (22, 0.06, 16), (17, 0.06, 16), (13, 0.1, 400), (22, 0.06, 400)])
+def test_every_shipped_horizon(N, dt, B):
+    """The horizons of the robots the reference ships configurations for (ergoCubSN000: 13, iCubGazeboV3: 15, ergoCubSN001: 22;
+    SURVEY 8a-1) are compile-time instantiations of the resident kernel; 17 takes the run-time-N variant; B = 400 > #CU takes the
+    HBM-factor variant with run-time N.  Walking problems with pushes, against the oracle."""
+    cfg = cm.config.ergocub_gazebo_v1(N, dt)
+    base, P0, X00 = cm.synthetic.config3_external_push(B, N=N, seed=31 + N)
+    assert base.N == N
+    # config3's generator is written for dt = 0.06: rebuild the schedule for this sampling time through the class-level generator
+    from cmpc_amd.synthetic import _walking_lists, _tile, _finish, ROBOT_MASS
+    from cmpc_amd.contacts import sample_schedule
+    rng = np.random.default_rng(31 + N)
+    sched = _tile(sample_schedule(cfg, _walking_lists(cfg, N // 3, N // 3)), B)
+    com0 = np.array([0.0, 0.0, 0.7]) + rng.uniform(-0.02, 0.02, (B, 3))
+    dcom0, h0 = rng.uniform(-0.1, 0.1, (B, 3)), rng.uniform(-0.05, 0.05, (B, 3))
+    ref = np.broadcast_to(np.array([0.0, 0.0, 0.7]), (B, N + 1, 3)).copy()
+    f_ext = np.zeros((B, N, 3))
+    f_ext[:, :2, :2] = (rng.uniform(-30.0, 30.0, (B, 2)) / ROBOT_MASS)[:, None, :]
+    _, P, X0 = _finish(cfg, sched, com0, dcom0, h0, ref, np.zeros((B, N + 1, 3)), f_ext)
+    P32, X032 = P.astype(np.float32), X0.astype(np.float32)
+    s = cm.BatchSolver(cfg, B)
+    X, info, rc = s.solve_host(P32, X032)
+    assert rc == 0 and (info[:, 5] == 0).all(), s.last_error
+    sample = np.arange(0, B, max(1, B // 16))
+    parity.assert_within(N, _worst(cfg, P32[sample], X[sample], _oracle(cfg, P32[sample], X032[sample])))
+
+
 def test_device_and_host_entry_points_agree():
     import torch
     cfg, P, X0 = cm.synthetic.config3_external_push(64)
