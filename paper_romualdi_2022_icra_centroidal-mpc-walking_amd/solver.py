@@ -277,8 +277,9 @@ class CentroidalMPC:
         return True
 
     def set_state(self, com, dcom, angular_momentum, external_wrench=None) -> bool:
-        """com, dcom, angular_momentum: [B,3]; external_wrench [B,6] (applied at every knot) or
-        [B,N,6] or None.  h and the wrench are mass-normalised (CentroidalMPCBlock.cpp:403-410)."""
+        """com, dcom, angular_momentum: [B,3]; external_wrench [B,6] (the measured wrench: enters the first knot only, like
+        the C++ facade -- BLF's own rule is not visible from the reference tree, parity unpinned) or [B,N,6] (per knot) or
+        None.  h and the wrench are mass-normalised (CentroidalMPCBlock.cpp:403-410)."""
         if not self._need_init():
             return False
         B, N = self._batch, self.cfg.N
@@ -288,7 +289,9 @@ class CentroidalMPC:
         if external_wrench is not None:
             w = np.asarray(external_wrench, np.float32)
             if w.ndim == 2:
-                w = np.broadcast_to(w[:, None, :], (B, N, 6))
+                w0 = w
+                w = np.zeros((B, N, 6), np.float32)
+                w[:, 0, :] = w0
             w = np.ascontiguousarray(w.reshape(B, N, 6))
         return self._ok(self._lib.cmpc_set_state(self._h, st.ctypes.data, w.ctypes.data if w is not None else None))
 
