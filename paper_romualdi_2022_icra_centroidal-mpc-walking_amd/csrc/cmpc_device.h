@@ -10,6 +10,7 @@
 #define CMPC_NI 44   // inequality rows per stage: 32 friction + 6 q upper + 6 q lower
 #define CMPC_REC_N 1088  // floats of one stage's factor record (layout: cmpc_solver.hip)
 #define CMPC_NMAX 40 // largest horizon the kernels are built for
+#define CMPC_TZ_LDS_NMAX 20  // HBM-factor variant: slacks / multipliers stay in LDS up to this horizon (three workgroups per CU still fit)
 #define CMPC_INFO_N 8
 
 // x / p index layout of the reference's generated NLP (tmp.c:62-67)

@@ -61,7 +61,7 @@
 #define REC_ZERO 572
 #define REC_N CMPC_REC_N
 // The HBM-factor variants are compiled for three workgroups per CU (168 registers per lane): their LDS image fits three times into
-// a CU up to N = 30 (45 KB at N = 20, 52 KB at N = 30).  Measured at N = 12, B = 8192, where 2, 3 and 4 all fit: 22.4 / 17.1 /
+// a CU up to N = 30 (52 KB at N = 20 and at N = 30).  Measured at N = 12, B = 8192, where 2, 3 and 4 all fit: 22.4 / 17.1 /
 // 17.8 ms -- at four (128 registers) the spills of the factorisation and the sweeps cost more than the fourth workgroup brings.
 
 namespace {
@@ -140,9 +140,10 @@ __device__ inline void make_ctx(Ctx& c, char* smem, int N, float* fg_base)
     c.sp = fp; fp += (c.L.np() + 3) & ~3;
     c.S = fp; fp += NS * (N + 1); c.U = fp; fp += NU * N;
     // slacks and multipliers: only ever touched by element-wise loops over all rows and by the descriptor builder that runs
-    // under the factorisation, never on a critical path -> with the factors in HBM they live there too (behind the records):
-    // 7 KB (N = 20) / 10.5 KB (N = 30) of LDS less, which is what lets three workgroups of horizon 30 share a CU
-    if (!FG) { c.T = fp; fp += NI * N; c.Z = fp; fp += NI * N; }
+    // under the factorisation, never on a critical path -> with the factors in HBM they live there too (behind the records)
+    // whenever the horizon is longer than CMPC_TZ_LDS_NMAX: 10.5 KB of LDS less at N = 30, which is what lets three workgroups
+    // of that horizon share a CU.  Up to N = 20 the image fits three times with them in LDS (52 KB), which is 1.5 % faster.
+    if (!FG || N <= CMPC_TZ_LDS_NMAX) { c.T = fp; fp += NI * N; c.Z = fp; fp += NI * N; }
     else { c.T = fg_base + (size_t)REC_N * N; c.Z = c.T + NI * N; }
     c.d = fp; fp += NS * N;
     c.geoA = fp; fp += GEO * N;
@@ -1772,7 +1773,7 @@ extern "C" size_t cmpc_solver_lds_bytes(int N, int factors_global)
     const size_t nlam = (size_t)NS * (N + 1) + (((size_t)NS * (N + 1)) & 1);
     const size_t dbl = nlam + 90 + 40 + 40 + 16 + 40 + 4 * NI + 8;
     const size_t flt = (size_t)NU * RLD + (size_t)NPAN * RLD + 96 + ((L.np + 3) & ~3)
-                       + ((size_t)NS * (N + 1) + (size_t)NU * N + (factors_global ? 0 : 2 * (size_t)NI * N)) + (size_t)NS * N
+                       + ((size_t)NS * (N + 1) + (size_t)NU * N + ((factors_global && N > CMPC_TZ_LDS_NMAX) ? 0 : 2 * (size_t)NI * N)) + (size_t)NS * N
                        + (size_t)GEO * N + ((NXA * PLD + 3) & ~3) + NS * 16 + ((NXA * GLD + 3) & ~3) + 2 * DSET_F + 40 + 40 + 8
                        + 2 * DSET_I + 4 + CMPC_NMAX + NTRI / 2 + (factors_global ? 0 : (size_t)REC_N * N);
     return ((sizeof(CmpcConsts) + 15) & ~(size_t)15) + dbl * 8 + flt * 4;
