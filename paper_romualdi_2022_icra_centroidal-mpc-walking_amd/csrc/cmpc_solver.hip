@@ -42,6 +42,10 @@
 #define RLD 36     // leading dim of the row-major float panels (16-byte aligned rows)
 #define NPAN 46    // panel rows: 15 (Qus^T) + 30 (I) + 1 (qu)
 #define GEO 36     // floats of stage geometry: r[24] | Fc[6] | Fsum[3] | pad
+// the factorisation of phase 3 on one wave (1) or two (0), per variant (FG = factors in HBM, three workgroups per CU)
+#ifndef CMPC_ONE_WAVE_FACTOR
+#define CMPC_ONE_WAVE_FACTOR(FG) (FG)
+#endif
 #define NTRI 256   // entries of the lower-triangle index table (the users need 210: 2x2 tiles of a 39x39)
 // Per-stage factor record (floats), in LDS or -- FG kernels -- in HBM scratch.  Phase 3 leaves column m of
 // L^{-1} and column j of Ws = L^{-1} Qus in the registers of one lane, so both are stored transposed, one
@@ -482,6 +486,14 @@ __device__ inline double rcp_d(double x)
 // The row lives in 15 register pairs (vv[j / 2][j % 2] = entry j) so that the trailing update can use packed FMAs.
 typedef float float2v __attribute__((ext_vector_type(2)));
 #define VE(j) vv[(j) >> 1][(j) & 1]
+// ONE: the whole factorisation on one wave.  76 rows do not fit 64 lanes, but the L rows of the first blocks are finished
+// (and never read again: broadcasts only come from rows below the pivot block, and L itself is not kept) long before the
+// identity rows of the last columns start to differ from unit vectors: at block LATE_B the lanes of L rows 0..NLATE-1 are
+// re-used for the identity rows LATE_M0..NU-1, which is exact because such a row is e_m until block m / 3.
+#define LATE_B 6
+#define LATE_M0 18
+#define NLATE (NU - LATE_M0)
+template <bool ONE>
 __device__ __forceinline__ bool chol_solve_fused(float2v (&vv)[NU / 2], double (&dd)[3], int lane, int fixedmask)
 {
     const int myblk = lane / 3, jm = lane - 3 * myblk;
@@ -489,6 +501,12 @@ __device__ __forceinline__ bool chol_solve_fused(float2v (&vv)[NU / 2], double (
 #pragma unroll
     for (int b = 0; b < NU / 3; ++b) {
         const int j0 = 3 * b;
+        if (ONE && b == LATE_B) {
+            if (lane < NLATE) {
+#pragma unroll
+                for (int cc = 0; cc < NU; ++cc) VE(cc) = (cc == LATE_M0 + lane) ? 1.f : 0.f;
+            }
+        }
         // (opaque copies: the lane predicates are recomputed per block instead of living in hoisted, spilled SGPR pairs)
         int myb = myblk, jmo = jm;
         asm volatile("" : "+v"(myb), "+v"(jmo));
@@ -558,11 +576,15 @@ __device__ __forceinline__ bool chol_solve_fused(float2v (&vv)[NU / 2], double (
 
 // phase 3 of a backward stage, kept out of line so that its ~40 VGPRs of matrix rows and its
 // stream of v_readlane broadcasts get a register allocation of their own
+template <bool ONE>
 __device__ __forceinline__ void stage_factor(const float* QuuF, const double* QuuD, float* Pan, float* rec,
                                           float D0, float D1, float D2, int* flag, int tid, int fixedmask)
 {
     const int lane = tid & 63, wv = tid >> 6;
-    const int prow = lane - 30 + 34 * wv;  // panel row of lanes >= 30
+    // panel row of lanes >= 30.  Two waves: rows 0..33 on wave 0, 34..45 on wave 1 (both repeat the L rows).  One wave: Qus rows
+    // 0..14, the qu row (NPAN - 1), identity rows m = 0..17; identity rows 18..29 take over lanes 0..11 at block LATE_B.
+    const int pi = lane - 30;
+    const int prow = ONE ? (pi < NS ? pi : (pi == NS ? NPAN - 1 : pi - 1)) : pi + 34 * wv;
     const bool isL = lane < NU;
     const bool active = isL || prow < NPAN;
     float2v vv[NU / 2];
@@ -588,18 +610,20 @@ __device__ __forceinline__ void stage_factor(const float* QuuF, const double* Qu
         }
     }
     PROF2(28);
-    const bool bad = chol_solve_fused(vv, dd, lane, fixedmask);
+    const bool bad = chol_solve_fused<ONE>(vv, dd, lane, fixedmask);
     PROF2(29);
     if (bad && tid == 0) *flag = 1;
-    if (!isL && active) {
+    const bool late = ONE && lane < NLATE;             // this lane now holds identity row LATE_M0 + lane
+    const int srow = late ? NS + LATE_M0 + lane : prow;  // the panel row this lane stores
+    if (late || (!isL && active)) {
         // one row per lane, 16-byte stores: the panel row for phase 4 and the record row for the sweeps
-        const int m = prow - NS;                       // identity rows: column m of L^{-1}
-        const bool isId = prow >= NS && prow < NS + NU;
+        const int m = srow - NS;                       // identity rows: column m of L^{-1}
+        const bool isId = srow >= NS && srow < NS + NU;
         float sc = 1.f;
         if (isId) sc = m < NF ? -((m % 3 == 0) ? D0 : ((m % 3 == 1) ? D1 : D2)) : 0.f;
-        const int jw = prow < NS ? prow : 15;          // Ws column j, or the lq row
+        const int jw = srow < NS ? srow : 15;          // Ws column j, or the lq row
         const int I = isId ? (m >> 2) : 0;
-        float* prow_p = Pan + prow * RLD;
+        float* prow_p = Pan + srow * RLD;
         float* rrow = rec + (isId ? ub_row(m) - 4 * I : REC_WT + 32 * jw);
         // one store per float4 for both kinds of row; float4s left of an identity row's diagonal block go to row 30
         // of U, a row whose only readers are lanes that discard what they compute (REC_ZERO is row 31)
@@ -1021,7 +1045,7 @@ __device__ __attribute__((noinline)) void phase_factor(lds_t lds, int Nrt, float
 {
     CMPC_PHASE_PROLOGUE;
     const int fixedmask = (~c.qmask[k]) & 63;
-    stage_factor(c.QuuF, c.QuuD, c.Pan, c.Lf + (size_t)REC_N * k, prm.D[0], prm.D[1], prm.D[2], c.flag, tid, fixedmask);
+    stage_factor<CMPC_ONE_WAVE_FACTOR(FG)>(c.QuuF, c.QuuD, c.Pan, c.Lf + (size_t)REC_N * k, prm.D[0], prm.D[1], prm.D[2], c.flag, tid, fixedmask);
 }
 template <int NT, int NC, bool FG>
 __device__ __attribute__((noinline)) void stage_pre(lds_t lds, int Nrt, float* fg_base, int k, bool havep, bool use_exact, float reg, float cmu)
@@ -1075,8 +1099,8 @@ __device__ int riccati_backward(lds_t lds, const Ctx& c, const CmpcConsts& prm, 
     for (int k = N - 1; k >= 0; --k) {
         stage_pre<NT, NC, FG>(lds, N, fg_base, k, k < N - 1, use_exact, reg, cmu);
         PROF_DECL;
-        if (tid < 128) phase_factor<NC, FG>(lds, N, fg_base, k);
-        else stage_qss<NT, NC, FG>(lds, N, fg_base, k, use_exact, cmu);
+        if (tid < (CMPC_ONE_WAVE_FACTOR(FG) ? 64 : 128)) phase_factor<NC, FG>(lds, N, fg_base, k);
+        else if (tid >= 128) stage_qss<NT, NC, FG>(lds, N, fg_base, k, use_exact, cmu);
         __syncthreads();
         PROF(3);
         if (*c.flag) return 1;
