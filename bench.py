@@ -284,8 +284,8 @@ def cpu_baseline(cfg, P32, X032, tol, mu_min, sample):
         ol.ref_solve_batch(oc, P[b:b + 1], X0[b:b + 1], ol.ipm_opts(tol=tol, mu_min=mu_min, max_iter=60), nthreads=1)
         lat.append((time.perf_counter() - t1) * 1e3)
     return {"value": round(sample / dt, 1), "unit": "solves/s", "cores": cores, "kind": "port",
-            "label": "CPU restatement baseline (oracle/ipm_ref.c, float64 Riccati interior point, same tolerances, without the GPU path's "
-                     "final extrapolation step), not IPOPT+MUMPS",
+            "label": "CPU restatement baseline (oracle/ipm_ref.c, float64 Riccati interior point, same tolerances; its final extrapolation "
+                     "step is not counted in its iteration figure), not IPOPT+MUMPS",
             "p50_solve_latency_ms_1thread": round(float(np.median(lat)), 3),
             "sample": f"{sample} problems of the same workload, float64, OpenMP x{cores}, {dt:.1f} s wall, "
                       f"{int((info[:, 5] == 0).sum())}/{sample} converged, mean {info[:, 0].mean():.1f} iterations"}
