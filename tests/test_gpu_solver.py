@@ -312,3 +312,35 @@ def test_compact_output_kernel_matches_the_torch_restatement():
     torch.cuda.synchronize()
     assert tuple(out.shape) == tuple(ref.shape)
     np.testing.assert_array_equal(out.cpu().numpy(), ref.cpu().numpy())
+
+
+def test_iteration_budget_exhausted_is_reported_per_problem():
+    """ipopt_max_iteration too small: the reference's advance() returns false (CentroidalMPCBlock.cpp:615-619); here every
+    problem reports status 1 with its last iterate (finite), and the batch call says CMPC_ERR_NOT_CONVERGED."""
+    cfg, P, X0 = cm.synthetic.config3_external_push(32)
+    s = cm.BatchSolver(cfg, 32, max_iterations=2)
+    X, info, rc = s.solve_host(P.astype(np.float32), X0.astype(np.float32))
+    assert rc == -3 and "converge" in s.last_error
+    assert (info[:, 5] == 1).all() and (info[:, 0] == 2).all()
+    assert np.isfinite(X).all()
+
+
+@pytest.mark.parametrize("B", [5, 1024])
+def test_a_poisoned_problem_does_not_touch_its_neighbours(B):
+    """One problem of the batch gets NaN parameters (resident variant at B = 5, HBM-factor variant at B = 1024): it must
+    come back flagged (status != 0) without hanging the kernel, and every other problem bit-identical to a clean solve."""
+    cfg, P, X0 = cm.synthetic.config3_external_push(B, seed=21)
+    P32, X032 = P.astype(np.float32), X0.astype(np.float32)
+    s = cm.BatchSolver(cfg, B)
+    X1, info1, rc1 = s.solve_host(P32, X032)
+    assert rc1 == 0 and (info1[:, 5] == 0).all()
+    bad = B // 2
+    Pb = P32.copy()
+    Pb[bad, :] = np.nan
+    X2, info2, rc2 = s.solve_host(Pb, X032)
+    assert rc2 == -3
+    assert info2[bad, 5] != 0
+    keep = np.arange(B) != bad
+    assert (info2[keep, 5] == 0).all()
+    np.testing.assert_array_equal(X1[keep], X2[keep])
+    np.testing.assert_array_equal(info1[keep, 0], info2[keep, 0])
