@@ -95,7 +95,7 @@ struct Ctx {
     int N;
     const float* sp;     // parameter vector in LDS
     float *S, *U, *T, *Z;
-    double* LAM;
+    float* LAM;            // costates (they only enter the exact-Hessian term and the exported duals: float)
     float *dS, *dU, *dT, *dZ, *d;
     float *Lf;             // per-stage factor records (REC_N floats each)
     float *geoA;           // N x GEO
@@ -121,7 +121,6 @@ __device__ inline void make_ctx(Ctx& c, char* smem, int N, float* fg_base)
     c.L.N = N;
     c.N = N;
     double* dp = reinterpret_cast<double*>(smem + KBYTES);
-    c.LAM = dp; dp += NS * (N + 1) + ((NS * (N + 1)) & 1);
     c.QuuD = dp; dp += 90;
     c.pv = dp; dp += 40; c.pn = dp; dp += 40; c.qs = dp; dp += 16; c.Pd = dp; dp += 40;
     c.sig = dp; dp += NI; c.gco = dp; dp += NI; dp += 2 * NI;  // (second descriptor set)
@@ -150,6 +149,7 @@ __device__ inline void make_ctx(Ctx& c, char* smem, int N, float* fg_base)
     if (!FG || N <= CMPC_TZ_LDS_NMAX) { c.T = fp; fp += NI * N; c.Z = fp; fp += NI * N; }
     else { c.T = fg_base + (size_t)REC_N * N; c.Z = c.T + NI * N; }
     c.d = fp; fp += NS * N;
+    c.LAM = fp; fp += NS * (N + 1);
     c.geoA = fp; fp += GEO * N;
     c.Bval = fp; fp += 3 * NU; c.Aval = fp; fp += 3 * NS + 3;
     c.arow = fp; fp += 96 + 12; fp += DSET_F;  // (second descriptor set)
@@ -715,7 +715,7 @@ __device__ inline void stage_desc_body(const Ctx& c, const CmpcConsts& prm, int 
             const int a = (t - 96) / 3, b = (t - 96) % 3;
             float sv = 0.f;
             if (use_exact && a != b) {
-                const float lv = (float)c.LAM[NS * (k + 1) + 6 + (3 - a - b)];
+                const float lv = c.LAM[NS * (k + 1) + 6 + (3 - a - b)];
                 sv = prm.dt * (((b - a + 3) % 3 == 1) ? -lv : lv);
             }
             c.arow[96 + t - 96] = sv;
@@ -1377,48 +1377,69 @@ __device__ void costate_update(const Ctx& c, const CmpcConsts& prm, int tid, flo
         // lane j < 15 owns costate component j.  Everything below is one formula with per-lane coefficients:
         //   lam_j = w (s_j - ref_j + ds_j) + sj pv_j + ce pv_je + cg (pv_{6+a1} F_a2 - pv_{6+a2} F_a1)
         //           + eg (dF_a1 lamh_a2 - dF_a2 lamh_a1)                       (exact Hessian only)
-        const int j = tid < NS ? tid : 0;
+        const bool own = tid < NS;
+        const int j = own ? tid : 0;
         const int ja = j < 3 ? j : (j >= 9 ? (j - 9) % 3 : 0), ja1 = (ja + 1) % 3, ja2 = (ja + 2) % 3;
         const int jct = j >= 12 ? 1 : 0;
         const int roff = j < 3 ? c.L.pComref() + j : (j < 6 ? c.L.pComref() : (j < 9 ? c.L.pHref() + j - 6 : c.L.pNom(jct) + ja));
-        const double wc = j == 0 ? 2.0 * prm.w_com0 : (j == 1 ? 2.0 * prm.w_com1 : (j < 6 ? 0.0 : (j < 9 ? 2.0 * prm.w_h : 2.0 * prm.w_pos)));
+        const float wc = j == 0 ? 2.f * prm.w_com0 : (j == 1 ? 2.f * prm.w_com1 : (j < 6 ? 0.f : (j < 9 ? 2.f * prm.w_h : 2.f * prm.w_pos)));
         const int gfo = j < 3 ? 30 : 24 + 3 * jct;       // Fsum or Fc of the foot (geometry record)
         const int dfo = j < 3 ? 6 : 3 * jct;             // total or per-foot force-step sum
-        const int je = (j >= 3 && j < 6) ? j - 3 : 0;
-        const double ce = (j >= 3 && j < 6) ? (double)prm.dt : 0.0;
-        const double eg = !use_exact ? 0.0 : (j < 3 ? -(double)prm.dt : (j >= 9 ? (double)prm.dt : 0.0));
-        if (tid < 3) c.qs[tid] = c.LAM[NS * N + 6 + tid];  // lam_h,N the Hessian used
-        if (tid < NS) {
-            const double w = j == 2 ? (double)prm.wz2[N] : wc;
-            c.pv[tid] = w * (((double)c.S[NS * N + j] - (double)c.sp[roff + 3 * N]) + (double)c.dS[NS * N + j]);
-        }
-        wave_lds_sync();
-        if (tid < NS) c.LAM[NS * N + tid] += (double)ap * (c.pv[tid] - c.LAM[NS * N + tid]);
-        for (int k = N - 1; k >= 1; --k) {
-            double v = 0.0, lold = 0.0;
-            if (tid < NS) {
-                const float* geo = c.geoA + GEO * k;
-                const float* F = geo + gfo;
-                const float* dF = c.d + NS * k + dfo;
-                const double gam = jct ? gam_of(c, 1, k) : gam_of(c, 0, k);
-                const double sj = j >= 9 ? gam : 1.0;
-                const double cg = j < 3 ? (double)prm.dt : (j >= 9 ? -(double)prm.dt * gam : 0.0);
-                const double w = j == 2 ? (double)prm.wz2[k] : wc;
-                const double* pv = c.pv;
-                const double* lh = c.qs;  // lam_h of stage k+1 as the Hessian used it
-                lold = c.LAM[NS * k + j];
-                v = w * (((double)c.S[NS * k + j] - (double)c.sp[roff + 3 * k]) + (double)c.dS[NS * k + j])
-                    + sj * pv[j] + ce * pv[je] + cg * (pv[6 + ja1] * (double)F[ja2] - pv[6 + ja2] * (double)F[ja1])
-                    + eg * ((double)dF[ja1] * lh[ja2] - (double)dF[ja2] * lh[ja1]);
+        const int gco = c.L.pGam(jct);
+        // per-lane coefficients: sj = sA + sB gam, cg = cgA + cgB gam, ce, eg; 0/1 masks picking components a1, a2 of a 3-vector
+        const float sA = j >= 9 ? 0.f : 1.f, sB = j >= 9 ? 1.f : 0.f;
+        const float cgA = j < 3 ? prm.dt : 0.f, cgB = j >= 9 ? -prm.dt : 0.f;
+        const float ce = (j >= 3 && j < 6) ? prm.dt : 0.f;
+        const float eg = !use_exact ? 0.f : (j < 3 ? -prm.dt : (j >= 9 ? prm.dt : 0.f));
+        const float m10 = ja1 == 0, m11 = ja1 == 1, m12 = ja1 == 2, m20 = ja2 == 0, m21 = ja2 == 1, m22 = ja2 == 2;
+        // The recursion runs in registers.  Per stage: the linear-momentum costates of stage k+1 reach the lanes of the CoM-velocity
+        // rows by a DPP row shift, its three angular-momentum costates (and, for the exact Hessian, the old ones the Hessian used)
+        // are broadcast with v_readlane and meet per-lane coefficient vectors built from the cross-product operands.  Everything
+        // that does not depend on the recursion (state, reference, step, forces, old costate) is fetched one stage ahead, two
+        // operand sets alternating -- a stage costs ~45 VALU instructions and no LDS round trip (it was two, in float64).
+        struct Ops { float s, ref, ds, F1, F2, dF1, dF2, gam, wz, lold; };
+        auto fetch = [&](int k) {
+            Ops o;
+            const float* geo = c.geoA + GEO * k;
+            o.s = c.S[NS * k + j]; o.ref = c.sp[roff + 3 * k]; o.ds = c.dS[NS * k + j];
+            o.F1 = geo[gfo + ja1]; o.F2 = geo[gfo + ja2];
+            o.dF1 = c.d[NS * k + dfo + ja1]; o.dF2 = c.d[NS * k + dfo + ja2];
+            o.gam = c.sp[gco + k];
+            o.wz = prm.wz2[k];
+            o.lold = c.LAM[NS * k + j];
+            return o;
+        };
+        float lold = c.LAM[NS * N + j];   // (lanes 6..8: lam_h,N as the Hessian used it)
+        float pvj = (j == 2 ? prm.wz2[N] : wc) * ((c.S[NS * N + j] - c.sp[roff + 3 * N]) + c.dS[NS * N + j]);
+        auto step = [&](int k, const Ops& o) {
+            // off the recursion: base term and coefficient vectors
+            const float base = (j == 2 ? o.wz : wc) * ((o.s - o.ref) + o.ds);
+            const float sj = fmaf(sB, o.gam, sA), cg = fmaf(cgB, o.gam, cgA);
+            const float cF1 = cg * o.F1, cF2 = cg * o.F2;
+            const float c0 = m10 * cF2 - m20 * cF1, c1 = m11 * cF2 - m21 * cF1, c2 = m12 * cF2 - m22 * cF1;
+            float v = base;
+            if (use_exact) {
+                const float eF1 = eg * o.dF1, eF2 = eg * o.dF2;
+                const float g0 = m20 * eF1 - m10 * eF2, g1 = m21 * eF1 - m11 * eF2, g2 = m22 * eF1 - m12 * eF2;
+                v += readlane_f(lold, 6) * g0 + readlane_f(lold, 7) * g1 + readlane_f(lold, 8) * g2;
             }
-            wave_lds_sync();
-            if (tid < NS) {
-                c.pv[j] = v;
-                if (j >= 6 && j < 9) c.qs[j - 6] = lold;
-                c.LAM[NS * k + j] = lold + (double)ap * (v - lold);
-            }
-            wave_lds_sync();
+            // on it
+            const float pe = __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(pvj), 0x113, 0xF, 0xF, true));  // row_shr:3
+            v += sj * pvj + ce * pe + readlane_f(pvj, 6) * c0 + readlane_f(pvj, 7) * c1 + readlane_f(pvj, 8) * c2;
+            lold = o.lold;
+            pvj = v;
+            if (own) c.LAM[NS * k + j] = lold + ap * (v - lold);
+        };
+        Ops oa = fetch(N > 1 ? N - 1 : 0), ob;
+        if (own) c.LAM[NS * N + j] = lold + ap * (pvj - lold);
+        int k = N - 1;
+        for (; k >= 2; k -= 2) {
+            ob = fetch(k - 1);
+            step(k, oa);
+            oa = fetch(k - 2);
+            step(k - 1, ob);
         }
+        if (k == 1) step(1, oa);
     }
     __syncthreads();
 }
@@ -1525,7 +1546,7 @@ __global__ __launch_bounds__(NT, FG ? 3 : 1) void cmpc_solve_kernel(CmpcParams k
                 c.S[e] = v;
                 // costates: zero, or -- warm start with duals -- the previous solve's shifted by one knot (they only enter the
                 // first iteration's exact-Hessian term; every iteration recomputes them)
-                c.LAM[e] = (use_duals && !cold) ? (double)dprev[NS * (k < N ? k + 1 : N) + i] : 0.0;
+                c.LAM[e] = (use_duals && !cold) ? dprev[NS * (k < N ? k + 1 : N) + i] : 0.f;
             }
             for (int e = tid; e < NU * N; e += NT) {
                 const int k = e / NU, m = e % NU;
@@ -1772,7 +1793,7 @@ __global__ __launch_bounds__(NT, FG ? 3 : 1) void cmpc_solve_kernel(CmpcParams k
         if (kp.duals) {
             __syncthreads();   // (the warm-start reads of this block's own record above are long done; other blocks own other rows)
             float* dq = kp.duals + (size_t)b * (NS * (N + 1) + 2 * NI * N);
-            for (int e = tid; e < NS * (N + 1); e += NT) dq[e] = (float)c.LAM[e];
+            for (int e = tid; e < NS * (N + 1); e += NT) dq[e] = c.LAM[e];
             for (int e = tid; e < NI * N; e += NT) { dq[NS * (N + 1) + e] = c.T[e]; dq[NS * (N + 1) + NI * N + e] = c.Z[e]; }
         }
         if (kp.info && tid == 0) {
@@ -1794,10 +1815,9 @@ extern "C" size_t cmpc_solver_lds_bytes(int N, int factors_global)
 {
     CmpcLayout L;
     cmpc_layout_init(L, N);
-    const size_t nlam = (size_t)NS * (N + 1) + (((size_t)NS * (N + 1)) & 1);
-    const size_t dbl = nlam + 90 + 40 + 40 + 16 + 40 + 4 * NI + 8;
+    const size_t dbl = 90 + 40 + 40 + 16 + 40 + 4 * NI + 8;
     const size_t flt = (size_t)NU * RLD + (size_t)NPAN * RLD + 96 + ((L.np + 3) & ~3)
-                       + ((size_t)NS * (N + 1) + (size_t)NU * N + ((factors_global && N > CMPC_TZ_LDS_NMAX) ? 0 : 2 * (size_t)NI * N)) + (size_t)NS * N
+                       + ((size_t)NS * (N + 1) + (size_t)NU * N + ((factors_global && N > CMPC_TZ_LDS_NMAX) ? 0 : 2 * (size_t)NI * N)) + (size_t)NS * N + (size_t)NS * (N + 1)
                        + (size_t)GEO * N + ((NXA * PLD + 3) & ~3) + NS * 16 + ((NXA * GLD + 3) & ~3) + 2 * DSET_F + 40 + 40 + 8
                        + 2 * DSET_I + 4 + CMPC_NMAX + NTRI / 2 + (factors_global ? 0 : (size_t)REC_N * N);
     return ((sizeof(CmpcConsts) + 15) & ~(size_t)15) + dbl * 8 + flt * 4;
