@@ -153,7 +153,7 @@ __device__ inline void make_ctx(Ctx& c, char* smem, int N, float* fg_base)
     c.geoA = fp; fp += GEO * N;
     c.Bval = fp; fp += 3 * NU; c.Aval = fp; fp += 3 * NS + 3;
     c.arow = fp; fp += 96 + 12; fp += DSET_F;  // (second descriptor set)
-    c.fpv = fp; fp += 40; c.fpn = fp; fp += 40; c.red = fp; fp += 8;
+    c.fpv = fp; fp += 40; c.fpn = fp; fp += 40; c.red = fp; fp += 24;
     c.Brow = reinterpret_cast<int*>(fp); fp += 3 * NU;
     c.Arow = reinterpret_cast<int*>(fp); fp += 3 * NS + 3; fp += DSET_I;  // (second descriptor set)
     c.flag = reinterpret_cast<int*>(fp); fp += 4;
@@ -274,26 +274,66 @@ __device__ inline double grad_sym(const Ctx& c, const CmpcConsts& prm, int k, in
     return 2.0 * prm.w_sym * (e - 0.25 * gam * esum);
 }
 
-template <int NT>
-__device__ inline float block_max(float v, float* red, int tid)
+__device__ inline float readlane_f(float x, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), lane)); }
+__device__ inline double readlane_d(double x, int lane)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(x), lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(x), lane);
+    return __hiloint2double(hi, lo);
+}
+
+// ---- reductions over the workgroup.  Inside a wave: DPP (quad swaps, half-row and row mirrors leave every row of 16 lanes
+// reduced, v_readlane joins the four rows) -- no LDS crossbar, ~12 instructions; __shfl_xor is six dependent ds_bpermute,
+// twelve for a double.  Across waves: one LDS slot per wave and value; values that are needed together share the two barriers. ----
+template <int CTRL>
+__device__ inline float dpp_f(float v) { return __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), CTRL, 0xF, 0xF, true)); }
+template <int CTRL>
+__device__ inline double dpp_d(double v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ inline float wave_max(float v)
+{
+    v = fmaxf(v, dpp_f<0xB1>(v));    // quad_perm [1,0,3,2]
+    v = fmaxf(v, dpp_f<0x4E>(v));    // quad_perm [2,3,0,1]
+    v = fmaxf(v, dpp_f<0x141>(v));   // row_half_mirror
+    v = fmaxf(v, dpp_f<0x140>(v));   // row_mirror
+    return fmaxf(fmaxf(readlane_f(v, 0), readlane_f(v, 16)), fmaxf(readlane_f(v, 32), readlane_f(v, 48)));
+}
+__device__ inline double wave_sum(double v)
+{
+    v += dpp_d<0xB1>(v);
+    v += dpp_d<0x4E>(v);
+    v += dpp_d<0x141>(v);
+    v += dpp_d<0x140>(v);
+    return (readlane_d(v, 0) + readlane_d(v, 16)) + (readlane_d(v, 32) + readlane_d(v, 48));
+}
+// maxima of up to three values at once (red: 3 slots per wave)
+template <int NT, int NV>
+__device__ inline void block_maxn(float (&v)[NV], float* red, int tid)
 {
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    for (int q = 0; q < NV; ++q) v[q] = wave_max(v[q]);
     __syncthreads();
-    if ((tid & 63) == 0) red[tid >> 6] = v;
-    __syncthreads();
-    float r = red[0];
+    if ((tid & 63) == 0) {
 #pragma unroll
-    for (int w = 1; w < NT / 64; ++w) r = fmaxf(r, red[w]);
-    return r;
+        for (int q = 0; q < NV; ++q) red[3 * (tid >> 6) + q] = v[q];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+        float r = red[q];
+#pragma unroll
+        for (int w = 1; w < NT / 64; ++w) r = fmaxf(r, red[3 * w + q]);
+        v[q] = r;
+    }
 }
-template <int NT>
-__device__ inline float block_min(float v, float* red, int tid) { return -block_max<NT>(-v, red, tid); }
 template <int NT>
 __device__ inline double block_sum(double v, double* red, int tid)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    v = wave_sum(v);
     __syncthreads();
     if ((tid & 63) == 0) red[tid >> 6] = v;
     __syncthreads();
@@ -301,6 +341,20 @@ __device__ inline double block_sum(double v, double* red, int tid)
 #pragma unroll
     for (int w = 1; w < NT / 64; ++w) r += red[w];
     return r;
+}
+// two maxima and one float64 sum behind one pair of barriers (the residual pass)
+template <int NT>
+__device__ inline void block_max2_sum(float& m0, float& m1, double& sm, float* red, double* redd, int tid)
+{
+    m0 = wave_max(m0); m1 = wave_max(m1); sm = wave_sum(sm);
+    __syncthreads();
+    if ((tid & 63) == 0) { red[3 * (tid >> 6)] = m0; red[3 * (tid >> 6) + 1] = m1; redd[tid >> 6] = sm; }
+    __syncthreads();
+    float r0 = red[0], r1 = red[1];
+    double rs = redd[0];
+#pragma unroll
+    for (int w = 1; w < NT / 64; ++w) { r0 = fmaxf(r0, red[3 * w]); r1 = fmaxf(r1, red[3 * w + 1]); rs += redd[w]; }
+    m0 = r0; m1 = r1; sm = rs;
 }
 
 // ---- geometry of every stage for the current iterate: r_cj = R c_j + pos_c - com (8x3), Fc (2x3,
@@ -457,13 +511,6 @@ __device__ inline float AB_step(const Ctx& c, const CmpcConsts& prm, int k, int 
     return gam * ds[i] + (1.f - gam) * land;
 }
 
-__device__ inline float readlane_f(float x, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), lane)); }
-__device__ inline double readlane_d(double x, int lane)
-{
-    const int lo = __builtin_amdgcn_readlane(__double2loint(x), lane);
-    const int hi = __builtin_amdgcn_readlane(__double2hiint(x), lane);
-    return __hiloint2double(hi, lo);
-}
 
 // ---- fused Cholesky + panel solve, one wave, rows in registers, 3x3 pivot blocks ----
 // lanes 0..29: row `lane` of the symmetric matrix (v[c], c <= lane, float; its own 3x3 diagonal
@@ -1353,8 +1400,9 @@ __device__ void step_lengths(const Ctx& c, int tid, float tau, float& ap, float&
         if (dt_ < 0.f) a_p = fminf(a_p, -tau * c.T[e] / dt_);
         if (dz_ < 0.f) a_d = fminf(a_d, -tau * c.Z[e] / dz_);
     }
-    ap = block_min<NT>(a_p, c.red, tid);
-    ad = block_min<NT>(a_d, c.red, tid);
+    float m[2] = {-a_p, -a_d};
+    block_maxn<NT, 2>(m, c.red, tid);
+    ap = -m[0]; ad = -m[1];
 }
 
 // new costates (backward, wave 0), blended into LAM with step ap:
@@ -1612,9 +1660,10 @@ __global__ __launch_bounds__(NT, FG ? 3 : 1) void cmpc_solve_kernel(CmpcParams k
                     l_mu += (double)t * z;
                 }
             }
-            ep = block_max<NT>(l_ep, c.red, tid);
-            const float ec = block_max<NT>(l_ec, c.red, tid);
-            mu_cur = (float)(block_sum<NT>(l_mu, c.redd, tid) / (double)nrow);
+            block_max2_sum<NT>(l_ep, l_ec, l_mu, c.red, c.redd, tid);
+            ep = l_ep;
+            const float ec = l_ec;
+            mu_cur = (float)(l_mu / (double)nrow);
             if (it == 0 && mu_adapt > 0.f) {
                 // cold start: the initial barrier parameter scales with the squared initial infeasibility (z = mu / t)
                 const float mu0 = fminf(fmaxf(mu_adapt * ep * ep, 0.03f), 0.5f);
@@ -1751,8 +1800,9 @@ __global__ __launch_bounds__(NT, FG ? 3 : 1) void cmpc_solve_kernel(CmpcParams k
                     l_fm = fmaxf(l_fm, fabsf(c.U[e]));
                 } else l_st = fmaxf(l_st, fabsf(du));
             }
-            const float fm = block_max<NT>(l_fm, c.red, tid);
-            const float step = ap * block_max<NT>(fmaxf(l_st, l_sf / fm), c.red, tid);
+            float m3[3] = {l_st, l_sf, l_fm};
+            block_maxn<NT, 3>(m3, c.red, tid);   // (the largest force is uniform: max(l_st, l_sf / fm) over threads = max(max l_st, max l_sf / fm))
+            const float step = ap * fmaxf(m3[0], m3[1] / m3[2]);
             step_prev = step_out;
             step_out = step;
             err = fmaxf(ep, ec);
@@ -1818,7 +1868,7 @@ extern "C" size_t cmpc_solver_lds_bytes(int N, int factors_global)
     const size_t dbl = 90 + 40 + 40 + 16 + 40 + 4 * NI + 8;
     const size_t flt = (size_t)NU * RLD + (size_t)NPAN * RLD + 96 + ((L.np + 3) & ~3)
                        + ((size_t)NS * (N + 1) + (size_t)NU * N + ((factors_global && N > CMPC_TZ_LDS_NMAX) ? 0 : 2 * (size_t)NI * N)) + (size_t)NS * N + (size_t)NS * (N + 1)
-                       + (size_t)GEO * N + ((NXA * PLD + 3) & ~3) + NS * 16 + ((NXA * GLD + 3) & ~3) + 2 * DSET_F + 40 + 40 + 8
+                       + (size_t)GEO * N + ((NXA * PLD + 3) & ~3) + NS * 16 + ((NXA * GLD + 3) & ~3) + 2 * DSET_F + 40 + 40 + 24
                        + 2 * DSET_I + 4 + CMPC_NMAX + NTRI / 2 + (factors_global ? 0 : (size_t)REC_N * N);
     return ((sizeof(CmpcConsts) + 15) & ~(size_t)15) + dbl * 8 + flt * 4;
 }
