@@ -879,68 +879,98 @@ __device__ inline void stage_pre_body(const Ctx& c, const CmpcConsts& prm, int t
             else quu_qus_triples<2>(c, prm, k, havep, tid);   // triples 0..255; the next wave takes 256..284 after its float64 blocks
             PROF2(5);
         } else if (tid < T2 + 64) {
+          // ---- the ten 3x3 diagonal blocks of Quu in float64 (60 lower entries).  Branch-free on clamped indices so that all
+          // loads of a dependency level are in flight together: level 0 the descriptor of column i, the barrier coefficients
+          // and friction rows of the corner, the E^T P entry; level 1 the three G entries the descriptor points at ----
           const int t = tid - T2;
-          if (t < 60) {
-            // lower entry w of diagonal block t / 6: (row, col) = (0,0) (1,0) (1,1) (2,0) (2,1) (2,2)
-            const int b = t / 6, w = t - 6 * b;
-            const int rr = w >= 3 ? 2 : (w >= 1 ? 1 : 0), cc = w - rr * (rr + 1) / 2;
-            const int i = 3 * b + rr, j = 3 * b + cc;
-            const int b0 = c.Brow[3 * i], b1 = c.Brow[3 * i + 1], b2 = c.Brow[3 * i + 2];
-            float vf = c.Bval[3 * i] * c.G[b0 * GLD + j] + c.Bval[3 * i + 1] * c.G[b1 * GLD + j] + c.Bval[3 * i + 2] * c.G[b2 * GLD + j];
-            if (havep && i < NF) vf += c.G[(NS + i) * GLD + j];
-            double v = (double)vf;
-            if (i < NF) {
-                if (i == j) {
-                    const double gam = gam_of(c, i / 12, k);
-                    v += 2.0 * prm.w_sym * (1.0 - 0.25 * gam * (2.0 - gam));
-                    if (pk) v += (double)prm.D[i % 3];
-                    v += (double)reg;
-                }
-                const int r0 = 4 * b;
+          const int tc = t < 60 ? t : 59;
+          // lower entry w of diagonal block b: (row, col) = (0,0) (1,0) (1,1) (2,0) (2,1) (2,2)
+          const int b = tc / 6, w = tc - 6 * b;
+          const int rr = w >= 3 ? 2 : (w >= 1 ? 1 : 0), cc = w - rr * (rr + 1) / 2;
+          const int i = 3 * b + rr, j = 3 * b + cc;
+          const bool isF = i < NF, dg = i == j;
+          const int b0 = c.Brow[3 * i], b1 = c.Brow[3 * i + 1], b2 = c.Brow[3 * i + 2];
+          const float w0 = c.Bval[3 * i], w1 = c.Bval[3 * i + 1], w2 = c.Bval[3 * i + 2];
+          const float ge = c.G[(NS + (isF ? i : 0)) * GLD + j];
+          const int r0 = isF ? 4 * b : 0;             // friction rows of the corner
+          const int iq = isF ? 0 : i - 24;            // landing-offset component
+          double sg[4], ar[4], ac[4];
 #pragma unroll
-                for (int f = 0; f < 4; ++f)
-                    v += c.sig[r0 + f] * (double)c.arow[3 * (r0 + f) + rr] * (double)c.arow[3 * (r0 + f) + cc];
-            } else if (i == j) {
-                const bool fr = qfree(c, k, i - 24);
-                v = fr ? v + c.sig[32 + i - 24] + c.sig[38 + i - 24] + (double)reg : 1.0;  // fixed q: exact identity row
-            }
-            c.QuuD[9 * b + 3 * rr + cc] = v;
+          for (int f = 0; f < 4; ++f) { sg[f] = c.sig[r0 + f]; ar[f] = (double)c.arow[3 * (r0 + f) + rr]; ac[f] = (double)c.arow[3 * (r0 + f) + cc]; }
+          const double slo = c.sig[32 + iq], shi = c.sig[38 + iq];
+          const bool fr = qfree(c, k, iq);
+          const double gam = gam_of(c, isF ? i / 12 : 0, k);
+          const float g0 = c.G[b0 * GLD + j], g1 = c.G[b1 * GLD + j], g2 = c.G[b2 * GLD + j];
+          float vf = w0 * g0 + w1 * g1 + w2 * g2;
+          if (havep && isF) vf += ge;
+          double v = (double)vf;
+          double vF = v;
+          if (dg) {
+              vF += 2.0 * prm.w_sym * (1.0 - 0.25 * gam * (2.0 - gam));
+              if (pk) vF += (double)prm.D[i % 3];
+              vF += (double)reg;
+          }
+#pragma unroll
+          for (int f = 0; f < 4; ++f) vF += sg[f] * ar[f] * ac[f];
+          const double vQ = dg ? (fr ? v + slo + shi + (double)reg : 1.0) : v;   // fixed q: exact identity row
+          if (t < 60) {
+            c.QuuD[9 * b + 3 * rr + cc] = isF ? vF : vQ;
             c.QuuF[i * RLD + j] = 0.f;  // the float copy of a diagonal block collects the updates by earlier blocks
             PROF4(7);
           }
-          if (t < 285 - 256) quu_qus_triples<1>(c, prm, k, havep, 256 + t);
+          if (NT < 512 && t < 285 - 256) quu_qus_triples<1>(c, prm, k, havep, 256 + t);
         } else if (tid < T2 + 128) {
-          // next wave: Pd = P [d; 0] + pv (float64), then qu, which reads it (same wave: LDS order suffices)
+          // ---- Pd = P [d; 0] + pv (float64), then qu, which reads it (same wave: LDS order suffices).  Every lane of the wave
+          // computes both on clamped indices, branch-free: two levels of loads instead of a chain of small dependent ones ----
           constexpr int T3 = T2 + 64;
-          if (tid < T3 + NXA) {
-            const int r = tid - T3;
-            double acc = c.pv[r];
-            if (r < NS || havep) {
+          const int l = tid - T3;
+          const int r = l < NXA ? l : NXA - 1, iq = l < NU ? l : NU - 1;
+          float pc[NS], dc[NS];
 #pragma unroll
-                for (int a = 0; a < NS; ++a) acc += (double)Pcur[r * PLD + a] * (double)c.d[NS * k + a];
-            }
-            c.Pd[r] = acc;
+          for (int a = 0; a < NS; ++a) { pc[a] = Pcur[a * PLD + r]; dc[a] = c.d[NS * k + a]; }   // (P is stored with both triangles:
+          // row a, column r is the same number as row r, column a, and consecutive lanes read consecutive banks)
+          const double pvr = c.pv[r];
+          const bool isF = iq < NF;
+          const int m = isF ? iq : 0, ct = m / 12, ax = m % 3;   // force component (clamped)
+          const int q = isF ? 0 : iq - 24;                         // landing-offset component (clamped)
+          const float* uf = u + 12 * ct + ax;
+          const float u0 = uf[0], u1 = uf[3], u2 = uf[6], u3 = uf[9], um = u[m];
+          const float up = c.U[NU * (pk ? k - 1 : 0) + m];
+          const double gam = gam_of(c, ct, k);
+          const int r0 = 4 * (m / 3);
+          double gc[4], ar[4];
+#pragma unroll
+          for (int f = 0; f < 4; ++f) { gc[f] = c.gco[r0 + f]; ar[f] = (double)c.arow[3 * (r0 + f) + ax]; }
+          const double glo = c.gco[32 + q], ghi = c.gco[38 + q];
+          const bool fr = qfree(c, k, q);
+          const int b0 = c.Brow[3 * iq], b1 = c.Brow[3 * iq + 1], b2 = c.Brow[3 * iq + 2];
+          const double w0 = c.Bval[3 * iq], w1 = c.Bval[3 * iq + 1], w2 = c.Bval[3 * iq + 2];
+          {
+            double acc = 0.0;
+#pragma unroll
+            for (int a = 0; a < NS; ++a) acc += (double)pc[a] * (double)dc[a];
+            if (l < NXA) c.Pd[r] = (r < NS || havep) ? pvr + acc : pvr;   // (rows >= NS of the terminal P do not exist: discarded)
           }
-          wave_lds_sync();
-          if (tid < T3 + NU) {
-            // qu (float64 -> float: it vanishes at convergence, so float keeps its relative accuracy)
-            const int iq = tid - T3;
-            double g;
-            if (iq < NF) {
-                g = grad_sym(c, prm, k, iq);
-                const int r0 = 4 * (iq / 3);
+          // gradient of the symmetry cost (grad_sym), barrier terms, force-rate term
+          const double mean = 0.25 * ((double)u0 + (double)u1 + (double)u2 + (double)u3);
+          const double esum = 4.0 * mean * (1.0 - gam);
+          double gF = 2.0 * prm.w_sym * (((double)um - gam * mean) - 0.25 * gam * esum);
 #pragma unroll
-                for (int f = 0; f < 4; ++f) g += c.gco[r0 + f] * (double)c.arow[3 * (r0 + f) + iq % 3];
-                if (pk) g += (double)prm.D[iq % 3] * ((double)u[iq] - (double)c.U[NU * (k - 1) + iq]);
-                if (havep) g += c.Pd[NS + iq];
-            } else {
-                const int q = iq - 24;
-                g = qfree(c, k, q) ? c.gco[32 + q] - c.gco[38 + q] : 0.0;
-            }
-            g += Bt_vec<double>(c, prm, k, iq, c.Pd);
+          for (int f = 0; f < 4; ++f) gF += gc[f] * ar[f];
+          if (pk) gF += (double)prm.D[ax] * ((double)um - (double)up);
+          const double gQ = fr ? glo - ghi : 0.0;
+          wave_lds_sync();
+          // B^T Pd through the column descriptor of B (the same float coefficients the Hessian blocks are built from)
+          const double pe = c.Pd[NS + m], p0 = c.Pd[b0], p1 = c.Pd[b1], p2 = c.Pd[b2];
+          double g = isF ? (havep ? gF + pe : gF) : gQ;
+          g += w0 * p0 + w1 * p1 + w2 * p2;
+          if (l < NU) {
+            // qu (float64 -> float: it vanishes at convergence, so float keeps its relative accuracy)
             c.Pan[(NPAN - 1) * RLD + iq] = (float)g;
             PROF3(8);
           }
+        } else if (NT >= 512 && tid >= T2 + 128 && tid < T2 + 128 + 285 - 256) {
+          quu_qus_triples<1>(c, prm, k, havep, 256 + tid - (T2 + 128));   // (eight waves: the last 29 triples on an idle wave)
         }
         __syncthreads();
         PROF(2);
