@@ -1019,6 +1019,12 @@ __device__ inline void stage_post_body(const Ctx& c, const CmpcConsts& prm, int 
                 const float4* ri1 = reinterpret_cast<const float4*>(c.Pan + (i0 + 1) * RLD);
                 const float4* rj0 = reinterpret_cast<const float4*>(c.Pan + j0 * RLD);
                 const float4* rj1 = reinterpret_cast<const float4*>(c.Pan + (j0 + 1) * RLD);
+                // what the products are subtracted from (Qss or D), fetched before the dot products: off their dependency chain
+                auto base_of = [&](int i, int j) {
+                    const float qb = Qb[(i < NS ? i : 0) * 16 + (j < NS ? j : 0)];
+                    return i < NS ? qb : (i == j ? prm.D[(i - NS) % 3] : 0.f);
+                };
+                const float b00 = base_of(i0, j0), b01 = base_of(i0, j0 + 1), b10 = base_of(i0 + 1, j0), b11 = base_of(i0 + 1, j0 + 1);
                 float a00 = 0.f, a01 = 0.f, a10 = 0.f, a11 = 0.f;
                 if (SPLIT) {
 #pragma unroll
@@ -1063,17 +1069,14 @@ __device__ inline void stage_post_body(const Ctx& c, const CmpcConsts& prm, int 
                     }
                 }
                 }
-                auto put = [&](int i, int j, float acc) {
+                auto put = [&](int i, int j, float base, float acc) {
                     if (j > i || i >= ncol) return;
-                    float base = 0.f;
-                    if (i < NS) base = Qb[i * 16 + j];
-                    else if (i == j) base = prm.D[(i - NS) % 3];
                     const float r = base - acc;
                     Pnew[i * PLD + j] = r;
                     Pnew[j * PLD + i] = r;
                 };
-                if (!SPLIT || khalf == 0) { put(i0, j0, a00); put(i0, j0 + 1, a01); }
-                if (!SPLIT || khalf == 1) { put(i0 + 1, j0, a10); put(i0 + 1, j0 + 1, a11); }
+                if (!SPLIT || khalf == 0) { put(i0, j0, b00, a00); put(i0, j0 + 1, b01, a01); }
+                if (!SPLIT || khalf == 1) { put(i0 + 1, j0, b10, a10); put(i0 + 1, j0 + 1, b11, a11); }
             }
             // gradient of the value function (float64)
             const int ncol = pk ? NXA : NS;
