@@ -775,7 +775,7 @@ __device__ inline void stage_desc_body(const Ctx& c, const CmpcConsts& prm, int 
 // R rounds per thread (ids id0, id0 + 128, ...): addresses, then descriptor loads, then G loads, then arithmetic, then
 // stores, so that the rounds overlap ----
 template <int R>
-__device__ inline void quu_qus_triples(const Ctx& c, const CmpcConsts& prm, int k, bool havep, int id0)
+__device__ inline void quu_qus_triples(const Ctx& c, const CmpcConsts& prm, int k, bool havep, int id0, int tpk)
 {
     const float* Gp = c.G;
     int dsc[R], col0[R], sto[R], eo[R], es[R], symc[R];
@@ -788,7 +788,7 @@ __device__ inline void quu_qus_triples(const Ctx& c, const CmpcConsts& prm, int 
         id = ok[rd] ? id : 0;
         const bool kind = id < 135;  // true: Quu
         const int idq = kind ? id : 0, idp = kind ? 0 : id - 135;
-        const unsigned short ij = c.tri[idq / 3];
+        const int ij = (tpk >> (16 * rd)) & 0xffff;   // tri[idq / 3], looked up once per backward pass (riccati_backward)
         const int i = 3 * ((ij >> 8) + 1) + idq % 3, j0 = 3 * (ij & 255);
         const int jr = idp / 10, i0 = 3 * (idp % 10);
         dsc[rd] = kind ? 3 * i : 3 * NU + 3 * jr;
@@ -839,7 +839,7 @@ __device__ inline void quu_qus_triples(const Ctx& c, const CmpcConsts& prm, int 
 
 template <int NT, int NC, bool FG>
 __device__ inline void stage_pre_body(const Ctx& c, const CmpcConsts& prm, int tid, int k, const float* Pcur, bool havep,
-                                      bool use_exact, float reg, float cmu)
+                                      bool use_exact, float reg, float cmu, int tpk)
 {
     const bool pk = k > 0;
     const float* u = c.U + NU * k;
@@ -875,8 +875,8 @@ __device__ inline void stage_pre_body(const Ctx& c, const CmpcConsts& prm, int t
         // (512 threads: waves 0-3 one round of triples, wave 4 the diagonal blocks, wave 5 Pd and qu; waves 6-7 idle here)
         constexpr int T2 = NT >= 512 ? 256 : 128;    // threads on the float32 triples
         if (tid < T2) {
-            if (NT >= 512) quu_qus_triples<1>(c, prm, k, havep, tid);
-            else quu_qus_triples<2>(c, prm, k, havep, tid);   // triples 0..255; the next wave takes 256..284 after its float64 blocks
+            if (NT >= 512) quu_qus_triples<1>(c, prm, k, havep, tid, tpk);
+            else quu_qus_triples<2>(c, prm, k, havep, tid, tpk);   // triples 0..255; the next wave takes 256..284 after its float64 blocks
             PROF2(5);
         } else if (tid < T2 + 64) {
           // ---- the ten 3x3 diagonal blocks of Quu in float64 (60 lower entries).  Branch-free on clamped indices so that all
@@ -918,7 +918,7 @@ __device__ inline void stage_pre_body(const Ctx& c, const CmpcConsts& prm, int t
             c.QuuF[i * RLD + j] = 0.f;  // the float copy of a diagonal block collects the updates by earlier blocks
             PROF4(7);
           }
-          if (NT < 512 && t < 285 - 256) quu_qus_triples<1>(c, prm, k, havep, 256 + t);
+          if (NT < 512 && t < 285 - 256) quu_qus_triples<1>(c, prm, k, havep, 256 + t, 0);
         } else if (tid < T2 + 128) {
           // ---- Pd = P [d; 0] + pv (float64), then qu, which reads it (same wave: LDS order suffices).  Every lane of the wave
           // computes both on clamped indices, branch-free: two levels of loads instead of a chain of small dependent ones ----
@@ -970,18 +970,18 @@ __device__ inline void stage_pre_body(const Ctx& c, const CmpcConsts& prm, int t
             PROF3(8);
           }
         } else if (NT >= 512 && tid >= T2 + 128 && tid < T2 + 128 + 285 - 256) {
-          quu_qus_triples<1>(c, prm, k, havep, 256 + tid - (T2 + 128));   // (eight waves: the last 29 triples on an idle wave)
+          quu_qus_triples<1>(c, prm, k, havep, 256 + tid - (T2 + 128), 0);   // (eight waves: the last 29 triples on an idle wave)
         }
         __syncthreads();
         PROF(2);
 }
 
 template <int NT>
-__device__ inline void stage_qss_body(const Ctx& c, const CmpcConsts& prm, int tid, int k, const float* Pcur, float* Qb)
+__device__ inline void stage_qss_body(const Ctx& c, const CmpcConsts& prm, int tid, int k, const float* Pcur, float* Qb, int tqp)
 {
             const int t = tid - 128;
             if (t < 120) {
-                const unsigned short ij = c.tri[t];
+                const int ij = tqp & 0xffff;   // tri[t]
                 const int i = ij >> 8, j = ij & 255;
                 const float ai0 = c.Aval[3 * i], ai1 = c.Aval[3 * i + 1], ai2 = c.Aval[3 * i + 2];
                 const float aj0 = c.Aval[3 * j], aj1 = c.Aval[3 * j + 1], aj2 = c.Aval[3 * j + 2];
@@ -998,7 +998,7 @@ __device__ inline void stage_qss_body(const Ctx& c, const CmpcConsts& prm, int t
 }
 
 template <int NT, bool LEAN>
-__device__ inline void stage_post_body(const Ctx& c, const CmpcConsts& prm, int tid, int k, float* Pnew, const float* Qb)
+__device__ inline void stage_post_body(const Ctx& c, const CmpcConsts& prm, int tid, int k, float* Pnew, const float* Qb, int tqp)
 {
     const bool pk = k > 0;
     const float* u = c.U + NU * k;
@@ -1012,7 +1012,7 @@ __device__ inline void stage_post_body(const Ctx& c, const CmpcConsts& prm, int 
             constexpr bool SPLIT = NT >= 512;
             const int tile = SPLIT ? (tid >> 1) : tid, khalf = SPLIT ? (tid & 1) : 0;
             if (tile < nb * (nb + 1) / 2) {
-                const unsigned short t = c.tri[tile];
+                const int t = (tqp >> 16) & 0xffff;   // tri[tile]
                 const int bi = t >> 8, bj = t & 255;
                 const int i0 = 2 * bi, j0 = 2 * bj, ncol = pk ? NXA : NS;
                 const float4* ri0 = reinterpret_cast<const float4*>(c.Pan + i0 * RLD);
@@ -1128,19 +1128,19 @@ __device__ __attribute__((noinline)) void phase_factor(lds_t lds, int Nrt, float
     stage_factor<CMPC_ONE_WAVE_FACTOR(FG)>(c.QuuF, c.QuuD, c.Pan, c.Lf + (size_t)REC_N * k, prm.D[0], prm.D[1], prm.D[2], c.flag, tid, fixedmask);
 }
 template <int NT, int NC, bool FG>
-__device__ __attribute__((noinline)) void stage_pre(lds_t lds, int Nrt, float* fg_base, int k, bool havep, bool use_exact, float reg, float cmu)
+__device__ __attribute__((noinline)) void stage_pre(lds_t lds, int Nrt, float* fg_base, int k, bool havep, bool use_exact, float reg, float cmu, int tpk)
 {
     CMPC_PHASE_PROLOGUE;
     use_desc_set(c, k & 1);
-    stage_pre_body<NT, NC, FG>(c, prm, tid, k, c.P0, havep, use_exact, reg, cmu);
+    stage_pre_body<NT, NC, FG>(c, prm, tid, k, c.P0, havep, use_exact, reg, cmu, tpk);
 }
 // waves 2-3 (t = tid - 128) while waves 0-1 factorise stage k: Qss and qs of stage k, then the descriptors of stage k-1
 template <int NT, int NC, bool FG>
-__device__ __attribute__((noinline)) void stage_qss(lds_t lds, int Nrt, float* fg_base, int k, bool use_exact, float cmu)
+__device__ __attribute__((noinline)) void stage_qss(lds_t lds, int Nrt, float* fg_base, int k, bool use_exact, float cmu, int tqp)
 {
     CMPC_PHASE_PROLOGUE;
     use_desc_set(c, k & 1);
-    stage_qss_body<NT>(c, prm, tid, k, c.P0, c.Qb);
+    stage_qss_body<NT>(c, prm, tid, k, c.P0, c.Qb, tqp);
     if (k > 0) {
         use_desc_set(c, ((k - 1) & 1) - (k & 1));
         stage_desc_body(c, prm, tid - 128, k - 1, use_exact, cmu);
@@ -1154,10 +1154,10 @@ __device__ __attribute__((noinline)) void stage_desc(lds_t lds, int Nrt, float* 
     stage_desc_body(c, prm, tid - 128, k, use_exact, cmu);
 }
 template <int NT, int NC, bool FG>
-__device__ __attribute__((noinline)) void stage_post(lds_t lds, int Nrt, float* fg_base, int k)
+__device__ __attribute__((noinline)) void stage_post(lds_t lds, int Nrt, float* fg_base, int k, int tqp)
 {
     CMPC_PHASE_PROLOGUE;
-    stage_post_body<NT, FG>(c, prm, tid, k, c.P0, c.Qb);
+    stage_post_body<NT, FG>(c, prm, tid, k, c.P0, c.Qb, tqp);
 }
 
 // ---- Riccati backward sweep (matrices + right-hand side of the affine step, or of a centring step with target
@@ -1175,18 +1175,29 @@ __device__ int riccati_backward(lds_t lds, const Ctx& c, const CmpcConsts& prm, 
     } else if (tid < NXA) c.pv[tid] = 0.0;
     if (tid >= 128) stage_desc<NT, NC, FG>(lds, N, fg_base, N - 1, use_exact, cmu);
     __syncthreads();
+    // Which entries of the triangle a thread owns does not change from stage to stage: the index-table look-ups (one dependent
+    // LDS round trip at the head of phases 2, 3 and 4) are made once here and handed down packed:
+    //   tpk = tri[id / 3] of the thread's (up to two) Quu triples;  tqp = tri[tid - 128] (Qss entry) | tri[tile] << 16 (phase 4)
+    int tpk, tqp;
+    {
+        const int id0 = tid, id1 = tid + 128;                       // (ids >= 135 are panel triples: no look-up)
+        tpk = (id0 < 135 ? c.tri[id0 / 3] : 0) | ((NT < 512 && id1 < 135 ? c.tri[id1 / 3] : 0) << 16);
+        const int tq = tid - 128, tile = NT >= 512 ? tid >> 1 : tid;
+        tqp = ((tq >= 0 && tq < 120) ? c.tri[tq] : 0) | ((tile < 210 ? c.tri[tile] : 0) << 16);
+    }
     // P0 holds the value function of stage k+1 and is overwritten in place by phase 4 (its last reader, Qss, ran in phase 3)
     for (int k = N - 1; k >= 0; --k) {
-        stage_pre<NT, NC, FG>(lds, N, fg_base, k, k < N - 1, use_exact, reg, cmu);
+        stage_pre<NT, NC, FG>(lds, N, fg_base, k, k < N - 1, use_exact, reg, cmu, tpk);
         PROF_DECL;
         if (tid < (CMPC_ONE_WAVE_FACTOR(FG) ? 64 : 128)) phase_factor<NC, FG>(lds, N, fg_base, k);
-        else if (tid >= 128) stage_qss<NT, NC, FG>(lds, N, fg_base, k, use_exact, cmu);
+        else if (tid >= 128) stage_qss<NT, NC, FG>(lds, N, fg_base, k, use_exact, cmu, tqp);
         __syncthreads();
         PROF(3);
-        if (*c.flag) return 1;
-        stage_post<NT, NC, FG>(lds, N, fg_base, k);
+        stage_post<NT, NC, FG>(lds, N, fg_base, k, tqp);
     }
-    return 0;
+    // (a non-positive pivot raises the flag and the stages after it run on garbage, harmlessly -- every array they write is
+    // rebuilt by the retry; testing the flag once here instead of once per stage takes an LDS round trip out of every stage)
+    return *c.flag ? 1 : 0;
 }
 
 // ---- forward sweep on wave 0: dS, dU.  All threads then compute dT, dZ (dZ holds the per-row
