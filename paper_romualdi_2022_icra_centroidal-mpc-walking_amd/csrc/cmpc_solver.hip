@@ -543,7 +543,7 @@ typedef float float2v __attribute__((ext_vector_type(2)));
 template <bool ONE>
 __device__ __forceinline__ bool chol_solve_fused(float2v (&vv)[NU / 2], double (&dd)[3], int lane, int fixedmask)
 {
-    const int myblk = lane / 3, jm = lane - 3 * myblk;
+    const int myblk = lane / 3;
     bool bad = false;
 #pragma unroll
     for (int b = 0; b < NU / 3; ++b) {
@@ -555,8 +555,8 @@ __device__ __forceinline__ bool chol_solve_fused(float2v (&vv)[NU / 2], double (
             }
         }
         // (opaque copies: the lane predicates are recomputed per block instead of living in hoisted, spilled SGPR pairs)
-        int myb = myblk, jmo = jm;
-        asm volatile("" : "+v"(myb), "+v"(jmo));
+        int myb = myblk;
+        asm volatile("" : "+v"(myb));
         const bool inblk = (myb == b);
         if (inblk) {
             dd[0] += (double)VE(j0);
@@ -587,11 +587,8 @@ __device__ __forceinline__ bool chol_solve_fused(float2v (&vv)[NU / 2], double (
         float x0 = VE(j0) * r00;
         float x1 = (VE(j0 + 1) - x0 * l10) * r11;
         float x2 = (VE(j0 + 2) - x0 * l20 - x1 * l21) * r22;
-        if (inblk) {  // the block's own rows of L: (l00 0 0), (l10 l11 0), (l20 l21 l22)
-            x0 = jmo == 0 ? p0f * r00 : (jmo == 1 ? l10 : l20);
-            x1 = jmo == 0 ? 0.f : (jmo == 1 ? p1f * r11 : l21);
-            x2 = jmo == 2 ? p2f * r22 : 0.f;
-        }
+        // (the block's own three lanes get meaningless x here -- their slots of the block are zero -- and that is fine: L itself
+        // is not kept, broadcasts only come from rows below the pivot block, so a lane's registers are dead once its block is done)
         VE(j0) = x0; VE(j0 + 1) = x1; VE(j0 + 2) = x2;
         // rank-3 update of the trailing columns: a leading odd column alone, then two columns per packed FMA.  Each
         // update is pinned here: left alone, the optimiser sinks the FMAs to the block that next reads the column and
