@@ -550,8 +550,9 @@ __device__ __forceinline__ bool chol_solve_fused(float2v (&vv)[NU / 2], double (
         const int j0 = 3 * b;
         if (ONE && b == LATE_B) {
             if (lane < NLATE) {
-#pragma unroll
-                for (int cc = 0; cc < NU; ++cc) VE(cc) = (cc == LATE_M0 + lane) ? 1.f : 0.f;
+                const unsigned hot = 1u << (LATE_M0 + lane);   // (bit-field extract + convert: two instructions per entry, no
+#pragma unroll                                                  //  compare -> mask hazard slots)
+                for (int cc = 0; cc < NU; ++cc) VE(cc) = (float)((hot >> cc) & 1u);
             }
         }
         // (opaque copies: the lane predicates are recomputed per block instead of living in hoisted, spilled SGPR pairs)
@@ -644,8 +645,9 @@ __device__ __forceinline__ void stage_factor(const float* QuuF, const double* Qu
             if (2 * q4 + 1 < NU / 2) vv[(2 * q4 + 1) % (NU / 2)] = float2v{t4.z, t4.w};
         }
         if (idrow) {
+            const unsigned hot = 1u << (prow - NS);
 #pragma unroll
-            for (int cc = 0; cc < NU; ++cc) VE(cc) = (cc == prow - NS) ? 1.f : 0.f;
+            for (int cc = 0; cc < NU; ++cc) VE(cc) = (float)((hot >> cc) & 1u);
         }
         if (isL) {
             dd[0] = QuuD[9 * (lane / 3) + 3 * (lane % 3) + 0];
