@@ -64,6 +64,9 @@
 #define REC_WT 576
 #define REC_ZERO 572
 #define REC_N CMPC_REC_N
+#ifndef CMPC_SWEEP_UNROLL
+#define CMPC_SWEEP_UNROLL 2   // stages per trip of the sweep loops in the resident variants (A/B knob)
+#endif
 // The HBM-factor variants are compiled for three workgroups per CU (168 registers per lane): their LDS image fits three times into
 // a CU up to N = 30 (52 KB at N = 20 and at N = 30).  Measured at N = 12, B = 8192, where 2, 3 and 4 all fit: 22.4 / 17.1 /
 // 17.8 ms -- at four (128 registers) the spills of the factorisation and the sweeps cost more than the fourth workgroup brings.
@@ -1205,7 +1208,7 @@ __device__ int riccati_backward(lds_t lds, const Ctx& c, const CmpcConsts& prm, 
 //             du = -L^{-T} y                                      (two lanes per column)
 //             ds+ = A ds + B du + d                               (9 + 6 lanes, corner sums by DPP)
 // Matrix operands do not depend on the recursion: they are read at the top of the stage. ----
-template <int NT>
+template <int NT, int UNR>
 __device__ void riccati_forward(const Ctx& c, const CmpcConsts& prm, int tid, bool affine)
 {
     const int N = c.N;
@@ -1245,6 +1248,8 @@ __device__ void riccati_forward(const Ctx& c, const CmpcConsts& prm, int tid, bo
         if (tid < NS) c.dS[tid] = 0.f;
         wave_lds_sync();
         PROF2_DECL;
+#pragma unroll UNR   // (two stages per trip in the resident variants: half the address updates of the ~30 operand pointers, +2 %;
+        // in the 168-register variants the doubled body spills)
         for (int k = 0; k < N; ++k) {
             const float* rec = c.Lf + (size_t)REC_N * k;
             float ym[20];
@@ -1328,6 +1333,7 @@ __device__ void riccati_forward(const Ctx& c, const CmpcConsts& prm, int tid, bo
 // holds w (0 on inactive rows).  Updates lq (slot 15 of the Ws rows) in place through the stored factors.
 // Per stage:  g = C^T w + fp_p + B^T fp_s ;  dl = L^{-1} g ;  lq += dl ;
 //             fp_s <- A^T fp_s - Ws^T dl ;  fp_p <- D L^{-T} dl ----
+template <int UNR>
 __device__ void riccati_delta(const Ctx& c, const CmpcConsts& prm, int tid)
 {
     const int N = c.N;
@@ -1360,6 +1366,7 @@ __device__ void riccati_delta(const Ctx& c, const CmpcConsts& prm, int tid)
         if (tid < 32) { gb[tid] = 0.f; }
         wave_lds_sync();
         PROF2_DECL;
+#pragma unroll UNR
         for (int k = N - 1; k >= 0; --k) {
             float* rec = c.Lf + (size_t)REC_N * k;
             float lm[16];
@@ -1540,13 +1547,13 @@ template <int NT, int NC, bool FG>
 __device__ __attribute__((noinline)) void phase_forward(lds_t lds, int Nrt, float* fg_base, bool affine)
 {
     CMPC_PHASE_PROLOGUE;
-    riccati_forward<NT>(c, prm, tid, affine);
+    riccati_forward<NT, (FG || NC == 0) ? 1 : CMPC_SWEEP_UNROLL>(c, prm, tid, affine);
 }
 template <int NT, int NC, bool FG>
 __device__ __attribute__((noinline)) void phase_delta(lds_t lds, int Nrt, float* fg_base)
 {
     CMPC_PHASE_PROLOGUE;
-    riccati_delta(c, prm, tid);
+    riccati_delta<(FG || NC == 0) ? 1 : CMPC_SWEEP_UNROLL>(c, prm, tid);
 }
 template <int NT, int NC, bool FG>
 __device__ __attribute__((noinline)) void phase_costate(lds_t lds, int Nrt, float* fg_base, float ap, bool use_exact)
