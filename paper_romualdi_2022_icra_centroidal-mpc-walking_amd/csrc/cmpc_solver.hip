@@ -65,7 +65,7 @@
 #define REC_ZERO 572
 #define REC_N CMPC_REC_N
 #ifndef CMPC_SWEEP_UNROLL
-#define CMPC_SWEEP_UNROLL 2   // stages per trip of the sweep loops in the resident variants (A/B knob)
+#define CMPC_SWEEP_UNROLL 4   // stages per trip of the sweep loops in the resident variants (A/B: 1 / 2 / 4 / 10 -> 184.4 / 186.1 / 189.8 / 188.0 k solves/s)
 #endif
 // The HBM-factor variants are compiled for three workgroups per CU (168 registers per lane): their LDS image fits three times into
 // a CU up to N = 30 (52 KB at N = 20 and at N = 30).  Measured at N = 12, B = 8192, where 2, 3 and 4 all fit: 22.4 / 17.1 /
@@ -1248,7 +1248,7 @@ __device__ void riccati_forward(const Ctx& c, const CmpcConsts& prm, int tid, bo
         if (tid < NS) c.dS[tid] = 0.f;
         wave_lds_sync();
         PROF2_DECL;
-#pragma unroll UNR   // (two stages per trip in the resident variants: half the address updates of the ~30 operand pointers, +2 %;
+#pragma unroll UNR   // (four stages per trip in the resident variants: a quarter of the address updates of the ~30 operand pointers, +3 %;
         // in the 168-register variants the doubled body spills)
         for (int k = 0; k < N; ++k) {
             const float* rec = c.Lf + (size_t)REC_N * k;
