@@ -114,6 +114,49 @@ struct Ctx {
 // SAME wave needs no wait, only a fence for the compiler
 __device__ inline void wave_lds_sync() { asm volatile("" ::: "memory"); }
 
+// ---- access to the per-stage factor records.  LDS in the resident variants.  In the HBM-factor variants they sit in global
+// scratch and go through a buffer descriptor built once per phase from the wave-uniform base (a pointer argument of an
+// out-of-line phase arrives in VGPRs: v_readfirstlane makes it provably uniform): buffer_load v, v_offset, s[rsrc], s_stage --
+// the lane's offset stays a loop-invariant VGPR and the stage offset an SGPR, no per-access VALU address arithmetic.  (A generic
+// pointer made every access a flat_ instruction on a 64-bit VALU-computed address: -2.3 % on configs 3 and 5; plain global-address-space
+// accesses on the uniform base measure 1 % below the descriptor form.) ----
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
+template <bool G>
+struct RecRef;
+template <>
+struct RecRef<false> {
+    float* p;
+    __device__ RecRef(float* base, int, int k) : p(base + (size_t)REC_N * k) {}
+    __device__ float ld(unsigned off) const { return p[off]; }
+    __device__ float4 ld4(unsigned off) const { return *reinterpret_cast<const float4*>(p + off); }
+    __device__ void st(unsigned off, float v) const { p[off] = v; }
+    __device__ void st4(unsigned off, const float4& w) const { *reinterpret_cast<float4*>(p + off) = w; }
+};
+template <>
+struct RecRef<true> {
+    __amdgpu_buffer_rsrc_t r;
+    unsigned so;   // byte offset of the stage (SGPR)
+    __device__ RecRef(float* base, int N, int k)
+    {
+        const unsigned long long a = (unsigned long long)base;
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+        r = __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0, 4 * REC_N * N, 0x00020000);
+        so = 4u * REC_N * (unsigned)k;
+    }
+    __device__ float ld(unsigned off) const { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, 4u * off, so, 0)); }
+    __device__ float4 ld4(unsigned off) const
+    {
+        const v4u v = __builtin_amdgcn_raw_buffer_load_b128(r, 4u * off, so, 0);
+        return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+    }
+    __device__ void st(unsigned off, float v) const { __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, 4u * off, so, 0); }
+    __device__ void st4(unsigned off, const float4& w) const
+    {
+        const v4u v = {__float_as_uint(w.x), __float_as_uint(w.y), __float_as_uint(w.z), __float_as_uint(w.w)};
+        __builtin_amdgcn_raw_buffer_store_b128(v, r, 4u * off, so, 0);
+    }
+};
+
 // carve the workgroup's LDS image (constants first, then doubles, then 16-byte aligned float panels).
 // Pure address arithmetic: every phase function rebuilds it instead of receiving it, so that the
 // out-of-line phases have a register allocation of their own.
@@ -624,8 +667,8 @@ __device__ __forceinline__ bool chol_solve_fused(float2v (&vv)[NU / 2], double (
 
 // phase 3 of a backward stage, kept out of line so that its ~40 VGPRs of matrix rows and its
 // stream of v_readlane broadcasts get a register allocation of their own
-template <bool ONE>
-__device__ __forceinline__ void stage_factor(const float* QuuF, const double* QuuD, float* Pan, float* rec,
+template <bool ONE, bool G>
+__device__ __forceinline__ void stage_factor(const float* QuuF, const double* QuuD, float* Pan, const RecRef<G>& rec,
                                           float D0, float D1, float D2, int* flag, int tid, int fixedmask)
 {
     const int lane = tid & 63, wv = tid >> 6;
@@ -673,10 +716,10 @@ __device__ __forceinline__ void stage_factor(const float* QuuF, const double* Qu
         const int jw = srow < NS ? srow : 15;          // Ws column j, or the lq row
         const int I = isId ? (m >> 2) : 0;
         float* prow_p = Pan + srow * RLD;
-        float* rrow = rec + (isId ? ub_row(m) - 4 * I : REC_WT + 32 * jw);
+        const unsigned rrow = isId ? ub_row(m) - 4 * I : REC_WT + 32 * jw;
         // one store per float4 for both kinds of row; float4s left of an identity row's diagonal block go to row 30
         // of U, a row whose only readers are lanes that discard what they compute (REC_ZERO is row 31)
-        float* trash = rec + ub_row(30);
+        const unsigned trash = ub_row(30);
         const int sw = isId ? 0 : (jw & 7);
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
@@ -685,7 +728,7 @@ __device__ __forceinline__ void stage_factor(const float* QuuF, const double* Qu
             w.z = 2 * q + 1 < NU / 2 ? vv[(2 * q + 1) % (NU / 2)].x : 0.f;
             w.w = 2 * q + 1 < NU / 2 ? vv[(2 * q + 1) % (NU / 2)].y : 0.f;
             *reinterpret_cast<float4*>(prow_p + 4 * q) = make_float4(sc * w.x, sc * w.y, sc * w.z, sc * w.w);
-            *reinterpret_cast<float4*>(q >= I ? rrow + 4 * (q ^ sw) : trash) = w;
+            rec.st4(q >= I ? rrow + 4 * (q ^ sw) : trash, w);
         }
     }
     PROF2(30);
@@ -1127,7 +1170,7 @@ __device__ __attribute__((noinline)) void phase_factor(lds_t lds, int Nrt, float
 {
     CMPC_PHASE_PROLOGUE;
     const int fixedmask = (~c.qmask[k]) & 63;
-    stage_factor<CMPC_ONE_WAVE_FACTOR(FG)>(c.QuuF, c.QuuD, c.Pan, c.Lf + (size_t)REC_N * k, prm.D[0], prm.D[1], prm.D[2], c.flag, tid, fixedmask);
+    stage_factor<CMPC_ONE_WAVE_FACTOR(FG), FG>(c.QuuF, c.QuuD, c.Pan, RecRef<FG>(c.Lf, N, k), prm.D[0], prm.D[1], prm.D[2], c.flag, tid, fixedmask);
 }
 template <int NT, int NC, bool FG>
 __device__ __attribute__((noinline)) void stage_pre(lds_t lds, int Nrt, float* fg_base, int k, bool havep, bool use_exact, float reg, float cmu, int tpk)
@@ -1208,7 +1251,7 @@ __device__ int riccati_backward(lds_t lds, const Ctx& c, const CmpcConsts& prm, 
 //             du = -L^{-T} y                                      (two lanes per column)
 //             ds+ = A ds + B du + d                               (9 + 6 lanes, corner sums by DPP)
 // Matrix operands do not depend on the recursion: they are read at the top of the stage. ----
-template <int NT, int UNR>
+template <int NT, int UNR, bool G>
 __device__ void riccati_forward(const Ctx& c, const CmpcConsts& prm, int tid, bool affine)
 {
     const int N = c.N;
@@ -1218,7 +1261,7 @@ __device__ void riccati_forward(const Ctx& c, const CmpcConsts& prm, int tid, bo
         float* yb = c.ybuf + 40;  // y (32)
         // per-lane offsets inside a stage record (loop invariant)
         // y-step: column r of [WT; U[0..23]] against x, 20 terms per half;  du-step: row r of U against y
-        int yoff[20], uoff[4];
+        unsigned yoff[20], uoff[4];
 #pragma unroll
         for (int t = 0; t < 20; ++t) {
             if (half == 0) yoff[t] = t < 16 ? wt_idx(t, r) : ub_row(t - 16) + r;
@@ -1251,13 +1294,13 @@ __device__ void riccati_forward(const Ctx& c, const CmpcConsts& prm, int tid, bo
 #pragma unroll UNR   // (four stages per trip in the resident variants: a quarter of the address updates of the ~30 operand pointers, +3 %;
         // in the 168-register variants the doubled body spills)
         for (int k = 0; k < N; ++k) {
-            const float* rec = c.Lf + (size_t)REC_N * k;
+            const RecRef<G> rec(c.Lf, N, k);
             float ym[20];
             float4 um[4];
 #pragma unroll
-            for (int t = 0; t < 20; ++t) ym[t] = rec[yoff[t]];
+            for (int t = 0; t < 20; ++t) ym[t] = rec.ld(yoff[t]);
 #pragma unroll
-            for (int t = 0; t < 4; ++t) um[t] = *reinterpret_cast<const float4*>(rec + uoff[t]);
+            for (int t = 0; t < 4; ++t) um[t] = rec.ld4(uoff[t]);
             // stage data of the dynamics step (independent of the recursion as well)
             const float* geo = c.geoA + GEO * k;
             const float gam0 = gam_of(c, 0, k), gam1 = gam_of(c, 1, k);
@@ -1333,7 +1376,7 @@ __device__ void riccati_forward(const Ctx& c, const CmpcConsts& prm, int tid, bo
 // holds w (0 on inactive rows).  Updates lq (slot 15 of the Ws rows) in place through the stored factors.
 // Per stage:  g = C^T w + fp_p + B^T fp_s ;  dl = L^{-1} g ;  lq += dl ;
 //             fp_s <- A^T fp_s - Ws^T dl ;  fp_p <- D L^{-T} dl ----
-template <int UNR>
+template <int UNR, bool G>
 __device__ void riccati_delta(const Ctx& c, const CmpcConsts& prm, int tid)
 {
     const int N = c.N;
@@ -1343,7 +1386,7 @@ __device__ void riccati_delta(const Ctx& c, const CmpcConsts& prm, int tid)
         float* lb = c.ybuf + 32;   // dl (32)
         // dl-step: column r of U against g, 16 terms per half;  fp-step: row r of U (lanes 0..31) or row r of WT
         // (lanes 32..47) against dl
-        int loff[16], foff[8];
+        unsigned loff[16], foff[8];
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
             const int m = 16 * half + t;
@@ -1368,13 +1411,13 @@ __device__ void riccati_delta(const Ctx& c, const CmpcConsts& prm, int tid)
         PROF2_DECL;
 #pragma unroll UNR
         for (int k = N - 1; k >= 0; --k) {
-            float* rec = c.Lf + (size_t)REC_N * k;
+            const RecRef<G> rec(c.Lf, N, k);
             float lm[16];
             float4 fm[8];
 #pragma unroll
-            for (int t = 0; t < 16; ++t) lm[t] = rec[loff[t]];
+            for (int t = 0; t < 16; ++t) lm[t] = rec.ld(loff[t]);
 #pragma unroll
-            for (int q = 0; q < 8; ++q) fm[q] = *reinterpret_cast<const float4*>(rec + foff[q]);
+            for (int q = 0; q < 8; ++q) fm[q] = rec.ld4(foff[q]);
             const float* geo = c.geoA + GEO * k;
             const float* wk = c.dT + NI * k;
             const float gam0 = gam_of(c, 0, k), gam1 = gam_of(c, 1, k);
@@ -1411,7 +1454,7 @@ __device__ void riccati_delta(const Ctx& c, const CmpcConsts& prm, int tid)
             }
             const float dl = half_sum(la + lc);
             if (tid < 32) lb[r] = dl;
-            if (tid < NU) rec[wt_idx(15, tid)] += dl;
+            if (tid < NU) { const unsigned lo = wt_idx(15, tid); rec.st(lo, rec.ld(lo) + dl); }
             wave_lds_sync();
             PROF2(26);
             // ---- fp ----
@@ -1547,13 +1590,13 @@ template <int NT, int NC, bool FG>
 __device__ __attribute__((noinline)) void phase_forward(lds_t lds, int Nrt, float* fg_base, bool affine)
 {
     CMPC_PHASE_PROLOGUE;
-    riccati_forward<NT, (FG || NC == 0) ? 1 : CMPC_SWEEP_UNROLL>(c, prm, tid, affine);
+    riccati_forward<NT, (FG || NC == 0) ? 1 : CMPC_SWEEP_UNROLL, FG>(c, prm, tid, affine);
 }
 template <int NT, int NC, bool FG>
 __device__ __attribute__((noinline)) void phase_delta(lds_t lds, int Nrt, float* fg_base)
 {
     CMPC_PHASE_PROLOGUE;
-    riccati_delta<(FG || NC == 0) ? 1 : CMPC_SWEEP_UNROLL>(c, prm, tid);
+    riccati_delta<(FG || NC == 0) ? 1 : CMPC_SWEEP_UNROLL, FG>(c, prm, tid);
 }
 template <int NT, int NC, bool FG>
 __device__ __attribute__((noinline)) void phase_costate(lds_t lds, int Nrt, float* fg_base, float ap, bool use_exact)
