@@ -1291,8 +1291,8 @@ __device__ void riccati_forward(const Ctx& c, const CmpcConsts& prm, int tid, bo
         if (tid < NS) c.dS[tid] = 0.f;
         wave_lds_sync();
         PROF2_DECL;
-#pragma unroll UNR   // (four stages per trip in the resident variants: a quarter of the address updates of the ~30 operand pointers, +3 %;
-        // in the 168-register variants the doubled body spills)
+#pragma unroll UNR   // (stages per trip: 4 in the resident variants -- a quarter of the address updates of the ~30 LDS operand
+        // pointers, +3 % -- and 2 in the HBM-factor variants, whose records come through the descriptor: +1 %, 4 brings no more)
         for (int k = 0; k < N; ++k) {
             const RecRef<G> rec(c.Lf, N, k);
             float ym[20];
@@ -1590,13 +1590,13 @@ template <int NT, int NC, bool FG>
 __device__ __attribute__((noinline)) void phase_forward(lds_t lds, int Nrt, float* fg_base, bool affine)
 {
     CMPC_PHASE_PROLOGUE;
-    riccati_forward<NT, (FG || NC == 0) ? 1 : CMPC_SWEEP_UNROLL, FG>(c, prm, tid, affine);
+    riccati_forward<NT, NC == 0 ? 1 : (FG ? 2 : CMPC_SWEEP_UNROLL), FG>(c, prm, tid, affine);
 }
 template <int NT, int NC, bool FG>
 __device__ __attribute__((noinline)) void phase_delta(lds_t lds, int Nrt, float* fg_base)
 {
     CMPC_PHASE_PROLOGUE;
-    riccati_delta<(FG || NC == 0) ? 1 : CMPC_SWEEP_UNROLL, FG>(c, prm, tid);
+    riccati_delta<NC == 0 ? 1 : (FG ? 2 : CMPC_SWEEP_UNROLL), FG>(c, prm, tid);
 }
 template <int NT, int NC, bool FG>
 __device__ __attribute__((noinline)) void phase_costate(lds_t lds, int Nrt, float* fg_base, float ap, bool use_exact)
