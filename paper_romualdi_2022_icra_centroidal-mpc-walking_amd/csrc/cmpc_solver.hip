@@ -1159,31 +1159,36 @@ __device__ inline void stage_post_body(const Ctx& c, const CmpcConsts& prm, int 
 typedef __attribute__((address_space(3))) char* lds_t;
 #define CMPC_PHASE_PROLOGUE                                                            \
     char* smem = (char*)lds;                                                           \
-    const int N = NC > 0 ? NC : Nrt;                                                   \
+    const int N = NC > 0 ? NC : __builtin_amdgcn_readfirstlane(Nrt);                   \
     Ctx c;                                                                             \
     make_ctx<FG>(c, smem, N, fg_base);                                                 \
     const CmpcConsts& prm = *reinterpret_cast<const CmpcConsts*>(smem);                \
     const int tid = threadIdx.x
 
 template <int NC, bool FG>
-__device__ __attribute__((noinline)) void phase_factor(lds_t lds, int Nrt, float* fg_base, int k)
+__device__ __attribute__((noinline)) void phase_factor(lds_t lds, int Nrt, float* fg_base, int k_in)
 {
     CMPC_PHASE_PROLOGUE;
+    const int k = __builtin_amdgcn_readfirstlane(k_in);   // (arguments arrive in VGPRs: a uniform copy keeps the stage's address arithmetic on the SALU)
     const int fixedmask = (~c.qmask[k]) & 63;
     stage_factor<CMPC_ONE_WAVE_FACTOR(FG), FG>(c.QuuF, c.QuuD, c.Pan, RecRef<FG>(c.Lf, N, k), prm.D[0], prm.D[1], prm.D[2], c.flag, tid, fixedmask);
 }
 template <int NT, int NC, bool FG>
-__device__ __attribute__((noinline)) void stage_pre(lds_t lds, int Nrt, float* fg_base, int k, bool havep, bool use_exact, float reg, float cmu, int tpk)
+__device__ __attribute__((noinline)) void stage_pre(lds_t lds, int Nrt, float* fg_base, int k_in, bool havep_in, bool exact_in, float reg, float cmu, int tpk)
 {
     CMPC_PHASE_PROLOGUE;
+    const int k = __builtin_amdgcn_readfirstlane(k_in);   // (arguments arrive in VGPRs: a uniform copy keeps the stage's address arithmetic on the SALU)
+    const bool havep = __builtin_amdgcn_readfirstlane((int)havep_in) != 0, use_exact = __builtin_amdgcn_readfirstlane((int)exact_in) != 0;
     use_desc_set(c, k & 1);
     stage_pre_body<NT, NC, FG>(c, prm, tid, k, c.P0, havep, use_exact, reg, cmu, tpk);
 }
 // waves 2-3 (t = tid - 128) while waves 0-1 factorise stage k: Qss and qs of stage k, then the descriptors of stage k-1
 template <int NT, int NC, bool FG>
-__device__ __attribute__((noinline)) void stage_qss(lds_t lds, int Nrt, float* fg_base, int k, bool use_exact, float cmu, int tqp)
+__device__ __attribute__((noinline)) void stage_qss(lds_t lds, int Nrt, float* fg_base, int k_in, bool exact_in, float cmu, int tqp)
 {
     CMPC_PHASE_PROLOGUE;
+    const int k = __builtin_amdgcn_readfirstlane(k_in);   // (arguments arrive in VGPRs: a uniform copy keeps the stage's address arithmetic on the SALU)
+    const bool use_exact = __builtin_amdgcn_readfirstlane((int)exact_in) != 0;
     use_desc_set(c, k & 1);
     stage_qss_body<NT>(c, prm, tid, k, c.P0, c.Qb, tqp);
     if (k > 0) {
@@ -1192,16 +1197,19 @@ __device__ __attribute__((noinline)) void stage_qss(lds_t lds, int Nrt, float* f
     }
 }
 template <int NT, int NC, bool FG>
-__device__ __attribute__((noinline)) void stage_desc(lds_t lds, int Nrt, float* fg_base, int k, bool use_exact, float cmu)
+__device__ __attribute__((noinline)) void stage_desc(lds_t lds, int Nrt, float* fg_base, int k_in, bool exact_in, float cmu)
 {
     CMPC_PHASE_PROLOGUE;
+    const int k = __builtin_amdgcn_readfirstlane(k_in);   // (arguments arrive in VGPRs: a uniform copy keeps the stage's address arithmetic on the SALU)
+    const bool use_exact = __builtin_amdgcn_readfirstlane((int)exact_in) != 0;
     use_desc_set(c, k & 1);
     stage_desc_body(c, prm, tid - 128, k, use_exact, cmu);
 }
 template <int NT, int NC, bool FG>
-__device__ __attribute__((noinline)) void stage_post(lds_t lds, int Nrt, float* fg_base, int k, int tqp)
+__device__ __attribute__((noinline)) void stage_post(lds_t lds, int Nrt, float* fg_base, int k_in, int tqp)
 {
     CMPC_PHASE_PROLOGUE;
+    const int k = __builtin_amdgcn_readfirstlane(k_in);   // (arguments arrive in VGPRs: a uniform copy keeps the stage's address arithmetic on the SALU)
     stage_post_body<NT, FG>(c, prm, tid, k, c.P0, c.Qb, tqp);
 }
 
@@ -1587,9 +1595,10 @@ __device__ void costate_update(const Ctx& c, const CmpcConsts& prm, int tid, flo
 
 // ---- out-of-line entry points of the sweeps ----
 template <int NT, int NC, bool FG>
-__device__ __attribute__((noinline)) void phase_forward(lds_t lds, int Nrt, float* fg_base, bool affine)
+__device__ __attribute__((noinline)) void phase_forward(lds_t lds, int Nrt, float* fg_base, bool affine_in)
 {
     CMPC_PHASE_PROLOGUE;
+    const bool affine = __builtin_amdgcn_readfirstlane((int)affine_in) != 0;
     riccati_forward<NT, NC == 0 ? 1 : (FG ? 2 : CMPC_SWEEP_UNROLL), FG>(c, prm, tid, affine);
 }
 template <int NT, int NC, bool FG>
@@ -1599,9 +1608,10 @@ __device__ __attribute__((noinline)) void phase_delta(lds_t lds, int Nrt, float*
     riccati_delta<NC == 0 ? 1 : (FG ? 2 : CMPC_SWEEP_UNROLL), FG>(c, prm, tid);
 }
 template <int NT, int NC, bool FG>
-__device__ __attribute__((noinline)) void phase_costate(lds_t lds, int Nrt, float* fg_base, float ap, bool use_exact)
+__device__ __attribute__((noinline)) void phase_costate(lds_t lds, int Nrt, float* fg_base, float ap, bool exact_in)
 {
     CMPC_PHASE_PROLOGUE;
+    const bool use_exact = __builtin_amdgcn_readfirstlane((int)exact_in) != 0;
     costate_update(c, prm, tid, ap, use_exact);
 }
 // NC > 0: horizon known at compile time (every LDS offset becomes an immediate); NC == 0: runtime N
