@@ -1582,6 +1582,7 @@ __device__ void costate_update(const Ctx& c, const CmpcConsts& prm, int tid, flo
         Ops oa = fetch(N > 1 ? N - 1 : 0), ob;
         if (own) c.LAM[NS * N + j] = lold + ap * (pvj - lold);
         int k = N - 1;
+#pragma unroll 1   // (left alone the compiler unrolls all N / 2 trips: 10 KB of straight-line code for a phase that runs once per iteration)
         for (; k >= 2; k -= 2) {
             ob = fetch(k - 1);
             step(k, oa);
