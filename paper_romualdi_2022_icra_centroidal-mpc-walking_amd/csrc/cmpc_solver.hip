@@ -734,13 +734,12 @@ __device__ __forceinline__ void stage_factor(const float* QuuF, const double* Qu
     PROF2(30);
 }
 
-// ---- Riccati backward sweep (matrices + right-hand side of the affine step).
-// Returns (uniformly) 0 ok, 1 non-positive pivot. ----
-// ---- one stage of the backward sweep, in out-of-line pieces (each with a register allocation of its own; inlined
-// into one loop the stage needs > 512 VGPRs and spills to scratch):
-//   stage_pre   phases 1-2: G = P [B;E], then Quu / Qus / Pd / qu
-//   stage_qss   Qss, qs of this stage and the descriptors of the next on waves 2-3 while waves 0-1 factorise (phase_factor)
-//   stage_post  phase 4: P <- [Qss 0; 0 D] - W^T W, value gradient ----
+// ---- one stage of the backward sweep, as inline bodies that the out-of-line entry points `stage_mid` and `stage_post_pre` string together (the
+// stage must stay out of the kernel body: inlined into its loops it needs > 512 VGPRs and spills to scratch):
+//   stage_pre_body   phases 1-2: G = P [B;E], then Quu / Qus / Pd / qu
+//   stage_factor     phase 3 on wave 0 (waves 0-1 in the resident variants): fused Cholesky + panel solve
+//   stage_qss_body   Qss, qs of this stage and (stage_desc_body) the descriptors of the next on the other waves meanwhile
+//   stage_post_body  phase 4: P <- [Qss 0; 0 D] - W^T W, value gradient ----
 // ---- column descriptors of A_k and B_k (closed forms; <= 3 non-zeros per column), barrier coefficients z/t and the
 // friction rows, the exact-Hessian block: 128 threads (t = 0..127), into the descriptor set selected in c ----
 __device__ inline void stage_desc_body(const Ctx& c, const CmpcConsts& prm, int t, int k, bool use_exact, float cmu)
@@ -1165,14 +1164,6 @@ typedef __attribute__((address_space(3))) char* lds_t;
     const CmpcConsts& prm = *reinterpret_cast<const CmpcConsts*>(smem);                \
     const int tid = threadIdx.x
 
-template <int NC, bool FG>
-__device__ __attribute__((noinline)) void phase_factor(lds_t lds, int Nrt, float* fg_base, int k_in)
-{
-    CMPC_PHASE_PROLOGUE;
-    const int k = __builtin_amdgcn_readfirstlane(k_in);   // (arguments arrive in VGPRs: a uniform copy keeps the stage's address arithmetic on the SALU)
-    const int fixedmask = (~c.qmask[k]) & 63;
-    stage_factor<CMPC_ONE_WAVE_FACTOR(FG), FG>(c.QuuF, c.QuuD, c.Pan, RecRef<FG>(c.Lf, N, k), prm.D[0], prm.D[1], prm.D[2], c.flag, tid, fixedmask);
-}
 template <int NT, int NC, bool FG>
 __device__ __attribute__((noinline)) void stage_pre(lds_t lds, int Nrt, float* fg_base, int k_in, bool havep_in, bool exact_in, float reg, float cmu, int tpk)
 {
@@ -1181,20 +1172,6 @@ __device__ __attribute__((noinline)) void stage_pre(lds_t lds, int Nrt, float* f
     const bool havep = __builtin_amdgcn_readfirstlane((int)havep_in) != 0, use_exact = __builtin_amdgcn_readfirstlane((int)exact_in) != 0;
     use_desc_set(c, k & 1);
     stage_pre_body<NT, NC, FG>(c, prm, tid, k, c.P0, havep, use_exact, reg, cmu, tpk);
-}
-// waves 2-3 (t = tid - 128) while waves 0-1 factorise stage k: Qss and qs of stage k, then the descriptors of stage k-1
-template <int NT, int NC, bool FG>
-__device__ __attribute__((noinline)) void stage_qss(lds_t lds, int Nrt, float* fg_base, int k_in, bool exact_in, float cmu, int tqp)
-{
-    CMPC_PHASE_PROLOGUE;
-    const int k = __builtin_amdgcn_readfirstlane(k_in);   // (arguments arrive in VGPRs: a uniform copy keeps the stage's address arithmetic on the SALU)
-    const bool use_exact = __builtin_amdgcn_readfirstlane((int)exact_in) != 0;
-    use_desc_set(c, k & 1);
-    stage_qss_body<NT>(c, prm, tid, k, c.P0, c.Qb, tqp);
-    if (k > 0) {
-        use_desc_set(c, ((k - 1) & 1) - (k & 1));
-        stage_desc_body(c, prm, tid - 128, k - 1, use_exact, cmu);
-    }
 }
 template <int NT, int NC, bool FG>
 __device__ __attribute__((noinline)) void stage_desc(lds_t lds, int Nrt, float* fg_base, int k_in, bool exact_in, float cmu)
@@ -1205,12 +1182,43 @@ __device__ __attribute__((noinline)) void stage_desc(lds_t lds, int Nrt, float* 
     use_desc_set(c, k & 1);
     stage_desc_body(c, prm, tid - 128, k, use_exact, cmu);
 }
+
+
+// A backward stage is two calls.  stage_mid: phase 3 of stage k -- the factorisation on wave 0 (waves 0-1 in the resident
+// variants), Qss and the descriptors of stage k-1 on the others -- and the barrier behind it.  stage_post_pre: phase 4 of stage k,
+// then phases 1-2 of stage k-1.  (Four calls per stage cost 2 % in prologues and stage addresses.  All of it behind ONE call
+// measures another +1 % but must not be done: with phase 4 in the same function as the factorisation the HBM-factor variants
+// other than N = 20 stop converging -- inexact steps, cause not found, barriers and waits ruled out; profiles/r02_experiments_not_kept.txt.)
 template <int NT, int NC, bool FG>
-__device__ __attribute__((noinline)) void stage_post(lds_t lds, int Nrt, float* fg_base, int k_in, int tqp)
+__device__ __attribute__((noinline)) void stage_mid(lds_t lds, int Nrt, float* fg_base, int k_in, bool exact_in, float cmu, int tqp)
 {
     CMPC_PHASE_PROLOGUE;
-    const int k = __builtin_amdgcn_readfirstlane(k_in);   // (arguments arrive in VGPRs: a uniform copy keeps the stage's address arithmetic on the SALU)
+    const int k = __builtin_amdgcn_readfirstlane(k_in);
+    const bool use_exact = __builtin_amdgcn_readfirstlane((int)exact_in) != 0;
+    if (tid < (CMPC_ONE_WAVE_FACTOR(FG) ? 64 : 128)) {
+        const int fixedmask = (~c.qmask[k]) & 63;
+        stage_factor<CMPC_ONE_WAVE_FACTOR(FG), FG>(c.QuuF, c.QuuD, c.Pan, RecRef<FG>(c.Lf, N, k), prm.D[0], prm.D[1], prm.D[2], c.flag, tid, fixedmask);
+    } else if (tid >= 128) {
+        use_desc_set(c, k & 1);
+        stage_qss_body<NT>(c, prm, tid, k, c.P0, c.Qb, tqp);
+        if (k > 0) {
+            use_desc_set(c, ((k - 1) & 1) - (k & 1));
+            stage_desc_body(c, prm, tid - 128, k - 1, use_exact, cmu);
+        }
+    }
+    __syncthreads();
+}
+template <int NT, int NC, bool FG>
+__device__ __attribute__((noinline)) void stage_post_pre(lds_t lds, int Nrt, float* fg_base, int k_in, bool exact_in, float reg, float cmu, int tpk, int tqp)
+{
+    CMPC_PHASE_PROLOGUE;
+    const int k = __builtin_amdgcn_readfirstlane(k_in);
+    const bool use_exact = __builtin_amdgcn_readfirstlane((int)exact_in) != 0;
     stage_post_body<NT, FG>(c, prm, tid, k, c.P0, c.Qb, tqp);
+    if (k > 0) {
+        use_desc_set(c, (k - 1) & 1);
+        stage_pre_body<NT, NC, FG>(c, prm, tid, k - 1, c.P0, true, use_exact, reg, cmu, tpk);
+    }
 }
 
 // ---- Riccati backward sweep (matrices + right-hand side of the affine step, or of a centring step with target
@@ -1239,14 +1247,10 @@ __device__ int riccati_backward(lds_t lds, const Ctx& c, const CmpcConsts& prm, 
         tqp = ((tq >= 0 && tq < 120) ? c.tri[tq] : 0) | ((tile < 210 ? c.tri[tile] : 0) << 16);
     }
     // P0 holds the value function of stage k+1 and is overwritten in place by phase 4 (its last reader, Qss, ran in phase 3)
+    stage_pre<NT, NC, FG>(lds, N, fg_base, N - 1, false, use_exact, reg, cmu, tpk);
     for (int k = N - 1; k >= 0; --k) {
-        stage_pre<NT, NC, FG>(lds, N, fg_base, k, k < N - 1, use_exact, reg, cmu, tpk);
-        PROF_DECL;
-        if (tid < (CMPC_ONE_WAVE_FACTOR(FG) ? 64 : 128)) phase_factor<NC, FG>(lds, N, fg_base, k);
-        else if (tid >= 128) stage_qss<NT, NC, FG>(lds, N, fg_base, k, use_exact, cmu, tqp);
-        __syncthreads();
-        PROF(3);
-        stage_post<NT, NC, FG>(lds, N, fg_base, k, tqp);
+        stage_mid<NT, NC, FG>(lds, N, fg_base, k, use_exact, cmu, tqp);
+        stage_post_pre<NT, NC, FG>(lds, N, fg_base, k, use_exact, reg, cmu, tpk, tqp);
     }
     // (a non-positive pivot raises the flag and the stages after it run on garbage, harmlessly -- every array they write is
     // rebuilt by the retry; testing the flag once here instead of once per stage takes an LDS round trip out of every stage)
