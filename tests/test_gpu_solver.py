@@ -135,11 +135,13 @@ def test_config4_shard_of_8192():
     parity.assert_within(cfg.N, worst)
 
 
-@pytest.mark.parametrize("N,dt,B", [(13, 0.1, 16), (15, 0.1, 16), (22, 0.06, 16), (17, 0.06, 16), (13, 0.1, 400), (22, 0.06, 400)])
+@pytest.mark.parametrize("N,dt,B", [(13, 0.1, 16), (15, 0.1, 16), (22, 0.06, 16), (17, 0.06, 16), (10, 0.1, 16), (12, 0.1, 16),
+                                    (13, 0.1, 400), (22, 0.06, 400), (10, 0.1, 400), (12, 0.1, 400), (15, 0.1, 400), (17, 0.06, 400), (25, 0.06, 400)])
 def test_every_shipped_horizon(N, dt, B):
     """The horizons of the robots the reference ships configurations for (ergoCubSN000: 13, iCubGazeboV3: 15, ergoCubSN001: 22;
-    SURVEY 8a-1) are compile-time instantiations of the resident kernel; 17 takes the run-time-N variant; B = 400 > #CU takes the
-    HBM-factor variant with run-time N.  Walking problems with pushes, against the oracle."""
+    SURVEY 8a-1; iCub plumbing config: 10; ergoCubGazeboV1_1: 12) are compile-time instantiations of the resident kernel; 17 takes the
+    run-time-N variant; B = 400 > #CU takes the HBM-factor variant with run-time N (every horizon but 20 and 30, which have their own
+    instantiations; 25 has its slacks and multipliers in HBM).  Walking problems with pushes, against the oracle."""
     cfg = cm.config.ergocub_gazebo_v1(N, dt)
     base, P0, X00 = cm.synthetic.config3_external_push(B, N=N, seed=31 + N)
     assert base.N == N
