@@ -1195,6 +1195,7 @@ __device__ __attribute__((noinline)) void stage_mid(lds_t lds, int Nrt, float* f
     CMPC_PHASE_PROLOGUE;
     const int k = __builtin_amdgcn_readfirstlane(k_in);
     const bool use_exact = __builtin_amdgcn_readfirstlane((int)exact_in) != 0;
+    PROF_DECL;
     if (tid < (CMPC_ONE_WAVE_FACTOR(FG) ? 64 : 128)) {
         const int fixedmask = (~c.qmask[k]) & 63;
         stage_factor<CMPC_ONE_WAVE_FACTOR(FG), FG>(c.QuuF, c.QuuD, c.Pan, RecRef<FG>(c.Lf, N, k), prm.D[0], prm.D[1], prm.D[2], c.flag, tid, fixedmask);
@@ -1207,6 +1208,7 @@ __device__ __attribute__((noinline)) void stage_mid(lds_t lds, int Nrt, float* f
         }
     }
     __syncthreads();
+    PROF(3);
 }
 template <int NT, int NC, bool FG>
 __device__ __attribute__((noinline)) void stage_post_pre(lds_t lds, int Nrt, float* fg_base, int k_in, bool exact_in, float reg, float cmu, int tpk, int tqp)
