@@ -273,6 +273,7 @@ static void fill_params(cmpc_handle h, CmpcParams& p)
     // config 2 wants ~0.03, config 3 ~0.3; the rule cuts the slowest problem of a 256-batch by ~0.7 iterations)
     p.mu_init = h->cfg.mu_init > 0 ? (float)h->cfg.mu_init : 0.1f;
     p.mu_adapt = h->cfg.mu_init > 0 ? 0.f : 3.5f;
+    if (const char* e = std::getenv("CMPC_MU_ADAPT")) { if (p.mu_adapt > 0.f) p.mu_adapt = (float)std::atof(e); }   // developer knob
     p.t_floor = 1e-2f;
     p.duals = h->dDuals; p.warm_duals = h->warm_duals;
 }
