@@ -56,13 +56,23 @@ def main():
         _, _, hc, hr = ref.sparsity("nlp_hess_l", "out", 0)
         jcol = np.repeat(np.arange(ref_nlp.NX), np.diff(jc))
         hcol = np.repeat(np.arange(ref_nlp.NX), np.diff(hc))
-        for t in range(4):
-            if t < 3:
+        # samples 0-2 random, 3 standing (as in round 1: the tests index them), 4-5 random, 6-9 stepping states from the package's
+        # N = 12 generators (swing phase + push; yawed feet, R != I) around their cold starts -- physically meaningful x and p
+        import cmpc_amd as cm
+        _, Pw, Xw = cm.synthetic.walking_push_n12(which, B=2, seed=141)
+        _, Py, Xy = cm.synthetic.yawed_steps_n12(which, B=2, seed=142)
+        stepping = [(Xw[0], Pw[0]), (Xw[1], Pw[1]), (Xy[0], Py[0]), (Xy[1], Py[1])]
+        for t in range(10):
+            if t < 3 or t in (4, 5):
                 x = rng.normal(size=ref_nlp.NX)
                 p = rng.normal(size=ref_nlp.NP)
-            else:
+            elif t == 3:
                 x, p = standing_xp(rng)
-            lf = float(rng.normal()) if t < 3 else 1.0
+            else:
+                x0, p = stepping[t - 6]
+                x = x0 + 0.02 * rng.normal(size=ref_nlp.NX)
+                p = np.array(p, dtype=np.float64)
+            lf = float(rng.normal()) if (t < 3 or t in (4, 5)) else 1.0
             lg = rng.normal(size=ref_nlp.NG)
             f, gf, g, J = ref.jac_fg(x, p)
             H = ref.hess_l(x, p, lf, lg)

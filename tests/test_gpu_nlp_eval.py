@@ -48,11 +48,15 @@ def test_callbacks_match_reference_generated_code(which, golden_dir):
     np.testing.assert_array_equal(jr, d["jac_row"]); np.testing.assert_array_equal(hr, d["hess_row"])
     np.testing.assert_array_equal(np.bincount(jc, minlength=555).cumsum(), d["jac_colind"][1:])
     np.testing.assert_array_equal(np.bincount(hc, minlength=555).cumsum(), d["hess_colind"][1:])
-    assert lam_f == 1.0
+    assert lam_f == 1.0 and n >= 10
     for t in range(n):
         _close(F[t], d["f"][t]); _close(G[t], d["g"][t]); _close(GF[t], d["grad_f"][t]); _close(J[t], d["jac_nnz"][t])
-    # hess goldens were taken with per-sample lam_f; rescale the cost part: compare sample 3 (lam_f = 1) directly
-    _close(H[3], d["hess_nnz"][3])
+    # hess goldens were taken with per-sample lam_f and one launch has one lam_f: compare the samples taken at lam_f = 1 (the standing
+    # state and the four stepping states: swing phase + push, yawed feet)
+    ones = [t for t in range(n) if d["lam_f"][t] == 1.0]
+    assert len(ones) >= 5
+    for t in ones:
+        _close(H[t], d["hess_nnz"][t])
 
 
 def test_callbacks_match_oracle_at_n20():
