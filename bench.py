@@ -341,6 +341,8 @@ def main():
                     pm = json.load(open(fn))
                     if abs(pm.get("algorithmic_bytes_per_launch", 0) - sm["roofline"]["algorithmic_hbm_bytes_per_launch"]) < 1:
                         sm["roofline"]["traffic"] = pm["hbm_bytes_per_launch"]
+                        sm["roofline"]["hbm_GBps"] = round(pm["hbm_bytes_per_launch"] / (sm["roofline"]["kernel_ms_avg"] * 1e-3) / 1e9, 1)
+                        sm["roofline"]["valu_active_over_wave_cycles"] = round(pm["derived"]["valu_active_over_wave_cycles"], 3)
                         sm["roofline"]["traffic_source"] = f"profiles/r02_pmc_summary_{wl}.json (committed rocprofv3 --pmc passes; not measured in this run)"
                         sm["roofline"]["traffic_note"] = ("HBM-factor variant: per-stage factor records, slacks and multipliers stream through L2/HBM "
                                                           "(three workgroups per CU); not re-reads of the inputs")
@@ -351,8 +353,12 @@ def main():
             import glob
             pm = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))
             if pm and args.workload == "config2" and m["batch_per_gpu"] == 256:
-                traffic = json.load(open(pm[-1]))["hbm_bytes_per_launch"]
+                pmj = json.load(open(pm[-1]))
+                traffic = pmj["hbm_bytes_per_launch"]
                 tsrc = os.path.relpath(pm[-1], ROOT)
+                # HBM GB/s (tiny: the state lives in LDS) and VALU busy, from the same committed counter passes
+                m["roofline"]["hbm_GBps"] = round(traffic / (m["roofline"]["kernel_ms_avg"] * 1e-3) / 1e9, 2)
+                m["roofline"]["valu_active_over_wave_cycles"] = round(pmj["derived"]["valu_active_over_wave_cycles"], 3)
         except Exception:
             traffic = None
         m["roofline"]["traffic"] = traffic
