@@ -134,14 +134,18 @@ struct RecRef<false> {
 };
 template <>
 struct RecRef<true> {
+    typedef __attribute__((address_space(1))) unsigned gu32_t;
+    typedef __attribute__((address_space(1))) v4u gv4u_t;
     __amdgpu_buffer_rsrc_t r;
     unsigned so;   // byte offset of the stage (SGPR)
+    char* gb;      // wave-uniform address of the stage's record, for the stores
     __device__ RecRef(float* base, int N, int k)
     {
         const unsigned long long a = (unsigned long long)base;
         const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
         r = __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0, 4 * REC_N * N, 0x00020000);
         so = 4u * REC_N * (unsigned)k;
+        gb = (char*)(((unsigned long long)hi << 32) | lo) + so;
     }
     __device__ float ld(unsigned off) const { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, 4u * off, so, 0)); }
     __device__ float4 ld4(unsigned off) const
@@ -149,11 +153,16 @@ struct RecRef<true> {
         const v4u v = __builtin_amdgcn_raw_buffer_load_b128(r, 4u * off, so, 0);
         return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
     }
-    __device__ void st(unsigned off, float v) const { __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, 4u * off, so, 0); }
+    // Stores are plain global stores on the uniform address, NOT buffer stores: a 16-byte buffer_store with the stage offset in an
+    // SGPR `soffset` delivered single wrong dwords (the data registers are re-used right behind the store; with a register soffset
+    // the compiler inserts no wait state for that) -- not in every build: the shipped one happened to be right, the instrumented
+    // build and a variant with the whole stage behind one call left 10-50 % of the problems of some batches unconverged.  Found by
+    // dumping the records of both builds: identical value functions, a handful of differing record entries (profiles/r02_experiments_not_kept.txt).
+    __device__ void st(unsigned off, float v) const { *(gu32_t*)(gb + 4u * off) = __float_as_uint(v); }
     __device__ void st4(unsigned off, const float4& w) const
     {
         const v4u v = {__float_as_uint(w.x), __float_as_uint(w.y), __float_as_uint(w.z), __float_as_uint(w.w)};
-        __builtin_amdgcn_raw_buffer_store_b128(v, r, 4u * off, so, 0);
+        *(gv4u_t*)(gb + 4u * off) = v;
     }
 };
 
