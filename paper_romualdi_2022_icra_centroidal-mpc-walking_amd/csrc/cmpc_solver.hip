@@ -1195,9 +1195,8 @@ __device__ __attribute__((noinline)) void stage_desc(lds_t lds, int Nrt, float* 
 
 // A backward stage is two calls.  stage_mid: phase 3 of stage k -- the factorisation on wave 0 (waves 0-1 in the resident
 // variants), Qss and the descriptors of stage k-1 on the others -- and the barrier behind it.  stage_post_pre: phase 4 of stage k,
-// then phases 1-2 of stage k-1.  (Four calls per stage cost 2 % in prologues and stage addresses.  All of it behind ONE call
-// measures another +1 % but must not be done: with phase 4 in the same function as the factorisation the HBM-factor variants
-// other than N = 20 stop converging -- inexact steps, cause not found, barriers and waits ruled out; profiles/r02_experiments_not_kept.txt.)
+// then phases 1-2 of stage k-1.  (Four calls per stage cost 2 % in prologues and stage addresses; all of it behind ONE call is
+// within +-0.5 % of two.  The one-call variant is how the buffer-store problem described at RecRef<true> was found.)
 template <int NT, int NC, bool FG>
 __device__ __attribute__((noinline)) void stage_mid(lds_t lds, int Nrt, float* fg_base, int k_in, bool exact_in, float cmu, int tqp)
 {
