@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcmpc_hip.so")
+LIB_PATH = os.path.join(_HERE, os.environ.get("CMPC_LIB", "libcmpc_hip.so"))   # (CMPC_LIB: developer knob, another build of the same library in the package directory)
 
 INFO = 8
 
