@@ -11,13 +11,16 @@
 // is test infrastructure; this file is the product and shares no code with it.
 //
 // Arithmetic: float32 storage and matrix work; float64 where cancellation decides the answer:
-// dynamics defects, right-hand-side / costate recursions, and the 3x3 diagonal blocks of the stage
+// dynamics defects, the right-hand-side recursion, and the 3x3 diagonal blocks of the stage
 // Hessian Quu through its Cholesky (barrier terms z/t span 1e-6..1e9 inside one corner's block
-// next to cost curvature of order 10).
+// next to cost curvature of order 10).  Costates are float32: they only enter the exact-Hessian term.
 //
-// Structure.  The kernel body is a driver; every phase is an out-of-line device function (a register
-// allocation of its own) handed the LDS base.  One stage of the backward sweep (256 threads = 4 waves,
-// 4 barriers):
+// Structure.  The kernel body is a driver; the phases live in out-of-line device functions (register
+// allocations of their own) handed the LDS base: two per backward stage (stage_mid: phase 3;
+// stage_post_pre: phase 4 and phases 1-2 of the next stage), one per sweep.  Two variants: "resident"
+// (512 threads, per-stage factor records in LDS, one workgroup per CU, B <= #CU) and "HBM-factor" (256
+// threads, records in global scratch, three workgroups per CU).  One stage of the backward sweep (wave
+// numbers of the four-wave shape; 4 barriers):
 //   1. G = P [B;E]                        sparse: every column of A, B has <= 3 non-zeros
 //   2. Quu, Qus (waves 0-1, float32), Quu diagonal blocks (wave 2, float64), Pd and qu (wave 3, float64)
 //   3. fused Cholesky + panel solve       waves 0-1, matrix rows in registers: lanes 0-29 hold the rows of
