@@ -93,6 +93,16 @@ int main()
             for (const auto& corner : contact.corners) fz += corner.force[2];
         }
         std::printf("tick %d contacts %d total_fz %.6f com %.5f %.5f %.5f\n", tick, ncontacts, fz, com[0], com[1], com[2]);
+        // the numbers themselves (tests/test_gpu_facade.py replays the ticks through the C ABI and compares): per contact in the
+        // output map the 12 first-knot corner-force components (what WholeBodyQPBlock.cpp:824-829 reads), then the CoM trajectory
+        for (const auto& [name, contact] : out.contacts) {
+            std::printf("forces %d %s", tick, name.c_str());
+            for (const auto& corner : contact.corners) std::printf(" %.9g %.9g %.9g", corner.force[0], corner.force[1], corner.force[2]);
+            std::printf("\n");
+        }
+        std::printf("comtraj %d", tick);
+        for (const auto& ck : out.comTrajectory) std::printf(" %.9g %.9g %.9g", ck[0], ck[1], ck[2]);
+        std::printf("\n");
     }
     const auto& ll = block.m_controller.getOutput().contactPhaseList.lists().at("left_foot");
     const auto next = ll.getNextContact(block.m_absoluteTime - block.m_dT);

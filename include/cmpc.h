@@ -66,15 +66,27 @@ typedef struct {
                                * mu = 0 (one more factorisation): removes the O(mu) bias of the barrier floor and
                                * the remaining termination error -- worst parity error of 1024 problems 8.7e-5 ->
                                * 1.7e-5 (config 2) for +0.8 iteration; 0: stop at the barrier floor */
+    /* tail polish (needs final_extrapolation): when the extrapolation step of the forces of the last tail_stages stages
+     * exceeds tail_trigger x the largest force component -- the symptom of nearly degenerate friction rows there, e.g. an
+     * unloaded corner at the apex of its pyramid, which the barrier keeps sqrt(mu / curvature) away from the optimum --
+     * those stages are re-solved on their own (state entering them held): tail_iterations Newton steps with per-row
+     * barrier targets, then their own extrapolation step.  Defaults 3 / 2 / 2e-5; tail_stages 0 switches it off. */
+    int tail_stages;
+    int tail_iterations;
+    double tail_trigger;
 } cmpc_config;
 
 /* number of floats per solve in the info array */
 #define CMPC_INFO 8
-/* info[b] = { iterations, kkt_error = max(primal_inf, max t*z), mu, gauss_newton_fallbacks, primal_inf,
- * status (0 ok, 1 iteration budget exhausted, 2 factorisation failed), solve_cycles (shader clock),
+/* info[b] = { iterations, kkt_error = max(primal_inf, max t*z), mu, safeguards, primal_inf,
+ * status (0 ok, 1 iteration budget exhausted, 2 factorisation failed or a residual that is not finite -- NaN/inf in P or
+ * X0: IPOPT's "invalid number"), solve_cycles (shader clock),
  * last_step (max-norm of the last Newton step taken inside the loop, forces relative to the largest force) }.
  * kkt_error, mu and primal_inf are those of the last iterate whose residuals were evaluated: the iterate the
- * termination test accepted.  With final_extrapolation the returned x is one affine-scaling step beyond it. */
+ * termination test accepted.  With final_extrapolation the returned x is one affine-scaling step beyond it.
+ * safeguards = Gauss-Newton fallbacks + 100 x emergency re-centrings (warm starts) + 10000 x (1 if the warm-started pass
+ * was abandoned and the problem solved again from the cold start) + 100000 x (1 if the tail was polished).
+ * iterations counts both passes of a restarted warm start: it can reach 2 x max_iterations. */
 
 void cmpc_default_config(cmpc_config* cfg);                      /* ergoCubGazeboV1 values, N=20 */
 int cmpc_dims(int horizon, int* n_x, int* n_p, int* n_g, int* nnz_jac, int* nnz_hess);
@@ -90,6 +102,12 @@ void* cmpc_stream(cmpc_handle h);                                 /* hipStream_t
  * Asynchronous on the handle's stream (or on `stream` if non-NULL); nothing is copied. */
 int cmpc_solve_device(cmpc_handle h, const float* dP, const float* dX0, float* dX, float* dInfo,
                       void* stream);
+/* the same when dX0 is the previous solution shifted by one knot (cmpc_shift_solution_device; is_warm_start_enabled,
+ * ergoCubGazeboV1/centroidal_mpc.ini:9): the barrier starts near the central path (mu = 1e-2) and a problem whose warm
+ * start does not converge is solved again inside the kernel from the cold start.  The warm property is this argument
+ * list's, not the handle's: any buffer, any stream. */
+int cmpc_solve_device_warm(cmpc_handle h, const float* dP, const float* dX0, float* dX, float* dInfo,
+                           void* stream);
 /* host buffers (includes the PCIe copies; synchronous). info may be NULL. Returns
  * CMPC_ERR_NOT_CONVERGED if any problem's status != 0 (the solutions are still written). */
 int cmpc_solve(cmpc_handle h, const float* P, const float* X0, float* X, float* info);
@@ -175,7 +193,8 @@ int cmpc_compact_output_device(cmpc_handle h, const float* dX, const float* dInf
 int cmpc_contacts_merge(int batch, int max_contacts, double now, const double* plan_t, const float* plan_pose, const int* plan_n,
                         const double* mpc_t, const float* mpc_pose, const int* mpc_n, double* out_t, float* out_pose, int* out_n,
                         int* ok /* [B] or NULL */);
-/* same on the device (one thread per problem and foot); dOk[B] or NULL; asynchronous on `stream` (NULL: the handle's) */
+/* same on the device (one thread per problem and foot); dOk[B] or NULL; asynchronous on `stream` (NULL: the handle's).
+ * A list length outside 0..max_contacts gives an empty merged list and dOk = 0 (nothing is read through it). */
 int cmpc_contacts_merge_device(cmpc_handle h, int max_contacts, double now, const double* dPlanT, const float* dPlanPose,
                                const int* dPlanN, const double* dMpcT, const float* dMpcPose, const int* dMpcN, double* dOutT,
                                float* dOutPose, int* dOutN, int* dOk, void* stream);
@@ -185,7 +204,10 @@ int cmpc_contacts_merge_device(cmpc_handle h, int max_contacts, double now, cons
  * is in contact iff a contact is active at its start; its orientation, box limits and the nominal position of knot
  * k+1 come from the stage's owner = the active contact, else the next one to activate, else the last.  box_upper /
  * box_lower [2][3]: bounding_box_{upper,lower}_limit of [CONTACT_i].  land[B][2] (or NULL) receives the landing knot of
- * each foot: first knot in contact after a swing stage, N if still in the air at the end, -1 if it never lifts. */
+ * each foot: first knot in contact after a swing stage, N if still in the air at the end, -1 if it never lifts.
+ * A foot whose list is empty or longer than max_contacts: the host entry points return CMPC_ERR_ARG; the device kernel
+ * leaves that foot's blocks of dP untouched and writes land = -2 (the caller must not solve that problem: the reference
+ * aborts the tick when its merge fails, CentroidalMPCBlock.cpp:603-607). */
 int cmpc_contacts_sample(int horizon, double dt, int batch, int max_contacts, double now, const double* t, const float* pose,
                          const int* n, const float* box_upper, const float* box_lower, float* P, int* land);
 int cmpc_contacts_sample_device(cmpc_handle h, int max_contacts, double now, const double* dT, const float* dPose, const int* dN,
@@ -204,8 +226,8 @@ int cmpc_contacts_adjust_device(cmpc_handle h, int max_contacts, double now, con
 
 /* setState on the device: dState[B][9] (com, dcom, h) and dWrench[B][N][6] (or NULL: left alone) into the rows of dP */
 int cmpc_write_state_device(cmpc_handle h, const float* dState, const float* dWrench, float* dP, void* stream);
-/* is_warm_start_enabled on the device: dX0 = dXprev shifted by one knot; the next cmpc_solve_device starts its barrier
- * near the central path (as cmpc_set_initial_guess(NULL, 1) + cmpc_advance do for the handle's own buffers) */
+/* is_warm_start_enabled on the device: dX0 = dXprev shifted by one knot; solve from it with cmpc_solve_device_warm
+ * (cmpc_set_initial_guess(NULL, 1) + cmpc_advance do the same for the handle's own buffers) */
 int cmpc_shift_solution_device(cmpc_handle h, const float* dXprev, float* dX0, void* stream);
 
 #ifdef __cplusplus

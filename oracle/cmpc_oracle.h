@@ -58,6 +58,9 @@ typedef struct {
     double mu_min;      /* smallest barrier parameter */
     int exact_hessian;  /* 1: Lagrangian Hessian incl. the bilinear momentum term; 0: Gauss-Newton */
     int verbose;
+    int tail_stages;    /* > 0: re-solve the last tail_stages stages after convergence when the extrapolation step there is large */
+    int tail_iters;     /* Newton steps of that re-solve (before its own affine-scaling step) */
+    double tail_trigger;/* ... larger than tail_trigger x the largest force component */
 } cmpc_ipm_opts;
 
 #ifdef __cplusplus

@@ -374,7 +374,7 @@ static void kkt_error(const ws* w, REAL mu, REAL* stat, REAL* prim, REAL* comp, 
 
 /* ---------------- Riccati backward sweep ---------------- */
 /* builds and factorises the stage QPs; returns 0 ok / 1 non-positive pivot at some stage */
-static int riccati_backward(ws* w, int use_exact)
+static int riccati_backward(ws* w, int use_exact, int k0)
 {
     const cmpc_nlp_cfg* cfg = w->cfg;
     const int N = w->N;
@@ -387,7 +387,7 @@ static int riccati_backward(ws* w, int use_exact)
     memset(Pm, 0, sizeof(Pm)); memset(pv, 0, sizeof(pv));
     for (i = 0; i < NS; ++i) { Pm[i * NXA + i] = qdiag(w, N, i); pv[i] = w->gs[N][i]; }
 
-    for (k = N - 1; k >= 0; --k) {
+    for (k = N - 1; k >= k0; --k) {
         const MREAL* A = w->A[k];
         const MREAL* B = w->B[k];
         const REAL* d = w->d[k];
@@ -554,13 +554,13 @@ static int riccati_backward(ws* w, int use_exact)
 
 /* vector-only backward sweep for a changed right-hand side: the row coefficients change by DG
  * (corrector of the predictor-corrector step); updates lq in place using the stored factors */
-static void riccati_delta(ws* w)
+static void riccati_delta(ws* w, int k0)
 {
     const int N = w->N;
     REAL dp[NXA], dq[NU], dl[NU];
     int k, i, a, havep = 0;
     memset(dp, 0, sizeof(dp));
-    for (k = N - 1; k >= 0; --k) {
+    for (k = N - 1; k >= k0; --k) {
         const MREAL* A = w->A[k];
         const MREAL* B = w->B[k];
         const MREAL* Lc = w->Lc[k];
@@ -601,19 +601,19 @@ static void riccati_delta(ws* w)
 }
 
 /* forward sweep: dS, dU; then new costates LAMn backward; then dT, dZ */
-static void riccati_forward(ws* w)
+static void riccati_forward(ws* w, int k0)
 {
     const int N = w->N;
     int k, i, a;
-    memset(w->dS[0], 0, sizeof(REAL) * NS);
-    for (k = 0; k < N; ++k) {
+    memset(w->dS[k0], 0, sizeof(REAL) * NS);   /* the state the sweep starts from is held (k0 = 0: the measured state) */
+    for (k = k0; k < N; ++k) {
         const MREAL* W = w->W[k];
         const MREAL* Lc = w->Lc[k];
         REAL y[NU];
         for (i = 0; i < NU; ++i) {
             REAL v = w->lq[k][i];
             for (a = 0; a < NS; ++a) v += W[i * NXA + a] * w->dS[k][a];
-            if (k > 0) for (a = 0; a < NF; ++a) v += W[i * NXA + NS + a] * w->dU[k - 1][a];
+            if (k > k0) for (a = 0; a < NF; ++a) v += W[i * NXA + NS + a] * w->dU[k - 1][a];   /* (the force before stage k0 is held too) */
             y[i] = -v;
         }
         for (i = NU - 1; i >= 0; --i) {
@@ -630,7 +630,7 @@ static void riccati_forward(ws* w)
     }
     /* costates: lam_N = Q_N ds_N + gs_N ; lam_k = gs_k + Q_k ds_k + S_k^T du_k + A_k^T lam_{k+1} */
     for (i = 0; i < NS; ++i) w->LAMn[N][i] = w->gs[N][i] + qdiag(w, N, i) * w->dS[N][i];
-    for (k = N - 1; k >= 1; --k) {
+    for (k = N - 1; k >= 1 && k0 == 0; --k) {
         REAL Fsum[3] = {0, 0, 0}, Fc[2][3] = {{0, 0, 0}, {0, 0, 0}};
         int c, j;
         for (c = 0; c < 2; ++c) {
@@ -653,7 +653,7 @@ static void riccati_forward(ws* w)
         }
     }
     memset(w->LAMn[0], 0, sizeof(REAL) * NS);
-    for (k = 0; k < N; ++k)
+    for (k = k0; k < N; ++k)
         for (i = 0; i < NI; ++i) {
             REAL t, z, r, dt_;
             if (!row_active(w, k, i)) { w->dT[k][i] = 0; w->dZ[k][i] = 0; continue; }
@@ -739,18 +739,51 @@ static void export_x(const ws* w, PREAL* x)
 }
 
 /* ---------------- driver ---------------- */
-static void step_lengths(const ws* w, REAL tau, REAL* ap_out, REAL* ad_out)
+static void step_lengths(const ws* w, REAL tau, int k0, REAL* ap_out, REAL* ad_out)
 {
     const int N = w->N;
     REAL ap = 1, ad = 1;
     int k, i;
-    for (k = 0; k < N; ++k)
+    for (k = k0; k < N; ++k)
         for (i = 0; i < NI; ++i) {
             if (!row_active(w, k, i)) continue;
             if (w->dT[k][i] < 0) { REAL a = -tau * w->T[k][i] / w->dT[k][i]; if (a < ap) ap = a; }
             if (w->dZ[k][i] < 0) { REAL a = -tau * w->Z[k][i] / w->dZ[k][i]; if (a < ad) ad = a; }
         }
     *ap_out = ap; *ad_out = ad;
+}
+
+/* ---------------- tail polish: the last stages re-solved with the state entering them held ----------------
+ * Stages k0..N-1 form a small problem of their own once s_k0 and f_{k0-1} are fixed: tail_iters Newton steps on it with
+ * per-row complementarity targets mu_i = mu_min min(1, z_i^2) (never below 1e-4 mu_min) -- a row keeps z_i / t_i = z_i^2 / mu_i
+ * <= 1 / mu_min, the conditioning the main loop already lives with, while rows whose multiplier vanishes are followed
+ * further down their path -- then one affine-scaling step (primal only), as at the end of the main loop. */
+static void tail_polish(ws* w, const cmpc_ipm_opts* opt, int k0)
+{
+    const int N = w->N;
+    int pi, k, i;
+    for (pi = 0; pi <= opt->tail_iters; ++pi) {
+        const int last = (pi == opt->tail_iters);
+        REAL ap, ad;
+        int fail;
+        linearise(w);
+        for (k = k0; k < N; ++k)
+            for (i = 0; i < NI; ++i) {
+                REAL z = w->Z[k][i], m = (REAL)opt->mu_min * (z < 1 ? z * z : (REAL)1);
+                if (m < (REAL)1e-4 * (REAL)opt->mu_min) m = (REAL)1e-4 * (REAL)opt->mu_min;
+                w->CMU[k][i] = (last || !row_active(w, k, i)) ? 0 : m;
+            }
+        fail = riccati_backward(w, opt->exact_hessian, k0);
+        if (fail) fail = riccati_backward(w, 0, k0);
+        if (fail) return;
+        riccati_forward(w, k0);
+        step_lengths(w, last ? (REAL)0.999 : (REAL)0.99, k0, &ap, &ad);
+        for (k = k0 + 1; k <= N; ++k) for (i = 0; i < NS; ++i) w->S[k][i] += ap * w->dS[k][i];
+        for (k = k0; k < N; ++k) {
+            for (i = 0; i < NU; ++i) w->U[k][i] += ap * w->dU[k][i];
+            if (!last) for (i = 0; i < NI; ++i) { w->T[k][i] += ap * w->dT[k][i]; w->Z[k][i] += ad * w->dZ[k][i]; }
+        }
+    }
 }
 
 /* info: [0]=iterations [1]=kkt error [2]=final mu [3]=#GN fallbacks [4]=primal inf [5]=status */
@@ -787,24 +820,39 @@ int FN(cmpc_ref_solve_one)(const cmpc_nlp_cfg* cfg, const cmpc_ipm_opts* opt, co
             status = 0;
             if (opt->verbose >= 0) {
                 memset(w->CMU, 0, sizeof(w->CMU));
-                fail = riccati_backward(w, opt->exact_hessian);
-                if (fail) fail = riccati_backward(w, 0);
+                fail = riccati_backward(w, opt->exact_hessian, 0);
+                if (fail) fail = riccati_backward(w, 0, 0);
                 if (!fail) {
-                    riccati_forward(w);
-                    step_lengths(w, (REAL)0.999, &ap, &ad);
-                    for (k = 0; k <= N; ++k) for (i = 0; i < NS; ++i) w->S[k][i] += ap * w->dS[k][i];
-                    for (k = 0; k < N; ++k) for (i = 0; i < NU; ++i) w->U[k][i] += ap * w->dU[k][i];
+                    int k0 = N, trig = 0;
+                    riccati_forward(w, 0);
+                    step_lengths(w, (REAL)0.999, 0, &ap, &ad);
+                    if (opt->tail_stages > 0 && opt->tail_stages < N) {
+                        /* The extrapolation is exact to first order where the central path is smooth in mu.  Rows that are
+                         * (nearly) degenerate -- slack and multiplier both -> 0, e.g. the friction rows of an unloaded corner --
+                         * follow sqrt(mu) and the step covers half of their distance.  That matters in the last stages only,
+                         * whose forces the cost barely sees (no cost on the CoM velocity, nothing after them): bias sqrt(mu / curvature).
+                         * A large extrapolation step there is the symptom: then those stages are re-solved on their own. */
+                        REAL fm = 1, tail = 0;
+                        k0 = N - opt->tail_stages;
+                        for (k = 0; k < N; ++k) for (i = 0; i < NF; ++i) { REAL a = (REAL)fabs((double)w->U[k][i]); if (a > fm) fm = a; }
+                        for (k = k0; k < N; ++k) for (i = 0; i < NF; ++i) { REAL a = (REAL)fabs((double)w->dU[k][i]); if (a > tail) tail = a; }
+                        trig = ap * tail > (REAL)opt->tail_trigger * fm;
+                        if (!trig) k0 = N;
+                    }
+                    for (k = 0; k <= (trig ? k0 : N); ++k) for (i = 0; i < NS; ++i) w->S[k][i] += ap * w->dS[k][i];
+                    for (k = 0; k < (trig ? k0 : N); ++k) for (i = 0; i < NU; ++i) w->U[k][i] += ap * w->dU[k][i];
+                    if (trig) { tail_polish(w, opt, k0); gn += 100; }   /* (info[3] >= 100 marks a polished tail) */
                 }
             }
             break;
         }
         /* predictor (affine scaling) */
         memset(w->CMU, 0, sizeof(w->CMU));
-        fail = riccati_backward(w, opt->exact_hessian);
-        if (fail) { ++gn; fail = riccati_backward(w, 0); }
+        fail = riccati_backward(w, opt->exact_hessian, 0);
+        if (fail) { ++gn; fail = riccati_backward(w, 0, 0); }
         if (fail) { status = 2; break; }
-        riccati_forward(w);
-        step_lengths(w, 1, &ap, &ad);
+        riccati_forward(w, 0);
+        step_lengths(w, 1, 0, &ap, &ad);
         for (k = 0; k < N; ++k)
             for (i = 0; i < NI; ++i)
                 if (row_active(w, k, i)) mu_aff += (w->T[k][i] + ap * w->dT[k][i]) * (w->Z[k][i] + ad * w->dZ[k][i]);
@@ -819,10 +867,10 @@ int FN(cmpc_ref_solve_one)(const cmpc_nlp_cfg* cfg, const cmpc_ipm_opts* opt, co
                 w->CMU[k][i] = mu_t - w->dT[k][i] * w->dZ[k][i];
                 w->DG[k][i] = w->CMU[k][i] / w->T[k][i];
             }
-        riccati_delta(w);
-        riccati_forward(w);
+        riccati_delta(w, 0);
+        riccati_forward(w, 0);
         tau = 1 - mu_t; if (tau < (REAL)0.99) tau = (REAL)0.99;
-        step_lengths(w, tau, &ap, &ad);
+        step_lengths(w, tau, 0, &ap, &ad);
         for (k = 0; k <= N; ++k)
             for (i = 0; i < NS; ++i) {
                 w->S[k][i] += ap * w->dS[k][i];

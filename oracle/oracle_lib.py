@@ -35,6 +35,9 @@ class IpmOpts(C.Structure):
         ("mu_min", C.c_double),
         ("exact_hessian", C.c_int),
         ("verbose", C.c_int),
+        ("tail_stages", C.c_int),
+        ("tail_iters", C.c_int),
+        ("tail_trigger", C.c_double),
     ]
 
 
@@ -150,9 +153,10 @@ def nlp_grad(cfg, x, p, lam_f, lam_g):
     return gx, gp
 
 
-def ipm_opts(max_iter=60, tol=1e-9, mu_init=0.1, mu_min=1e-10, exact_hessian=1, verbose=0):
+def ipm_opts(max_iter=60, tol=1e-9, mu_init=0.1, mu_min=1e-10, exact_hessian=1, verbose=0, tail_stages=0, tail_iters=3, tail_trigger=1e-5):
     o = IpmOpts()
     o.max_iter, o.tol, o.mu_init, o.mu_min, o.exact_hessian, o.verbose = max_iter, tol, mu_init, mu_min, exact_hessian, verbose
+    o.tail_stages, o.tail_iters, o.tail_trigger = tail_stages, tail_iters, tail_trigger
     return o
 
 

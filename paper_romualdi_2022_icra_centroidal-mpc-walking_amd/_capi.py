@@ -30,6 +30,9 @@ class CmpcConfig(C.Structure):
         ("mu_min", C.c_double),
         ("exact_hessian", C.c_int),
         ("final_extrapolation", C.c_int),
+        ("tail_stages", C.c_int),
+        ("tail_iterations", C.c_int),
+        ("tail_trigger", C.c_double),
     ]
 
 
@@ -41,7 +44,7 @@ EXPORTS = [
     "cmpc_get_output", "cmpc_set_reference_from_planner", "cmpc_plant_step_device", "cmpc_test_poison_lds",
     "cmpc_compact_output_device", "cmpc_contacts_merge", "cmpc_contacts_merge_device", "cmpc_contacts_sample",
     "cmpc_contacts_sample_device", "cmpc_set_contact_lists", "cmpc_contacts_adjust", "cmpc_contacts_adjust_device",
-    "cmpc_write_state_device", "cmpc_shift_solution_device", "cmpc_eval_nlp_grad_device",
+    "cmpc_write_state_device", "cmpc_shift_solution_device", "cmpc_eval_nlp_grad_device", "cmpc_solve_device_warm",
 ]
 
 _lib = None
@@ -73,6 +76,7 @@ def lib():
         L.cmpc_stream.argtypes = [vp]
         L.cmpc_stream.restype = vp
         L.cmpc_solve_device.argtypes = [vp, fp, fp, fp, fp, vp]
+        L.cmpc_solve_device_warm.argtypes = [vp, fp, fp, fp, fp, vp]
         L.cmpc_solve.argtypes = [vp, fp, fp, fp, fp]
         L.cmpc_last_solve_ms.argtypes = [vp]
         L.cmpc_test_poison_lds.argtypes = [vp]

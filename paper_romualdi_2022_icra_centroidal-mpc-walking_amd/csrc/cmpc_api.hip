@@ -46,15 +46,18 @@ struct cmpc_handle_s {
     CmpcConsts* dConsts = nullptr;
     float* dScratch = nullptr;   // factor storage when the horizon's LDS image exceeds 160 KiB
     float* dBox = nullptr;       // bounding-box limits upper[2][3] | lower[2][3] of the schedule sampler
-    float* dDuals = nullptr;     // costates, slacks, multipliers of the last solve (warm start with duals; allocated on first use)
+    float* dDuals = nullptr;     // costates, slacks, multipliers of the last solve (warm start with duals: allocated by cmpc_create when the developer knob CMPC_WARM_DUALS is set)
     int warm_duals = 0;          // 0: primal shift only (default); 1: + costates; 2: + multipliers
     float hBox[12] = {0};
     bool box_set = false;
     long long scratch_stride = 0;
     std::vector<float> hP, hX0;  // host staging for the class-shaped setters
     bool have_solution = false, x0_set = false;
-    bool warm = false;           // the pending initial guess is a shifted previous solution
+    bool warm = false;           // class path only (cmpc_set_initial_guess(.., 1) -> cmpc_advance): the handle's own dX0 is a shifted previous solution
     double mu_warm = 1e-2, floor_warm = 1e-2;  // measured: 1e-2 saves 35 % (standing) / 15 % (walking) of the iterations; 1e-4 can stall
+    int stall_window = 0;        // warm starts: see CmpcParams::stall_window
+    bool force_warm = false;     // developer knob CMPC_FORCE_WARM (read once, at cmpc_create)
+    float mu_adapt = 3.5f;       // cold starts: mu0 = clamp(mu_adapt ep0^2, 0.03, 0.5) (developer knob CMPC_MU_ADAPT, read once)
     size_t lds = 0;
     std::string err;
 };
@@ -102,6 +105,9 @@ void cmpc_default_config(cmpc_config* c)
     c->mu_min = 5e-8;
     c->exact_hessian = 1;
     c->final_extrapolation = 1;
+    c->tail_stages = 3;
+    c->tail_iterations = 2;
+    c->tail_trigger = 2e-5;
 }
 
 int cmpc_dims(int N, int* nx, int* np, int* ng, int* nnzj, int* nnzh)
@@ -144,6 +150,15 @@ int cmpc_create(const cmpc_config* cfg, int batch, int device, cmpc_handle* out)
     h->device = device;
     if (const char* e = std::getenv("CMPC_WARM_DUALS")) h->warm_duals = std::atoi(e);   // developer knob
     if (const char* e = std::getenv("CMPC_MU_WARM")) { h->mu_warm = std::atof(e); h->floor_warm = std::min(1e-2, h->mu_warm); }   // developer knob
+    // (every developer knob is read here, once: no getenv on the solve path)
+    h->stall_window = CMPC_STALL_WINDOW_DEFAULT;
+    if (const char* e = std::getenv("CMPC_STALL")) h->stall_window = std::atoi(e);
+    h->force_warm = std::getenv("CMPC_FORCE_WARM") != nullptr;
+    if (const char* e = std::getenv("CMPC_MU_ADAPT")) h->mu_adapt = (float)std::atof(e);
+    if (h->cfg.tail_stages < 0 || h->cfg.tail_stages >= h->cfg.horizon) h->cfg.tail_stages = 0;
+    if (h->cfg.tail_iterations < 0) h->cfg.tail_iterations = 0;
+    if (!(h->cfg.tail_trigger > 0)) h->cfg.tail_trigger = 2e-5;
+    if (!h->cfg.final_extrapolation) h->cfg.tail_stages = 0;   // (the polish hangs off the extrapolation step)
     cmpc_layout_init(h->L, cfg->horizon);
     h->lds = cmpc_solver_lds_bytes(cfg->horizon, 0);
     // factors in HBM scratch when the LDS image would not fit -- or, by choice, to halve the image so that
@@ -227,6 +242,7 @@ static void fill_consts(cmpc_handle h, CmpcConsts& q)
     std::memset(&q, 0, sizeof(q));
     q.N = c.horizon; q.max_iter = c.max_iterations;
     q.exact_hessian = c.exact_hessian; q.final_extrap = c.final_extrapolation;
+    q.tail_stages = c.tail_stages; q.tail_iters = c.tail_iterations; q.tail_trigger = (float)c.tail_trigger;
     q.dt = (float)c.sampling_time; q.mu_fr = (float)c.friction_coefficient; q.grav = (float)c.gravity;
     q.w_com0 = (float)c.com_weight[0]; q.w_com1 = (float)c.com_weight[1];
     q.w_h = (float)c.angular_momentum_weight; q.w_pos = (float)c.contact_position_weight;
@@ -272,13 +288,13 @@ static void fill_params(cmpc_handle h, CmpcParams& p)
     // mu0 = clamp(3.5 ep0^2, 0.03, 0.5) from the initial primal infeasibility ep0 (measured on 4096-problem batches:
     // config 2 wants ~0.03, config 3 ~0.3; the rule cuts the slowest problem of a 256-batch by ~0.7 iterations)
     p.mu_init = h->cfg.mu_init > 0 ? (float)h->cfg.mu_init : 0.1f;
-    p.mu_adapt = h->cfg.mu_init > 0 ? 0.f : 3.5f;
-    if (const char* e = std::getenv("CMPC_MU_ADAPT")) { if (p.mu_adapt > 0.f) p.mu_adapt = (float)std::atof(e); }   // developer knob
+    p.mu_adapt = h->cfg.mu_init > 0 ? 0.f : h->mu_adapt;
     p.t_floor = 1e-2f;
+    p.stall_window = h->stall_window;
     p.duals = h->dDuals; p.warm_duals = h->warm_duals;
 }
 
-int cmpc_solve_device(cmpc_handle h, const float* dP, const float* dX0, float* dX, float* dInfo, void* stream)
+static int solve_device_impl(cmpc_handle h, const float* dP, const float* dX0, float* dX, float* dInfo, void* stream, bool warm)
 {
     if (!h || !dP || !dX0 || !dX) return fail(h, CMPC_ERR_ARG, "cmpc_solve_device: null argument");
     HIPCHK(h, hipSetDevice(h->device));
@@ -286,10 +302,8 @@ int cmpc_solve_device(cmpc_handle h, const float* dP, const float* dX0, float* d
     CmpcParams p;
     fill_params(h, p);
     p.P = dP; p.X0 = dX0; p.X = dX; p.info = dInfo ? dInfo : h->dInfo;
-    if (std::getenv("CMPC_FORCE_WARM")) h->warm = true;   // developer knob
-    if (h->warm) {  // the initial guess was produced by cmpc_shift_solution_device: start near the central path
+    if (warm || h->force_warm) {  // dX0 is a previous solution shifted by one knot: start near the central path
         p.mu_init = (float)h->mu_warm; p.mu_adapt = 0.f; p.t_floor = (float)h->floor_warm; p.warm = 1;
-        h->warm = false;
     }
     HIPCHK(h, hipEventRecord(h->ev0, st));
     int rc = cmpc_launch_solver(&p, h->lds, st);
@@ -297,6 +311,16 @@ int cmpc_solve_device(cmpc_handle h, const float* dP, const float* dX0, float* d
     HIPCHK(h, hipEventRecord(h->ev1, st));
     h->timed = true;
     return CMPC_OK;
+}
+
+int cmpc_solve_device(cmpc_handle h, const float* dP, const float* dX0, float* dX, float* dInfo, void* stream)
+{
+    return solve_device_impl(h, dP, dX0, dX, dInfo, stream, false);
+}
+
+int cmpc_solve_device_warm(cmpc_handle h, const float* dP, const float* dX0, float* dX, float* dInfo, void* stream)
+{
+    return solve_device_impl(h, dP, dX0, dX, dInfo, stream, true);
 }
 
 namespace {
@@ -496,7 +520,6 @@ int cmpc_advance(cmpc_handle h)
         fill_params(h, p);
         p.P = h->dP; p.X0 = h->dX0; p.X = h->dX; p.info = h->dInfo;
         if (h->warm) { p.mu_init = (float)h->mu_warm; p.mu_adapt = 0.f; p.t_floor = (float)h->floor_warm; p.warm = 1; }
-        if (const char* e = std::getenv("CMPC_MU_WARM")) { if (h->warm) { p.mu_init = (float)std::atof(e); p.mu_adapt = 0.f; p.t_floor = std::min(1e-2f, p.mu_init); } }
         HIPCHK(h, hipEventRecord(h->ev0, h->stream));
         int lrc = cmpc_launch_solver(&p, h->lds, h->stream);
         if (lrc != 0) return fail(h, CMPC_ERR_HIP, std::string("solver launch: ") + hipGetErrorString((hipError_t)lrc));
@@ -677,7 +700,8 @@ int cmpc_contacts_adjust(int horizon, int batch, int max_contacts, double now, c
     for (int b = 0; b < batch; ++b)
         for (int c = 0; c < 2; ++c) {
             const size_t e = (size_t)b * 2 + c, o = e * max_contacts;
-            if (land[e] < 0) continue;
+            if (land[e] < 0 || land[e] > horizon) continue;
+            if (n[e] < 1 || n[e] > max_contacts) return fail(nullptr, CMPC_ERR_ARG, "cmpc_contacts_adjust: every foot needs 1..max_contacts contacts");
             const int nx = cmpc_next_contact(t + 2 * o, n[e], now);
             if (nx < 0) continue;
             for (int i = 0; i < 3; ++i) pose[7 * (o + nx) + i] = X[(size_t)b * L.nx() + L.oPos(c) + 3 * land[e] + i];
@@ -744,8 +768,7 @@ int cmpc_shift_solution_device(cmpc_handle h, const float* dXprev, float* dX0, v
     fill_params(h, p);
     int rc = cmpc_launch_warm_shift(&p, dXprev, dX0, stream ? (hipStream_t)stream : h->stream);
     if (rc != 0) return fail(h, CMPC_ERR_HIP, "warm-start shift launch failed");
-    h->warm = true;   // the next cmpc_solve_device starts the barrier at mu_warm
-    return CMPC_OK;
+    return CMPC_OK;   // (no state on the handle: the caller solves from dX0 with cmpc_solve_device_warm)
 }
 
 // the handle's own contact blocks from contact lists (what the class facade's setContactPhaseList calls)

@@ -15,8 +15,11 @@ __global__ __launch_bounds__(128) void cmpc_contacts_merge_kernel(int B, int M, 
     const int e = blockIdx.x * blockDim.x + threadIdx.x;   // problem * 2 + foot
     if (e >= 2 * B) return;
     const size_t o = (size_t)e * M;
-    const bool good = cmpc_merge_foot(now, plan_t + 2 * o, plan_pose + 7 * o, plan_n[e], mpc_t + 2 * o, mpc_pose + 7 * o, mpc_n[e], M,
-                                      out_t + 2 * o, out_pose + 7 * o, out_n + e);
+    // list lengths outside 0..M (the host entry point rejects them with CMPC_ERR_ARG): nothing is read, the merged list is empty, ok = 0
+    const bool sane = plan_n[e] >= 0 && plan_n[e] <= M && mpc_n[e] >= 0 && mpc_n[e] <= M;
+    if (!sane) out_n[e] = 0;
+    const bool good = sane && cmpc_merge_foot(now, plan_t + 2 * o, plan_pose + 7 * o, plan_n[e], mpc_t + 2 * o, mpc_pose + 7 * o, mpc_n[e], M,
+                                              out_t + 2 * o, out_pose + 7 * o, out_n + e);
     if (ok && !good) atomicAnd(ok + (e >> 1), 0);   // (ok[] starts at 1: cmpc_launch_contacts_merge fills it)
 }
 
@@ -36,6 +39,13 @@ __global__ __launch_bounds__(128) void cmpc_contacts_sample_kernel(int B, int N,
     const int b = e >> 1, c = e & 1;
     const CmpcIdx L{N};
     const size_t o = (size_t)e * M;
+    // An empty list (cmpc_merge_foot leaves one where the reference's updateContactPhaseList returns false, CentroidalMPCBlock.cpp:70-77,
+    // and the reference then aborts the tick, :603-607) or a length beyond M has no owner to sample: the foot's blocks of P are left
+    // as they are and the landing knot reads -2 (the host entry point returns CMPC_ERR_ARG for the same input).
+    if (n[e] < 1 || n[e] > M) {
+        if (land) land[e] = -2;
+        return;
+    }
     const int lk = cmpc_sample_foot(N, dt, now, c, t + 2 * o, pose + 7 * o, n[e], box, box + 6, P + (size_t)b * L.np());
     if (land) land[e] = lk;
 }
@@ -49,7 +59,7 @@ __global__ __launch_bounds__(128) void cmpc_contacts_adjust_kernel(int B, int N,
     if (e >= 2 * B) return;
     const int b = e >> 1, c = e & 1;
     const int lk = land[e];
-    if (lk < 0) return;
+    if (lk < 0 || lk > N || n[e] < 1 || n[e] > M) return;   // (no landing inside the horizon, or a list that was not sampled)
     const CmpcIdx L{N};
     const size_t o = (size_t)e * M;
     const int nx = cmpc_next_contact(t + 2 * o, n[e], now);

@@ -12,6 +12,7 @@
 #define CMPC_NMAX 40 // largest horizon the kernels are built for
 #define CMPC_TZ_LDS_NMAX 20  // HBM-factor variant: slacks / multipliers stay in LDS up to this horizon (three workgroups per CU still fit)
 #define CMPC_INFO_N 8
+#define CMPC_STALL_WINDOW_DEFAULT 0   // warm starts: progress watch off until tuned on the walking roll-out (see CmpcParams::stall_window)
 
 // x / p index layout of the reference's generated NLP (tmp.c:62-67)
 struct CmpcLayout {
@@ -52,6 +53,8 @@ __host__ __device__ inline void cmpc_layout_init(CmpcLayout& L, int N)
 // SGPRs, and ~100 of them would be spilled and re-read all through the sweeps)
 struct CmpcConsts {
     int N, max_iter, exact_hessian, final_extrap;
+    int tail_stages, tail_iters;  // tail polish: stages re-solved after convergence (0: off), Newton steps of the re-solve
+    float tail_trigger;          // ... when the extrapolation step of those stages exceeds this fraction of the largest force
     float dt, mu_fr, grav;
     float w_com0, w_com1, w_h, w_pos, w_sym;
     float D[3];                  // 2 * force_rate_of_change_weight
@@ -103,6 +106,7 @@ struct CmpcParams {
     float mu_init, t_floor;      // starting barrier parameter and slack floor of this solve (cold: 0.1 / 1e-2)
     float mu_adapt;              // > 0: mu_init is replaced per problem by clamp(mu_adapt * ep0^2, 0.03, 0.5)
     int warm;                    // the initial guess is a shifted previous solution: a problem that fails is restarted cold
+    int stall_window;            // warm starts: iterations max(primal residual, max t z) may go without halving before the cold restart (0: only at the budget)
     float* duals;                // [B][NS (N+1) + 2 NI N] costates | slacks | multipliers of the last solve (written at exit; read, shifted
     int warm_duals;              //  by one knot, at the start of a warm solve if warm_duals != 0); may be null
     float* scratch;              // per-problem factor storage when it does not fit in LDS, else null

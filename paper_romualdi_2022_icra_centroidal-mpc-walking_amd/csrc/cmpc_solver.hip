@@ -352,6 +352,12 @@ __device__ inline double dpp_d(double v)
     const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, true);
     return __hiloint2double(hi, lo);
 }
+// running maximum of |v| that a NaN turns into +inf (fmaxf alone drops a NaN operand: a non-finite residual or step would
+// read as zero and pass the termination test)
+__device__ inline float amax_nan(float m, float v) { return (v == v) ? fmaxf(m, fabsf(v)) : INFINITY; }
+// complementarity target of one row in the tail polish: mu_min for rows with multiplier >= 1 (z / t = z^2 / mu stays <= what the main
+// loop lives with), mu_min z^2 below -- rows whose multiplier vanishes are followed further down their path -- never below 1e-4 mu_min
+__device__ inline float row_target(float z, float mu_min) { return fmaxf(mu_min * fminf(1.f, z * z), 1e-4f * mu_min); }
 __device__ inline float wave_max(float v)
 {
     v = fmaxf(v, dpp_f<0xB1>(v));    // quad_perm [1,0,3,2]
@@ -805,7 +811,8 @@ __device__ inline void stage_desc_body(const Ctx& c, const CmpcConsts& prm, int 
                 const double t = c.T[NI * k + i], z = c.Z[NI * k + i];
                 const double rv = (double)row_val(c, prm, k, i, u);
                 sg = z / t;
-                gc = (double)cmu / t + sg * (rv + t);  // complementarity target cmu (0: affine-scaling predictor)
+                const float cm = cmu < 0.f ? row_target((float)z, -cmu) : cmu;   // (cmu < 0: per-row targets of the tail polish)
+                gc = (double)cm / t + sg * (rv + t);  // complementarity target cm (0: affine-scaling predictor)
             }
             c.sig[i] = sg; c.gco[i] = gc;
             if (i < 32) {
@@ -1236,8 +1243,9 @@ __device__ __attribute__((noinline)) void stage_post_pre(lds_t lds, int Nrt, flo
 
 // ---- Riccati backward sweep (matrices + right-hand side of the affine step, or of a centring step with target
 // cmu).  Returns (uniformly) 0 ok, 1 non-positive pivot. ----
+// k0 > 0: only stages N-1 .. k0 (the tail polish: the state entering stage k0 is held, so nothing before it is needed).
 template <int NT, int NC, bool FG>
-__device__ int riccati_backward(lds_t lds, const Ctx& c, const CmpcConsts& prm, int tid, float* fg_base, bool use_exact, float reg, float cmu)
+__device__ int riccati_backward(lds_t lds, const Ctx& c, const CmpcConsts& prm, int tid, float* fg_base, bool use_exact, float reg, float cmu, int k0 = 0)
 {
     const int N = c.N;
     for (int e = tid; e < NXA * PLD; e += NT) c.P0[e] = 0.f;
@@ -1261,9 +1269,9 @@ __device__ int riccati_backward(lds_t lds, const Ctx& c, const CmpcConsts& prm, 
     }
     // P0 holds the value function of stage k+1 and is overwritten in place by phase 4 (its last reader, Qss, ran in phase 3)
     stage_pre<NT, NC, FG>(lds, N, fg_base, N - 1, false, use_exact, reg, cmu, tpk);
-    for (int k = N - 1; k >= 0; --k) {
+    for (int k = N - 1; k >= k0; --k) {
         stage_mid<NT, NC, FG>(lds, N, fg_base, k, use_exact, cmu, tqp);
-        stage_post_pre<NT, NC, FG>(lds, N, fg_base, k, use_exact, reg, cmu, tpk, tqp);
+        if (k > k0 || k0 == 0) stage_post_pre<NT, NC, FG>(lds, N, fg_base, k, use_exact, reg, cmu, tpk, tqp);   // (the value function of stage k0 > 0 has no reader)
     }
     // (a non-positive pivot raises the flag and the stages after it run on garbage, harmlessly -- every array they write is
     // rebuilt by the retry; testing the flag once here instead of once per stage takes an LDS round trip out of every stage)
@@ -1276,8 +1284,9 @@ __device__ int riccati_backward(lds_t lds, const Ctx& c, const CmpcConsts& prm, 
 //             du = -L^{-T} y                                      (two lanes per column)
 //             ds+ = A ds + B du + d                               (9 + 6 lanes, corner sums by DPP)
 // Matrix operands do not depend on the recursion: they are read at the top of the stage. ----
+// k0 > 0 (tail polish): the sweep starts at stage k0 with ds_k0 = 0 and the force step before it zero.
 template <int NT, int UNR, bool G>
-__device__ void riccati_forward(const Ctx& c, const CmpcConsts& prm, int tid, bool affine)
+__device__ void riccati_forward(const Ctx& c, const CmpcConsts& prm, int tid, bool affine, int k0)
 {
     const int N = c.N;
     if (tid < 64) {
@@ -1313,12 +1322,12 @@ __device__ void riccati_forward(const Ctx& c, const CmpcConsts& prm, int tid, bo
         const bool isPos = j >= 9;
         const float Dm = prm.D[r % 3];
         if (tid < 40) xb[tid] = tid == 15 ? 1.f : 0.f;
-        if (tid < NS) c.dS[tid] = 0.f;
+        if (tid < NS) c.dS[NS * k0 + tid] = 0.f;
         wave_lds_sync();
         PROF2_DECL;
 #pragma unroll UNR   // (stages per trip: 4 in the resident variants -- a quarter of the address updates of the ~30 LDS operand
         // pointers, +3 % -- and 2 in the HBM-factor variants, whose records come through the descriptor: +1 %, 4 brings no more)
-        for (int k = 0; k < N; ++k) {
+        for (int k = k0; k < N; ++k) {
             const RecRef<G> rec(c.Lf, N, k);
             float ym[20];
             float4 um[4];
@@ -1382,7 +1391,7 @@ __device__ void riccati_forward(const Ctx& c, const CmpcConsts& prm, int tid, bo
         }
     }
     __syncthreads();
-    for (int e = tid; e < N * NI; e += NT) {
+    for (int e = tid + NI * k0; e < N * NI; e += NT) {
         const int k = e / NI, i = e % NI;
         float dt_ = 0.f, dz_ = 0.f;
         if (row_active(c, k, i)) {
@@ -1510,10 +1519,10 @@ __device__ void riccati_delta(const Ctx& c, const CmpcConsts& prm, int tid)
 
 // largest step lengths keeping t, z positive (fraction tau to the boundary)
 template <int NT>
-__device__ void step_lengths(const Ctx& c, int tid, float tau, float& ap, float& ad)
+__device__ void step_lengths(const Ctx& c, int tid, float tau, float& ap, float& ad, int k0 = 0)
 {
     float a_p = 1.f, a_d = 1.f;
-    for (int e = tid; e < c.N * NI; e += NT) {
+    for (int e = tid + NI * k0; e < c.N * NI; e += NT) {
         const float dt_ = c.dT[e], dz_ = c.dZ[e];
         if (dt_ < 0.f) a_p = fminf(a_p, -tau * c.T[e] / dt_);
         if (dz_ < 0.f) a_d = fminf(a_d, -tau * c.Z[e] / dz_);
@@ -1617,7 +1626,15 @@ __device__ __attribute__((noinline)) void phase_forward(lds_t lds, int Nrt, floa
 {
     CMPC_PHASE_PROLOGUE;
     const bool affine = __builtin_amdgcn_readfirstlane((int)affine_in) != 0;
-    riccati_forward<NT, NC == 0 ? 1 : (FG ? 2 : CMPC_SWEEP_UNROLL), FG>(c, prm, tid, affine);
+    riccati_forward<NT, NC == 0 ? 1 : (FG ? 2 : CMPC_SWEEP_UNROLL), FG>(c, prm, tid, affine, 0);
+}
+template <int NT, int NC, bool FG>
+__device__ __attribute__((noinline)) void phase_forward_tail(lds_t lds, int Nrt, float* fg_base, bool affine_in, int k0_in)
+{
+    CMPC_PHASE_PROLOGUE;
+    const bool affine = __builtin_amdgcn_readfirstlane((int)affine_in) != 0;
+    const int k0 = __builtin_amdgcn_readfirstlane(k0_in);
+    riccati_forward<NT, 1, FG>(c, prm, tid, affine, k0);
 }
 template <int NT, int NC, bool FG>
 __device__ __attribute__((noinline)) void phase_delta(lds_t lds, int Nrt, float* fg_base)
@@ -1632,6 +1649,54 @@ __device__ __attribute__((noinline)) void phase_costate(lds_t lds, int Nrt, floa
     const bool use_exact = __builtin_amdgcn_readfirstlane((int)exact_in) != 0;
     costate_update(c, prm, tid, ap, use_exact);
 }
+// ---- tail polish (out of line: rare, and the driver keeps its register allocation).  Stages k0 .. N-1 with the state entering stage
+// k0 and the force before it held form a small problem of their own.  Why: the final extrapolation is exact to first order where the
+// central path is smooth in mu; rows that are (nearly) degenerate -- slack and multiplier both -> 0: the friction rows of an unloaded
+// corner at the apex of its pyramid -- follow sqrt(mu) and the step covers half of their distance.  That matters in the last stages
+// only, whose forces the cost barely sees (no cost on the CoM velocity, nothing after them): bias sqrt(mu / curvature) = 3e-4 N/kg at
+// mu = 5e-8 (N = 30: all-knot force error 8e-5, CoM velocity 2.3e-4 against the oracle; 2.6e-5 elsewhere).  So, when the
+// extrapolation step of the tail is large (the symptom), the tail is re-solved: tail_iters Newton steps with per-row targets
+// (row_target: conditioning as in the main loop), then its own affine-scaling step.  Stated in oracle/ipm_ref.c:tail_polish.
+// Returns nothing: a factorisation that fails leaves the converged iterate of the pass before. ----
+template <int NT, int NC, bool FG>
+__device__ __attribute__((noinline)) void tail_polish(lds_t lds, int Nrt, float* fg_base, int k0_in)
+{
+    CMPC_PHASE_PROLOGUE;
+    const int k0 = __builtin_amdgcn_readfirstlane(k0_in);
+    for (int pi = 0; pi <= prm.tail_iters; ++pi) {
+        const bool last = pi == prm.tail_iters;
+        all_geo<NT>(c, prm, tid);
+        for (int e = tid + NS * k0; e < NS * N; e += NT) c.d[e] = (float)defect(c, prm, e / NS, e % NS);
+        __syncthreads();
+        const float cmu = last ? 0.f : -prm.mu_min;
+        int fail = riccati_backward<NT, NC, FG>(lds, c, prm, tid, fg_base, prm.exact_hessian != 0, prm.reg, cmu, k0);
+        if (fail) {
+            __syncthreads();
+            fail = riccati_backward<NT, NC, FG>(lds, c, prm, tid, fg_base, false, prm.reg, cmu, k0);
+        }
+        if (fail) break;
+        if (!last) {
+            for (int e = tid + NI * k0; e < NI * N; e += NT) c.dZ[e] = row_active(c, e / NI, e % NI) ? row_target(c.Z[e], prm.mu_min) : 0.f;
+            __syncthreads();
+        }
+        phase_forward_tail<NT, NC, FG>(lds, N, fg_base, last, k0);
+        float ap, ad;
+        step_lengths<NT>(c, tid, last ? 0.999f : 0.99f, ap, ad, k0);
+        // (a step that is not finite is not taken)
+        float bad = 0.f;
+        for (int e = tid + NU * k0; e < NU * N; e += NT) bad = amax_nan(bad, c.dU[e]);
+        for (int e = tid + NS * (k0 + 1); e < NS * (N + 1); e += NT) bad = amax_nan(bad, c.dS[e]);
+        float m1[1] = {bad};
+        block_maxn<NT, 1>(m1, c.red, tid);
+        if (!(m1[0] < INFINITY)) break;
+        for (int e = tid + NS * (k0 + 1); e < NS * (N + 1); e += NT) c.S[e] += ap * c.dS[e];
+        for (int e = tid + NU * k0; e < NU * N; e += NT) c.U[e] += ap * c.dU[e];
+        if (!last)
+            for (int e = tid + NI * k0; e < NI * N; e += NT) { c.T[e] += ap * c.dT[e]; c.Z[e] += ad * c.dZ[e]; }
+        __syncthreads();
+    }
+}
+
 // NC > 0: horizon known at compile time (every LDS offset becomes an immediate); NC == 0: runtime N
 // FG: the per-stage factors (Linv, Ws: 915 floats per stage) live in global scratch instead of LDS
 // (horizons whose LDS image would exceed 160 KiB)
@@ -1692,7 +1757,7 @@ __global__ __launch_bounds__(NT, FG ? 3 : 1) void cmpc_solve_kernel(CmpcParams k
     // Two passes at most: a warm-started solve (shifted previous solution) that exhausts its iteration budget is started
     // again from the cold start -- rare (a landing or lift-off tick, 1 in ~60000 solves of a walking roll-out) and cheaper than
     // failing the tick, which is all the caller could do (CentroidalMPCBlock.cpp:615-619 aborts).
-    int status = 1, gn = 0, it_total = 0;
+    int status = 1, gn = 0, nrc = 0, restarted = 0, polished = 0, it_total = 0;
     float err = 0.f, ep = 0.f, mu_cur = 0.f, step_out = 0.f, step_prev = 0.f;
     for (int pass = 0; pass < 2; ++pass) {
         const float mu_init = pass ? 0.1f : kp.mu_init, t_floor = pass ? 1e-2f : kp.t_floor, mu_adapt = pass ? 3.5f : kp.mu_adapt;
@@ -1760,6 +1825,10 @@ __global__ __launch_bounds__(NT, FG ? 3 : 1) void cmpc_solve_kernel(CmpcParams k
         int it = 0;
         status = 1;
         bool finishing = false;
+        // progress watch of a warm start (kp.stall_window > 0): phi = max(primal residual, max t z) must halve at least once every
+        // stall_window iterations, else the pass is abandoned for the cold start at once instead of after the whole budget
+        float phi_best = INFINITY;
+        int since = 0;
         for (it = 0; it < prm.max_iter + 1; ++it) {
             if (it == prm.max_iter && !finishing) break;
             // ---- residuals of the current iterate ----
@@ -1770,14 +1839,14 @@ __global__ __launch_bounds__(NT, FG ? 3 : 1) void cmpc_solve_kernel(CmpcParams k
             for (int e = tid; e < NS * N; e += NT) {
                 const double dv = defect(c, prm, e / NS, e % NS);
                 c.d[e] = (float)dv;
-                l_ep = fmaxf(l_ep, fabsf((float)dv));
+                l_ep = amax_nan(l_ep, (float)dv);
             }
             for (int e = tid; e < NI * N; e += NT) {
                 const int k = e / NI, i = e % NI;
                 if (row_active(c, k, i)) {
                     const float t = c.T[e], z = c.Z[e];
-                    l_ep = fmaxf(l_ep, fabsf(row_val(c, prm, k, i, c.U + NU * k) + t));
-                    l_ec = fmaxf(l_ec, t * z);
+                    l_ep = amax_nan(l_ep, row_val(c, prm, k, i, c.U + NU * k) + t);
+                    l_ec = amax_nan(l_ec, t * z);
                     l_mu += (double)t * z;
                 }
             }
@@ -1785,6 +1854,15 @@ __global__ __launch_bounds__(NT, FG ? 3 : 1) void cmpc_solve_kernel(CmpcParams k
             ep = l_ep;
             const float ec = l_ec;
             mu_cur = (float)(l_mu / (double)nrow);
+            // a residual that is not finite (NaN or inf in P or X0, or a step that went wrong): "invalid number" -- the reference's
+            // IPOPT stops there and advance() returns false.  (The maxima above turn NaN into +inf; plain fmaxf would drop it, the
+            // iterate would read as converged and NaN forces would go downstream with status 0.)
+            if (!(fmaxf(ep, ec) < INFINITY) || !(mu_cur == mu_cur)) { status = 2; err = INFINITY; break; }
+            if (kp.warm && pass == 0 && kp.stall_window > 0 && !finishing) {
+                const float phi = fmaxf(ep, ec);
+                if (phi < 0.5f * phi_best) { phi_best = phi; since = 0; }
+                else if (++since >= kp.stall_window) break;   // (status 1: the cold pass follows)
+            }
             if (it == 0 && mu_adapt > 0.f) {
                 // cold start: the initial barrier parameter scales with the squared initial infeasibility (z = mu / t)
                 const float mu0 = fminf(fmaxf(mu_adapt * ep * ep, 0.03f), 0.5f);
@@ -1811,7 +1889,7 @@ __global__ __launch_bounds__(NT, FG ? 3 : 1) void cmpc_solve_kernel(CmpcParams k
                         l2 += (double)t * z;
                     }
                 mu_cur = (float)(block_sum<NT>(l2, c.redd, tid) / (double)nrow);
-                ++gn;   // (counted with the Gauss-Newton fallbacks in info[3])
+                ++nrc;
             }
             PROF(10);
             // The step that produced this iterate was already below the step tolerance and its residuals are converged:
@@ -1860,10 +1938,33 @@ __global__ __launch_bounds__(NT, FG ? 3 : 1) void cmpc_solve_kernel(CmpcParams k
             if (finishing) {
                 // last step: affine-scaling extrapolation of the central path to mu = 0 (primal only)
                 step_lengths<NT>(c, tid, 0.999f, ap, ad);
-                for (int e = tid; e < NS * (N + 1); e += NT) c.S[e] += ap * c.dS[e];
-                for (int e = tid; e < NU * N; e += NT) c.U[e] += ap * c.dU[e];
-                __syncthreads();
+                // its size: over everything (NaN-aware: a step that is not finite is not taken -- the converged iterate stands) and
+                // over the forces of the last tail_stages stages, relative to the largest force
+                const int kt = N - prm.tail_stages;
+                float l_all = 0.f, l_tail = 0.f, l_fm = 1.f;
+                for (int e = tid; e < NS * (N + 1); e += NT) l_all = amax_nan(l_all, c.dS[e]);
+                for (int e = tid; e < NU * N; e += NT) {
+                    const float du = c.dU[e];
+                    l_all = amax_nan(l_all, du);
+                    if (e % NU < NF) {
+                        l_fm = fmaxf(l_fm, fabsf(c.U[e]));
+                        if (e >= NU * kt) l_tail = fmaxf(l_tail, fabsf(du));
+                    }
+                }
+                float m3[3] = {l_all, l_tail, l_fm};
+                block_maxn<NT, 3>(m3, c.red, tid);
                 ++it;
+                if (!(m3[0] < INFINITY)) break;
+                // a large extrapolation step in the tail: nearly degenerate rows there (see tail_polish) -- the step is applied up
+                // to the state entering stage k0 and the tail is re-solved from it
+                const int k0 = (prm.tail_stages > 0 && ap * m3[1] > prm.tail_trigger * m3[2]) ? kt : N;
+                for (int e = tid; e < NS * (k0 < N ? k0 + 1 : N + 1); e += NT) c.S[e] += ap * c.dS[e];
+                for (int e = tid; e < NU * k0; e += NT) c.U[e] += ap * c.dU[e];
+                __syncthreads();
+                if (k0 < N) {
+                    tail_polish<NT, NC, FG>(lds, N, fg_base, k0);
+                    polished = 1;
+                }
                 break;
             }
             step_lengths<NT>(c, tid, 1.f, ap, ad);
@@ -1909,17 +2010,17 @@ __global__ __launch_bounds__(NT, FG ? 3 : 1) void cmpc_solve_kernel(CmpcParams k
             // Force steps count relative to the largest corner-force component of the iterate (the parity tolerance is
             // relative; forces are ~1-3 N/kg here), states and landing offsets absolutely (metres, m/s: order one or less).
             float l_st = 0.f, l_sf = 0.f, l_fm = 1.f;
-            for (int e = tid; e < NS * (N + 1); e += NT) l_st = fmaxf(l_st, fabsf(c.dS[e]));
+            for (int e = tid; e < NS * (N + 1); e += NT) l_st = amax_nan(l_st, c.dS[e]);
             for (int e = tid; e < NU * N; e += NT) {
                 const int k = e / NU, m = e % NU;
                 const float du = c.dU[e];
                 if (m < NF) {
                     const float* f = c.dU + NU * k + 12 * (m / 12) + m % 3;
                     const float mean = 0.25f * (f[0] + f[3] + f[6] + f[9]);
-                    l_sf = fmaxf(l_sf, fabsf(du - gam_of(c, m / 12, k) * mean));
-                    if (k > 0) l_sf = fmaxf(l_sf, fabsf(du - c.dU[e - NU]));
+                    l_sf = amax_nan(l_sf, du - gam_of(c, m / 12, k) * mean);
+                    if (k > 0) l_sf = amax_nan(l_sf, du - c.dU[e - NU]);
                     l_fm = fmaxf(l_fm, fabsf(c.U[e]));
-                } else l_st = fmaxf(l_st, fabsf(du));
+                } else l_st = amax_nan(l_st, du);
             }
             float m3[3] = {l_st, l_sf, l_fm};
             block_maxn<NT, 3>(m3, c.red, tid);   // (the largest force is uniform: max(l_st, l_sf / fm) over threads = max(max l_st, max l_sf / fm))
@@ -1941,7 +2042,8 @@ __global__ __launch_bounds__(NT, FG ? 3 : 1) void cmpc_solve_kernel(CmpcParams k
             }
         }
         it_total += it;
-        if (status == 0 || !kp.warm) break;
+        if (status == 0 || !kp.warm || pass > 0) break;
+        restarted = 1;
         __syncthreads();
     }
     // ---- export x in the reference layout ----
@@ -1969,7 +2071,7 @@ __global__ __launch_bounds__(NT, FG ? 3 : 1) void cmpc_solve_kernel(CmpcParams k
         }
         if (kp.info && tid == 0) {
             float* inf = kp.info + (size_t)b * CMPC_INFO_N;
-            inf[0] = (float)it_total; inf[1] = err; inf[2] = mu_cur; inf[3] = (float)gn; inf[4] = ep; inf[5] = (float)status;
+            inf[0] = (float)it_total; inf[1] = err; inf[2] = mu_cur; inf[3] = (float)(gn + 100 * nrc + 10000 * restarted + 100000 * polished); inf[4] = ep; inf[5] = (float)status;
             inf[6] = (float)(__builtin_amdgcn_s_memtime() - t_start); inf[7] = step_out;
         }
         if (prm.dev[2] != 0.f) {  // developer probe: where the hardware put each wave (overwrites x[0..3]; HW_ID: wave slot

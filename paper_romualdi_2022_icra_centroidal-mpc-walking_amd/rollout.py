@@ -57,8 +57,10 @@ class WalkingRollout:
             com_speed = last / t_last if t_last > 0 else 0.0
         self.com_speed = com_speed
 
-    def run(self, ticks, com0, dcom0, h0, push=None, push_ticks=0, warm=True, dump=None):
-        """com0/dcom0/h0 [B,3] numpy; push [B,3] (mass-normalised force held for the first `push_ticks` ticks).
+    def run(self, ticks, com0, dcom0, h0, push=None, push_ticks=0, warm=True, dump=None, replan=None, slow=None):
+        """com0/dcom0/h0 [B,3] numpy; push [B,3] (mass-normalised force held for the first `push_ticks` ticks);
+        replan {tick: (t, pose, n)}: the planner's lists from that tick on (the reference's generator re-plans while walking);
+        slow (threshold, list): developer hook -- (tick, problem, P row, X0 row, info row) of every solve with more iterations.
         Returns a dict of per-tick numpy records."""
         torch, L, cfg, B, N = self.torch, self.L, self.cfg, self.B, self.cfg.N
         dt = cfg.sampling_time
@@ -78,11 +80,19 @@ class WalkingRollout:
         box_lo = np.array([c.bounding_box_lower_limit for c in cfg.contacts])
         for i in range(ticks):
             now = i * dt
+            if replan and i in replan:
+                self.plan = replan[i]
             if mpc_prev is None:
                 lists = tuple(a.clone() for a in self.plan)
                 ok = torch.ones((B,), dtype=torch.int32, device=dev)
             else:
                 lists, ok = s.contacts_merge_device(now, self.plan, mpc_prev)
+                if not bool(ok.all().item()):
+                    # the reference aborts the tick when updateContactPhaseList returns false (CentroidalMPCBlock.cpp:603-607): so does
+                    # the roll-out -- the merged lists of the failing problems are empty and must not be sampled or solved
+                    rec["merge_ok"].append(False)
+                    rec["aborted_tick"] = i
+                    break
             land = s.contacts_sample_device(now, lists, dP)
             # references at the knots (CentroidalMPCBlock.cpp:525-577 resamples the planner's; here a straight line)
             ref = dP[:, L.p_comref:L.p_comref + 3 * (N + 1)].view(B, N + 1, 3)
@@ -93,7 +103,8 @@ class WalkingRollout:
             if dpush is not None and i < push_ticks:
                 wrench[:, :max(push_ticks - i, 1), :3] = dpush[:, None, :]
             s.write_state_device(state, dP, wrench)
-            if mpc_prev is None or not warm:
+            shifted = not (mpc_prev is None or not warm)
+            if not shifted:
                 # cold start: CoM at com0, feet at nominal, f_z = g/8 per corner
                 dX0.zero_()
                 dX0[:, L.com:L.com + 3 * (N + 1)] = state[:, 0:3].repeat(1, N + 1)
@@ -105,12 +116,15 @@ class WalkingRollout:
                 s.shift_solution_device(dX, dX0)
             if dump is not None and i == dump[0]:   # developer hook: (tick, path) -> the tick's P and X0
                 np.savez(dump[1], P=dP.cpu().numpy(), X0=dX0.cpu().numpy())
-            s.solve_device(dP, dX0, dX, dInfo)
+            s.solve_device(dP, dX0, dX, dInfo, warm=shifted)
             s.contacts_adjust_device(now, dX, land, lists)
             mpc_prev = lists
             state, zmp = s.plant_step_device(dX, dP, state, step=dt / self.substeps, substeps=self.substeps)
             torch.cuda.synchronize()
             info = dInfo.cpu().numpy()
+            if slow is not None:
+                for b in np.where(info[:, 0] > slow[0])[0]:
+                    slow[1].append((i, int(b), dP[b].cpu().numpy(), dX0[b].cpu().numpy(), info[b].copy()))
             rec["iterations_mean"].append(float(info[:, 0].mean()))
             rec["iterations_max"].append(int(info[:, 0].max()))
             rec["converged"].append(bool((info[:, 5] == 0).all()))

@@ -21,7 +21,8 @@ from .layout import Layout
 
 
 def _c_config(cfg: CentroidalMPCConfig, tolerance=None, mu_min=None, max_iterations=None,
-              exact_hessian=True, final_extrapolation=True, step_tolerance=None, mu_init=None) -> _capi.CmpcConfig:
+              exact_hessian=True, final_extrapolation=True, step_tolerance=None, mu_init=None,
+              tail_stages=3, tail_iterations=2, tail_trigger=2e-5) -> _capi.CmpcConfig:
     c = _capi.CmpcConfig()
     c.horizon = cfg.N
     c.sampling_time = cfg.sampling_time
@@ -42,6 +43,8 @@ def _c_config(cfg: CentroidalMPCConfig, tolerance=None, mu_min=None, max_iterati
     c.mu_min = mu_min if mu_min is not None else 0.05 * c.tolerance
     c.exact_hessian = int(exact_hessian)
     c.final_extrapolation = int(final_extrapolation)
+    # tail polish (include/cmpc.h): the last stages re-solved when their extrapolation step is large
+    c.tail_stages, c.tail_iterations, c.tail_trigger = int(tail_stages), int(tail_iterations), float(tail_trigger)
     return c
 
 
@@ -73,9 +76,10 @@ class BatchSolver:
     def last_error(self) -> str:
         return self._lib.cmpc_last_error(self._h).decode()
 
-    def solve_device(self, dP, dX0, dX=None, dInfo=None, stream=None):
+    def solve_device(self, dP, dX0, dX=None, dInfo=None, stream=None, warm=False):
         """torch CUDA tensors float32: P[B,np], X0[B,nx] -> X[B,nx], info[B,8].  Launches on
-        torch's current stream unless `stream` (a raw hipStream_t) is given; asynchronous."""
+        torch's current stream unless `stream` (a raw hipStream_t) is given; asynchronous.
+        warm: dX0 is the previous solution shifted by one knot (shift_solution_device) -> cmpc_solve_device_warm."""
         import torch
         L = self.layout
         assert dP.is_cuda and dP.dtype == torch.float32 and dP.is_contiguous() and tuple(dP.shape) == (self.batch, L.np)
@@ -94,7 +98,8 @@ class BatchSolver:
             stream = self._stream.cuda_stream
         else:
             cur = None
-        rc = self._lib.cmpc_solve_device(self._h, dP.data_ptr(), dX0.data_ptr(), dX.data_ptr(), dInfo.data_ptr(), stream)
+        fn = self._lib.cmpc_solve_device_warm if warm else self._lib.cmpc_solve_device
+        rc = fn(self._h, dP.data_ptr(), dX0.data_ptr(), dX.data_ptr(), dInfo.data_ptr(), stream)
         if rc != 0:
             raise RuntimeError(f"cmpc_solve_device failed ({rc}): {self.last_error}")
         if cur is not None:
@@ -219,7 +224,7 @@ class BatchSolver:
             self._h, dState.data_ptr(), dWrench.data_ptr() if dWrench is not None else None, dP.data_ptr(), st))
 
     def shift_solution_device(self, dXprev, dX0):
-        """is_warm_start_enabled: dX0 = dXprev shifted by one knot; the next solve_device starts near the central path."""
+        """is_warm_start_enabled: dX0 = dXprev shifted by one knot; solve from it with solve_device(..., warm=True)."""
         self._launch(dX0.device, lambda st: self._lib.cmpc_shift_solution_device(self._h, dXprev.data_ptr(), dX0.data_ptr(), st))
 
 

@@ -57,15 +57,11 @@ TOL = 1e-4   # north_star: relative error on the CoM trajectory and the contact 
 
 
 def limits(N):
-    """Tolerance per quantity.  What the controller consumes -- the CoM trajectory, the first-knot forces, the foot
-    positions -- and, for horizons up to 20, every other quantity too: 1e-4.  Beyond N = 20 (config 5, N = 30) the
-    forces of the far horizon and the CoM velocity of the last knots get 2e-4 / 5e-4: an unloaded corner at the end of the
-    horizon (optimal force ~1e-6, all four friction rows active with zero multipliers: the apex of the pyramid) sits
-    sqrt(mu / curvature) inside the cone at the barrier floor mu = 5e-8 -- 3e-4 N/kg, whatever the arithmetic: the float64
-    oracle run at the same floor shows forces 8.4e-5 / dcom 2.5e-4 on those problems (gpurun_out -> profiles/
-    r02_accuracy_sweep.txt); float32 storage forbids a lower floor (slacks fall below one ulp of the row values)."""
-    far = 1.0 if N <= 20 else 2.0
-    return dict(com=TOL, force0=TOL, pos=TOL, forces=far * TOL, dcom=TOL if N <= 20 else 5 * TOL)
+    """Tolerance per quantity: north_star's 1e-4 on everything at every knot, at every horizon.  (Round 2 allowed 2e-4 on the
+    far-horizon forces and 5e-4 on the CoM velocity beyond N = 20: unloaded corners of the LAST stages sit sqrt(mu / curvature)
+    inside their friction pyramid at the barrier floor.  The tail polish -- cmpc_config.tail_stages -- removes that bias:
+    measured margins in profiles/r03_accuracy_sweep.txt.)"""
+    return dict(com=TOL, force0=TOL, pos=TOL, forces=TOL, dcom=TOL)
 
 
 def worst_errors(N, P, X, Xref):

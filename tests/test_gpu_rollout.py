@@ -17,53 +17,89 @@ def _ptr(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
-def test_device_contact_kernels_match_the_host_entry_points():
+def test_device_contact_kernels_match_the_oracles():
+    """All three device kernels of row 8f-1 / 8a-4 against NON-product code: the merge against oracle/contacts_ref.py (the
+    restatement of the reference's updateContactPhaseList, incl. its `return false`), the sampling and the step adjustment
+    against oracle/schedule_ref.py (integer-nanosecond restatement of the rule) -- Gamma, landing knots, list lengths and
+    times bit-exact, positions exact, R to 3e-7.  The host entry points of the C ABI are then held to the device results
+    (bit-exact: both run the same __host__ __device__ functions)."""
     import torch
+    from tests.test_contacts_cpu import (assert_adjust_matches_schedule_oracle, assert_merge_matches_contacts_oracle,
+                                         assert_sample_matches_schedule_oracle)
     cfg = cm.config.ergocub_gazebo_v1(20, 0.06)
     L = cm.Layout(cfg.N)
     B = 96
     lists = _random_walks(cfg, B, 17)
+    lists[1] = cm.rollout.walking_plan(cfg)       # every time a multiple of dT: knots fall exactly on activations
     plan = pack_lists(cfg, lists, max_contacts=12)
     mpc = (plan[0].copy(), plan[1].copy(), plan[2].copy())
     mpc[1][..., :3] += np.random.default_rng(2).uniform(-0.01, 0.01, mpc[1][..., :3].shape).astype(np.float32)
     plan[0][5] += 50.0       # one problem where the reference's function returns false (a stance foot the planner does not know)
     s = cm.BatchSolver(cfg, B)
     dev = lambda t: tuple(torch.from_numpy(a).cuda() for a in t)
+    host = lambda t: tuple(a.cpu().numpy() for a in t)
     now = 0.06 * 9
-    (ot, op, on), ok = update_contact_phase_list(now, plan, mpc)
-    (dt_, dp_, dn_), dok = s.contacts_merge_device(now, dev(plan), dev(mpc))
+    out_d, dok = s.contacts_merge_device(now, dev(plan), dev(mpc))
     torch.cuda.synchronize()
-    np.testing.assert_array_equal(dok.cpu().numpy().astype(bool), ok)
-    assert not ok[5] and ok.sum() == B - 1
+    (dt_, dp_, dn_), ok_d = host(out_d), dok.cpu().numpy()
+    assert_merge_matches_contacts_oracle(cfg, now, plan, mpc, (dt_, dp_, dn_), ok_d)
+    assert not ok_d[5] and ok_d.sum() == B - 1 and dn_[5].min() == 0
+    (ot, op, on), ok = update_contact_phase_list(now, plan, mpc)            # host C entry point == device kernel
+    np.testing.assert_array_equal(ok_d.astype(bool), ok)
     good = np.where(ok)[0]
-    np.testing.assert_array_equal(dn_.cpu().numpy()[good], on[good])
+    np.testing.assert_array_equal(dn_[good], on[good])
     for b in good:
         for c in range(2):
             m = on[b, c]
-            np.testing.assert_array_equal(dt_.cpu().numpy()[b, c, :m], ot[b, c, :m])
-            np.testing.assert_array_equal(dp_.cpu().numpy()[b, c, :m], op[b, c, :m])
-    # sampling: device kernel == numpy mirror == C host function
-    lists_ok = (ot[good[:64]], op[good[:64]], on[good[:64]])
-    s2 = cm.BatchSolver(cfg, 64)
-    dP = torch.full((64, L.np), 3.0, dtype=torch.float32, device="cuda")
-    land = s2.contacts_sample_device(now, dev(lists_ok), dP)
+            np.testing.assert_array_equal(dt_[b, c, :m], ot[b, c, :m])
+            np.testing.assert_array_equal(dp_[b, c, :m], op[b, c, :m])
+    # sampling of the merged lists, the failed problem (an empty list) included: it must be left alone and flagged
+    dP = torch.full((B, L.np), 3.0, dtype=torch.float32, device="cuda")
+    land = s.contacts_sample_device(now, out_d, dP)
     torch.cuda.synchronize()
-    ref, rland = sample_schedule_batch(cfg, *lists_ok, now)
-    z = np.zeros((64, 3))
-    Pref = cm.pack_parameters(cfg.N, ref["R"], ref["upper"], ref["lower"], ref["enabled"], ref["nominal"], ref["current"], z, z, z,
-                              np.zeros((64, cfg.N + 1, 3)), np.zeros((64, cfg.N + 1, 3)), dtype=np.float32)
-    np.testing.assert_array_equal(land.cpu().numpy(), rland)
-    np.testing.assert_allclose(dP.cpu().numpy()[:, :L.p_com0], Pref[:, :L.p_com0], atol=1e-7)
-    assert (dP.cpu().numpy()[:, L.p_com0:] == 3.0).all()
+    Ph, lh = dP.cpu().numpy(), land.cpu().numpy()
+    assert_sample_matches_schedule_oracle(cfg, dt_, dp_, dn_, now, Ph, lh, rows=good)
+    assert (Ph[good][:, L.p_com0:] == 3.0).all()                         # state, reference and wrench rows are not the sampler's
+    empty = [c for c in range(2) if dn_[5, c] == 0]
+    assert empty and all(lh[5, c] == -2 for c in empty)
+    for c in empty:
+        assert (Ph[5, L.p_R[c]:L.p_cur[c] + 3] == 3.0).all()
+    ref, rland = sample_schedule_batch(cfg, dt_[good], dp_[good], dn_[good], now)    # (and the numpy mirror agrees)
+    np.testing.assert_array_equal(lh[good], rland)
     # step adjustment
-    X = np.random.default_rng(0).normal(size=(64, L.nx)).astype(np.float32)
-    dl = dev(lists_ok)
-    s2.contacts_adjust_device(now, torch.from_numpy(X).cuda(), land, dl)
+    X = np.random.default_rng(0).normal(size=(B, L.nx)).astype(np.float32)
+    before = dp_.copy()
+    s.contacts_adjust_device(now, torch.from_numpy(X).cuda(), land, out_d)
     torch.cuda.synchronize()
-    hp = lists_ok[1].copy()
-    assert s2._lib.cmpc_contacts_adjust(cfg.N, 64, 12, now, _ptr(X), _ptr(rland), _ptr(lists_ok[0]), _ptr(hp), _ptr(lists_ok[2])) == 0
-    np.testing.assert_array_equal(dl[1].cpu().numpy(), hp)
-    assert np.abs(hp - lists_ok[1]).max() > 0
+    after = out_d[1].cpu().numpy()
+    assert_adjust_matches_schedule_oracle(cfg, dt_, before, after, dn_, now, X, lh, rows=good)
+    for c in empty:
+        np.testing.assert_array_equal(after[5, c], before[5, c])          # a foot without a list is not touched
+    hp = before[good].copy()
+    assert s._lib.cmpc_contacts_adjust(cfg.N, len(good), 12, now, _ptr(np.ascontiguousarray(X[good])), _ptr(np.ascontiguousarray(lh[good])),
+                                       _ptr(np.ascontiguousarray(dt_[good])), _ptr(hp), _ptr(np.ascontiguousarray(dn_[good]))) == 0
+    np.testing.assert_array_equal(after[good], hp)
+    assert np.abs(after - before).max() > 0
+    # list lengths outside 0..M never reach the lists: empty result, ok = 0
+    bad_n = plan[2].copy(); bad_n[7, 0] = 13; bad_n[8, 1] = -1
+    out_b, okb = s.contacts_merge_device(now, (dev(plan)[0], dev(plan)[1], torch.from_numpy(bad_n).cuda()), dev(mpc))
+    torch.cuda.synchronize()
+    okb, nb = okb.cpu().numpy(), out_b[2].cpu().numpy()
+    assert okb[7] == 0 and okb[8] == 0 and nb[7, 0] == 0 and nb[8, 1] == 0 and okb.sum() == B - 3
+
+
+def test_rollout_aborts_the_tick_like_the_reference_when_the_merge_fails():
+    """updateContactPhaseList returning false makes the reference abort the tick (CentroidalMPCBlock.cpp:603-607); the
+    roll-out stops there too instead of sampling an empty list."""
+    import torch
+    cfg = cm.config.ergocub_gazebo_v1(20, 0.06)
+    B = 8
+    ro = cm.rollout.WalkingRollout(cfg, B)
+    t = ro.plan[0].clone()
+    t[3, 0] += 100.0          # from tick 2 on the planner of problem 3 no longer knows the left foot's current contact
+    com0 = np.tile([0.0, 0.0, 0.7], (B, 1)); z = np.zeros((B, 3))
+    rec = ro.run(5, com0, z, z, replan={2: (t, ro.plan[1], ro.plan[2])})
+    assert rec.get("aborted_tick") == 2 and rec["merge_ok"] == [True, True, False] and len(rec["converged"]) == 2
 
 
 def test_walking_rollout_stays_in_hbm_and_on_its_feet():

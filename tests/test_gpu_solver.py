@@ -367,3 +367,109 @@ def test_hbm_factor_and_resident_variants_agree(N, monkeypatch):
     for b in range(32):
         e = parity.errors(cfg.N, P32[b], out["hbm"][0][b], out["lds"][0][b])
         assert e["com"] < 2e-5 and e["forces"] < 5e-5 and e["pos"] < 2e-5, (b, e)
+
+
+@pytest.mark.parametrize("B", [5, 1024])
+@pytest.mark.parametrize("where", ["com_ref", "f_ext", "x0"])
+def test_a_single_nan_is_reported_not_returned_as_converged(B, where):
+    """A NaN that reaches only the right-hand side (one entry of the CoM reference, of the external force, or of the
+    initial guess) leaves the first factorisation intact: every step becomes NaN, and a termination test built on fmaxf
+    would read the residuals as zero.  The reference's IPOPT stops with 'invalid number' and advance() returns false
+    (CentroidalMPCBlock.cpp:615-619): status != 0, rc = CMPC_ERR_NOT_CONVERGED, the neighbours untouched."""
+    cfg, P, X0 = cm.synthetic.config3_external_push(B, seed=23)
+    L = cm.Layout(cfg.N)
+    P32, X032 = P.astype(np.float32), X0.astype(np.float32)
+    s = cm.BatchSolver(cfg, B)
+    X1, info1, rc1 = s.solve_host(P32, X032)
+    assert rc1 == 0
+    bad = B // 3
+    Pb, Xb = P32.copy(), X032.copy()
+    if where == "com_ref":
+        Pb[bad, L.p_comref + 3 * 7 + 1] = np.nan
+    elif where == "f_ext":
+        Pb[bad, L.p_fext + 3 * 2] = np.nan
+    else:
+        Xb[bad, L.f[1][2] + 3 * 5 + 2] = np.nan
+    X2, info2, rc2 = s.solve_host(Pb, Xb)
+    assert rc2 == -3
+    assert info2[bad, 5] != 0, info2[bad]
+    assert info2[bad, 0] <= 3                      # stopped at once, not after the iteration budget
+    keep = np.arange(B) != bad
+    assert (info2[keep, 5] == 0).all()
+    np.testing.assert_array_equal(X1[keep], X2[keep])
+
+
+def test_full_size_properties_config5():
+    """BASELINE config 5 at its full size (B = 8192, N = 30; 1.16 GB of factor scratch): every problem converges and satisfies
+    the NLP's constraints, the solve is invariant under a permutation of the batch, and 64 sampled problems match the float64
+    oracle at north_star's tolerance on every quantity at every knot (mirrors test_config4_shard_of_8192)."""
+    from oracle import oracle_lib as ol, problem_nlp
+    B = 8192
+    cfg, P, X0 = cm.synthetic.config5_footstep_candidates(B)
+    assert cfg.N == 30
+    P32, X032 = P.astype(np.float32), X0.astype(np.float32)
+    s = cm.BatchSolver(cfg, B)
+    X, info, rc = s.solve_host(P32, X032)
+    assert rc == 0 and (info[:, 5] == 0).all(), s.last_error
+    perm = np.random.default_rng(6).permutation(B)
+    Xp, _, _ = s.solve_host(P32[perm], X032[perm])
+    np.testing.assert_array_equal(Xp, X[perm])
+    oc = problem_nlp.oracle_cfg(cfg)
+    N = cfg.N
+    sample = np.arange(0, B, 128)
+    for b in sample:
+        _, g = ol.nlp_fg(oc, X[b].astype(np.float64), P32[b].astype(np.float64))
+        lb, ub = problem_nlp.bounds(cfg, P32[b].astype(np.float64))
+        assert np.abs(g[15:15 + 15 * N]).max() < 2e-6
+        assert (g <= ub + 2e-6).all() and (g >= lb - 2e-6).all()
+    worst = _worst(cfg, P32[sample], X[sample], _oracle(cfg, P32[sample], X032[sample]))
+    parity.assert_within(cfg.N, worst)
+    # the tail polish ran where the extrapolation step of the last stages was large, and only there
+    polished = info[:, 3] >= 100000
+    assert 0 < polished.sum() < B
+    s.close()
+
+
+def test_failed_scratch_allocation_is_an_error_not_a_crash():
+    """cmpc_create with a batch whose factor scratch cannot be allocated (N = 30: 141 KB per problem; 3 000 000 problems = 423 GB
+    against 288 GB of HBM) returns CMPC_ERR_HIP with the handle released (csrc/cmpc_api.hip: HIPCHK_CREATE -> cmpc_destroy), and
+    the library keeps working."""
+    import ctypes as C
+    cfg = cm.config.ergocub_gazebo_v1(30, 0.06)
+    lib = cm._capi.lib()
+    ccfg = cm.solver._c_config(cfg)
+    h = C.c_void_p()
+    rc = lib.cmpc_create(C.byref(ccfg), 3_000_000, 0, C.byref(h))
+    assert rc == -2 and not h.value, rc
+    assert b"hipMalloc" in lib.cmpc_last_error(None)
+    _, P, X0 = cm.synthetic.config5_footstep_candidates(8)
+    s = cm.BatchSolver(cfg, 8)
+    X, info, rc = s.solve_host(P.astype(np.float32), X0.astype(np.float32))
+    assert rc == 0 and (info[:, 5] == 0).all()
+
+
+def test_tail_polish_only_moves_the_tail(monkeypatch):
+    """cmpc_config.tail_stages: the stages before the tail are bit-identical with and without the polish (it holds the state
+    entering the tail), and where it ran the last knots move towards the oracle."""
+    B = 256
+    cfg, P, X0 = cm.synthetic.config5_footstep_candidates(B, seed=77)
+    N, L = cfg.N, cm.Layout(cfg.N)
+    P32, X032 = P.astype(np.float32), X0.astype(np.float32)
+    s0 = cm.BatchSolver(cfg, B, tail_stages=0)
+    Xa, infa, rc = s0.solve_host(P32, X032)
+    assert rc == 0
+    s1 = cm.BatchSolver(cfg, B)
+    Xb, infb, rc = s1.solve_host(P32, X032)
+    assert rc == 0
+    polished = infb[:, 3] >= 100000
+    assert polished.any() and (infa[:, 3] < 100000).all()
+    np.testing.assert_array_equal(infa[:, 0], infb[:, 0])                # the polish is not counted as an iteration
+    np.testing.assert_array_equal(Xa[~polished], Xb[~polished])
+    k0 = N - 3
+    for c in range(2):
+        for j in range(4):
+            np.testing.assert_array_equal(L.x_force(Xa, c, j)[:, :k0], L.x_force(Xb, c, j)[:, :k0])
+    np.testing.assert_array_equal(L.x_com(Xa)[:, :k0 + 1], L.x_com(Xb)[:, :k0 + 1])
+    Xr = _oracle(cfg, P32[polished], X032[polished])
+    wa, wb = _worst(cfg, P32[polished], Xa[polished], Xr), _worst(cfg, P32[polished], Xb[polished], Xr)
+    assert wb["forces"] < wa["forces"] and wb["dcom"] < wa["dcom"], (wa, wb)
