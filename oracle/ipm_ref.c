@@ -739,12 +739,14 @@ static void export_x(const ws* w, PREAL* x)
 }
 
 /* ---------------- driver ---------------- */
-static void step_lengths(const ws* w, REAL tau, int k0, REAL* ap_out, REAL* ad_out)
+static void step_lengths_range(const ws* w, REAL tau, int k0, int k1, REAL* ap_out, REAL* ad_out);
+static void step_lengths(const ws* w, REAL tau, int k0, REAL* ap_out, REAL* ad_out) { step_lengths_range(w, tau, k0, w->N, ap_out, ad_out); }
+/* rows of stages k0 .. k1-1 */
+static void step_lengths_range(const ws* w, REAL tau, int k0, int k1, REAL* ap_out, REAL* ad_out)
 {
-    const int N = w->N;
     REAL ap = 1, ad = 1;
     int k, i;
-    for (k = k0; k < N; ++k)
+    for (k = k0; k < k1; ++k)
         for (i = 0; i < NI; ++i) {
             if (!row_active(w, k, i)) continue;
             if (w->dT[k][i] < 0) { REAL a = -tau * w->T[k][i] / w->dT[k][i]; if (a < ap) ap = a; }
@@ -761,11 +763,13 @@ static void step_lengths(const ws* w, REAL tau, int k0, REAL* ap_out, REAL* ad_o
 static void tail_polish(ws* w, const cmpc_ipm_opts* opt, int k0)
 {
     const int N = w->N;
-    int pi, k, i;
-    for (pi = 0; pi <= opt->tail_iters; ++pi) {
-        const int last = (pi == opt->tail_iters);
+    int pi, k, i, last = 0, blocked = 1;
+    /* tail_iters Newton steps at least; while a step was blocked (a row on its way to becoming active: the multipliers need their
+     * iterations) up to six more, then the affine-scaling step */
+    for (pi = 0; pi <= opt->tail_iters + 6 && !last; ++pi) {
         REAL ap, ad;
         int fail;
+        last = (pi >= opt->tail_iters + 6) || (pi >= opt->tail_iters && !blocked);
         linearise(w);
         for (k = k0; k < N; ++k)
             for (i = 0; i < NI; ++i) {
@@ -778,6 +782,7 @@ static void tail_polish(ws* w, const cmpc_ipm_opts* opt, int k0)
         if (fail) return;
         riccati_forward(w, k0);
         step_lengths(w, last ? (REAL)0.999 : (REAL)0.99, k0, &ap, &ad);
+        blocked = ap < (REAL)0.9 || ad < (REAL)0.9;
         for (k = k0 + 1; k <= N; ++k) for (i = 0; i < NS; ++i) w->S[k][i] += ap * w->dS[k][i];
         for (k = k0; k < N; ++k) {
             for (i = 0; i < NU; ++i) w->U[k][i] += ap * w->dU[k][i];
@@ -836,8 +841,10 @@ int FN(cmpc_ref_solve_one)(const cmpc_nlp_cfg* cfg, const cmpc_ipm_opts* opt, co
                         k0 = N - opt->tail_stages;
                         for (k = 0; k < N; ++k) for (i = 0; i < NF; ++i) { REAL a = (REAL)fabs((double)w->U[k][i]); if (a > fm) fm = a; }
                         for (k = k0; k < N; ++k) for (i = 0; i < NF; ++i) { REAL a = (REAL)fabs((double)w->dU[k][i]); if (a > tail) tail = a; }
-                        trig = ap * tail > (REAL)opt->tail_trigger * fm;
+                        trig = tail > (REAL)opt->tail_trigger * fm;   /* (the full step: a nearly degenerate row is what blocks ap) */
                         if (!trig) k0 = N;
+                        /* the tail goes its own way: the step of the stages before it is limited by their own rows only */
+                        else step_lengths_range(w, (REAL)0.999, 0, k0, &ap, &ad);
                     }
                     for (k = 0; k <= (trig ? k0 : N); ++k) for (i = 0; i < NS; ++i) w->S[k][i] += ap * w->dS[k][i];
                     for (k = 0; k < (trig ? k0 : N); ++k) for (i = 0; i < NU; ++i) w->U[k][i] += ap * w->dU[k][i];

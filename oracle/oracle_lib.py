@@ -153,7 +153,7 @@ def nlp_grad(cfg, x, p, lam_f, lam_g):
     return gx, gp
 
 
-def ipm_opts(max_iter=60, tol=1e-9, mu_init=0.1, mu_min=1e-10, exact_hessian=1, verbose=0, tail_stages=0, tail_iters=3, tail_trigger=1e-5):
+def ipm_opts(max_iter=60, tol=1e-9, mu_init=0.1, mu_min=1e-10, exact_hessian=1, verbose=0, tail_stages=0, tail_iters=2, tail_trigger=2e-5):
     o = IpmOpts()
     o.max_iter, o.tol, o.mu_init, o.mu_min, o.exact_hessian, o.verbose = max_iter, tol, mu_init, mu_min, exact_hessian, verbose
     o.tail_stages, o.tail_iters, o.tail_trigger = tail_stages, tail_iters, tail_trigger

@@ -44,7 +44,7 @@ EXPORTS = [
     "cmpc_get_output", "cmpc_set_reference_from_planner", "cmpc_plant_step_device", "cmpc_test_poison_lds",
     "cmpc_compact_output_device", "cmpc_contacts_merge", "cmpc_contacts_merge_device", "cmpc_contacts_sample",
     "cmpc_contacts_sample_device", "cmpc_set_contact_lists", "cmpc_contacts_adjust", "cmpc_contacts_adjust_device",
-    "cmpc_write_state_device", "cmpc_shift_solution_device", "cmpc_eval_nlp_grad_device", "cmpc_solve_device_warm",
+    "cmpc_write_state_device", "cmpc_shift_solution_device", "cmpc_eval_nlp_grad_device", "cmpc_solve_device_warm", "cmpc_set_warm_policy",
 ]
 
 _lib = None
@@ -76,9 +76,12 @@ def lib():
         L.cmpc_stream.argtypes = [vp]
         L.cmpc_stream.restype = vp
         L.cmpc_solve_device.argtypes = [vp, fp, fp, fp, fp, vp]
-        L.cmpc_solve_device_warm.argtypes = [vp, fp, fp, fp, fp, vp]
+        if hasattr(L, "cmpc_solve_device_warm"):   # (absent from round-2 builds of the library, which tools/ab_bench.sh may load as the baseline)
+            L.cmpc_solve_device_warm.argtypes = [vp, fp, fp, fp, fp, vp]
         L.cmpc_solve.argtypes = [vp, fp, fp, fp, fp]
         L.cmpc_last_solve_ms.argtypes = [vp]
+        if hasattr(L, "cmpc_set_warm_policy"):
+            L.cmpc_set_warm_policy.argtypes = [vp, C.c_int, C.c_int]
         L.cmpc_test_poison_lds.argtypes = [vp]
         L.cmpc_compact_output_device.argtypes = [vp, fp, fp, fp, vp]
         L.cmpc_last_solve_ms.restype = C.c_float

@@ -55,7 +55,7 @@ struct cmpc_handle_s {
     bool have_solution = false, x0_set = false;
     bool warm = false;           // class path only (cmpc_set_initial_guess(.., 1) -> cmpc_advance): the handle's own dX0 is a shifted previous solution
     double mu_warm = 1e-2, floor_warm = 1e-2;  // measured: 1e-2 saves 35 % (standing) / 15 % (walking) of the iterations; 1e-4 can stall
-    int stall_window = 0;        // warm starts: see CmpcParams::stall_window
+    int warm_budget = 0, warm_no_restart = 0;   // cmpc_set_warm_policy (CmpcParams)
     bool force_warm = false;     // developer knob CMPC_FORCE_WARM (read once, at cmpc_create)
     float mu_adapt = 3.5f;       // cold starts: mu0 = clamp(mu_adapt ep0^2, 0.03, 0.5) (developer knob CMPC_MU_ADAPT, read once)
     size_t lds = 0;
@@ -151,8 +151,6 @@ int cmpc_create(const cmpc_config* cfg, int batch, int device, cmpc_handle* out)
     if (const char* e = std::getenv("CMPC_WARM_DUALS")) h->warm_duals = std::atoi(e);   // developer knob
     if (const char* e = std::getenv("CMPC_MU_WARM")) { h->mu_warm = std::atof(e); h->floor_warm = std::min(1e-2, h->mu_warm); }   // developer knob
     // (every developer knob is read here, once: no getenv on the solve path)
-    h->stall_window = CMPC_STALL_WINDOW_DEFAULT;
-    if (const char* e = std::getenv("CMPC_STALL")) h->stall_window = std::atoi(e);
     h->force_warm = std::getenv("CMPC_FORCE_WARM") != nullptr;
     if (const char* e = std::getenv("CMPC_MU_ADAPT")) h->mu_adapt = (float)std::atof(e);
     if (h->cfg.tail_stages < 0 || h->cfg.tail_stages >= h->cfg.horizon) h->cfg.tail_stages = 0;
@@ -189,6 +187,7 @@ int cmpc_create(const cmpc_config* cfg, int batch, int device, cmpc_handle* out)
         hipError_t e_ = (call);                                                                               \
         if (e_ != hipSuccess) {                                                                               \
             const std::string m_ = std::string("cmpc_create: " #call ": ") + hipGetErrorString(e_);           \
+            (void)hipGetLastError(); /* the runtime keeps the error until it is read: a later launch must not see it */ \
             cmpc_destroy(h);                                                                                  \
             return fail(nullptr, CMPC_ERR_HIP, m_);                                                           \
         }                                                                                                     \
@@ -290,7 +289,7 @@ static void fill_params(cmpc_handle h, CmpcParams& p)
     p.mu_init = h->cfg.mu_init > 0 ? (float)h->cfg.mu_init : 0.1f;
     p.mu_adapt = h->cfg.mu_init > 0 ? 0.f : h->mu_adapt;
     p.t_floor = 1e-2f;
-    p.stall_window = h->stall_window;
+    p.warm_budget = h->warm_budget; p.warm_no_restart = h->warm_no_restart;
     p.duals = h->dDuals; p.warm_duals = h->warm_duals;
 }
 
@@ -316,6 +315,14 @@ static int solve_device_impl(cmpc_handle h, const float* dP, const float* dX0, f
 int cmpc_solve_device(cmpc_handle h, const float* dP, const float* dX0, float* dX, float* dInfo, void* stream)
 {
     return solve_device_impl(h, dP, dX0, dX, dInfo, stream, false);
+}
+
+int cmpc_set_warm_policy(cmpc_handle h, int warm_budget, int restart_in_kernel)
+{
+    if (!h || warm_budget < 0) return fail(h, CMPC_ERR_ARG, "cmpc_set_warm_policy: bad argument");
+    h->warm_budget = warm_budget;
+    h->warm_no_restart = restart_in_kernel ? 0 : 1;
+    return CMPC_OK;
 }
 
 int cmpc_solve_device_warm(cmpc_handle h, const float* dP, const float* dX0, float* dX, float* dInfo, void* stream)

@@ -12,7 +12,6 @@
 #define CMPC_NMAX 40 // largest horizon the kernels are built for
 #define CMPC_TZ_LDS_NMAX 20  // HBM-factor variant: slacks / multipliers stay in LDS up to this horizon (three workgroups per CU still fit)
 #define CMPC_INFO_N 8
-#define CMPC_STALL_WINDOW_DEFAULT 0   // warm starts: progress watch off until tuned on the walking roll-out (see CmpcParams::stall_window)
 
 // x / p index layout of the reference's generated NLP (tmp.c:62-67)
 struct CmpcLayout {
@@ -106,7 +105,9 @@ struct CmpcParams {
     float mu_init, t_floor;      // starting barrier parameter and slack floor of this solve (cold: 0.1 / 1e-2)
     float mu_adapt;              // > 0: mu_init is replaced per problem by clamp(mu_adapt * ep0^2, 0.03, 0.5)
     int warm;                    // the initial guess is a shifted previous solution: a problem that fails is restarted cold
-    int stall_window;            // warm starts: iterations max(primal residual, max t z) may go without halving before the cold restart (0: only at the budget)
+    int warm_budget;             // warm starts: iteration budget of the warm-started pass (0: max_iter)
+    int warm_no_restart;         // warm starts: 1 = a pass that exhausts its budget returns status 1 (the caller re-solves it), 0 = it is started again
+                                 //  from the cold start inside the kernel
     float* duals;                // [B][NS (N+1) + 2 NI N] costates | slacks | multipliers of the last solve (written at exit; read, shifted
     int warm_duals;              //  by one knot, at the start of a warm solve if warm_duals != 0); may be null
     float* scratch;              // per-problem factor storage when it does not fit in LDS, else null

@@ -333,6 +333,13 @@ __device__ inline double grad_sym(const Ctx& c, const CmpcConsts& prm, int k, in
 }
 
 __device__ inline float readlane_f(float x, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), lane)); }
+// a value every lane holds, moved to an SGPR: the results of the block reductions (residuals, step lengths, barrier parameter) live across
+// the out-of-line phase calls of the driver -- as VGPRs they were spilled to scratch memory there, as SGPRs they cost a v_writelane at worst
+__device__ inline float uniform_f(float x) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x))); }
+__device__ inline double uniform_d(double x)
+{
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(x)), __builtin_amdgcn_readfirstlane(__double2loint(x)));
+}
 __device__ inline double readlane_d(double x, int lane)
 {
     const int lo = __builtin_amdgcn_readlane(__double2loint(x), lane);
@@ -391,7 +398,7 @@ __device__ inline void block_maxn(float (&v)[NV], float* red, int tid)
         float r = red[q];
 #pragma unroll
         for (int w = 1; w < NT / 64; ++w) r = fmaxf(r, red[3 * w + q]);
-        v[q] = r;
+        v[q] = uniform_f(r);
     }
 }
 template <int NT>
@@ -404,7 +411,7 @@ __device__ inline double block_sum(double v, double* red, int tid)
     double r = red[0];
 #pragma unroll
     for (int w = 1; w < NT / 64; ++w) r += red[w];
-    return r;
+    return uniform_d(r);
 }
 // two maxima and one float64 sum behind one pair of barriers (the residual pass)
 template <int NT>
@@ -418,7 +425,7 @@ __device__ inline void block_max2_sum(float& m0, float& m1, double& sm, float* r
     double rs = redd[0];
 #pragma unroll
     for (int w = 1; w < NT / 64; ++w) { r0 = fmaxf(r0, red[3 * w]); r1 = fmaxf(r1, red[3 * w + 1]); rs += redd[w]; }
-    m0 = r0; m1 = r1; sm = rs;
+    m0 = uniform_f(r0); m1 = uniform_f(r1); sm = uniform_d(rs);
 }
 
 // ---- geometry of every stage for the current iterate: r_cj = R c_j + pos_c - com (8x3), Fc (2x3,
@@ -1519,10 +1526,11 @@ __device__ void riccati_delta(const Ctx& c, const CmpcConsts& prm, int tid)
 
 // largest step lengths keeping t, z positive (fraction tau to the boundary)
 template <int NT>
-__device__ void step_lengths(const Ctx& c, int tid, float tau, float& ap, float& ad, int k0 = 0)
+__device__ void step_lengths(const Ctx& c, int tid, float tau, float& ap, float& ad, int k0 = 0, int k1 = CMPC_NMAX)
 {
     float a_p = 1.f, a_d = 1.f;
-    for (int e = tid + NI * k0; e < c.N * NI; e += NT) {
+    const int ke = k1 < c.N ? k1 : c.N;   // rows of stages k0 .. ke-1
+    for (int e = tid + NI * k0; e < ke * NI; e += NT) {
         const float dt_ = c.dT[e], dz_ = c.dZ[e];
         if (dt_ < 0.f) a_p = fminf(a_p, -tau * c.T[e] / dt_);
         if (dz_ < 0.f) a_d = fminf(a_d, -tau * c.Z[e] / dz_);
@@ -1663,8 +1671,11 @@ __device__ __attribute__((noinline)) void tail_polish(lds_t lds, int Nrt, float*
 {
     CMPC_PHASE_PROLOGUE;
     const int k0 = __builtin_amdgcn_readfirstlane(k0_in);
-    for (int pi = 0; pi <= prm.tail_iters; ++pi) {
-        const bool last = pi == prm.tail_iters;
+    // tail_iters Newton steps at least; while a step was blocked (a row on its way to becoming active: the multipliers need their
+    // iterations) up to six more, then the affine-scaling step
+    bool last = false, blocked = true;   // (step lengths come out of block reductions: uniform)
+    for (int pi = 0; pi <= prm.tail_iters + 6 && !last; ++pi) {
+        last = pi >= prm.tail_iters + 6 || (pi >= prm.tail_iters && !blocked);
         all_geo<NT>(c, prm, tid);
         for (int e = tid + NS * k0; e < NS * N; e += NT) c.d[e] = (float)defect(c, prm, e / NS, e % NS);
         __syncthreads();
@@ -1689,11 +1700,323 @@ __device__ __attribute__((noinline)) void tail_polish(lds_t lds, int Nrt, float*
         float m1[1] = {bad};
         block_maxn<NT, 1>(m1, c.red, tid);
         if (!(m1[0] < INFINITY)) break;
+        blocked = ap < 0.9f || ad < 0.9f;
         for (int e = tid + NS * (k0 + 1); e < NS * (N + 1); e += NT) c.S[e] += ap * c.dS[e];
         for (int e = tid + NU * k0; e < NU * N; e += NT) c.U[e] += ap * c.dU[e];
         if (!last)
             for (int e = tid + NI * k0; e < NI * N; e += NT) { c.T[e] += ap * c.dT[e]; c.Z[e] += ad * c.dZ[e]; }
         __syncthreads();
+    }
+}
+
+// ---- the residual pass of an iteration, out of line (the driver is control flow and a handful of scalars; inlined there, this pass and the
+// update pass below pushed the driver of the 168-register variants to scratch spills inside the iteration loop: -1.5 % on configs 3-5).
+// Geometry, dynamics defects (float64 from the float32 iterate), inequality residuals, max t z, mean t z. ----
+struct Resid { float ep, ec, mu; };
+template <int NT, int NC, bool FG>
+__device__ __attribute__((noinline)) Resid phase_residuals(lds_t lds, int Nrt, float* fg_base, int nrow_in)
+{
+    CMPC_PHASE_PROLOGUE;
+    const int nrow = __builtin_amdgcn_readfirstlane(nrow_in);
+    float l_ep = 0.f, l_ec = 0.f, l_chk = 0.f;   // l_chk: a plain sum over everything the maxima see -- fmaxf drops a NaN operand, a sum keeps it
+    double l_mu = 0.0;
+    all_geo<NT>(c, prm, tid);
+    for (int e = tid; e < NS * N; e += NT) {
+        const double dv = defect(c, prm, e / NS, e % NS);
+        c.d[e] = (float)dv;
+        l_ep = fmaxf(l_ep, fabsf((float)dv));
+        l_chk += (float)dv;
+    }
+    for (int e = tid; e < NI * N; e += NT) {
+        const int k = e / NI, i = e % NI;
+        if (row_active(c, k, i)) {
+            const float t = c.T[e], z = c.Z[e];
+            const float rv = row_val(c, prm, k, i, c.U + NU * k) + t;
+            l_ep = fmaxf(l_ep, fabsf(rv));
+            l_ec = fmaxf(l_ec, t * z);
+            l_chk += rv + t * z;
+            l_mu += (double)t * z;
+        }
+    }
+    if (!(fabsf(l_chk) < INFINITY)) l_ep = INFINITY;   // (one test per thread, not per element: NaN, inf, inf - inf all end here)
+    block_max2_sum<NT>(l_ep, l_ec, l_mu, c.red, c.redd, tid);
+    Resid r;
+    r.ep = l_ep; r.ec = l_ec; r.mu = (float)(l_mu / (double)nrow);
+    return r;
+}
+
+// ---- the iterate takes its step (ap primal, ad dual) and the step is measured: out of line like the residual pass.  Returns the step
+// norm of the termination test. ----
+template <int NT, int NC, bool FG>
+__device__ __attribute__((noinline)) float phase_update(lds_t lds, int Nrt, float* fg_base, float ap_in, float ad_in)
+{
+    CMPC_PHASE_PROLOGUE;
+    const float ap = uniform_f(ap_in), ad = uniform_f(ad_in);
+    for (int e = tid; e < NS * (N + 1); e += NT) c.S[e] += ap * c.dS[e];
+    for (int e = tid; e < NU * N; e += NT) c.U[e] += ap * c.dU[e];
+    for (int e = tid; e < NI * N; e += NT) {
+        const float tn = c.T[e] + ap * c.dT[e];
+        float zn = c.Z[e] + ad * c.dZ[e];
+        c.T[e] = tn; c.Z[e] = zn;
+    }
+    // ---- convergence: the Newton step itself is the error estimate.  Flat directions of the cost
+    // (e.g. the internal force along the line joining the feet) are kept quiet by the Levenberg
+    // shift `reg`.  The stationarity residual of a float32-stored iterate cannot go below ~1e-3
+    // (one ulp of com_z moves its gradient by 2 w_z^2 ulp ~ 5e-3), so it is not the test. ----
+    // The step is measured on what the cost and the dynamics see: the states, the deviation of
+    // each corner force from its foot's mean, the force rate, the landing offsets.  A constant
+    // internal force along the line joining two stance feet changes none of them (the NLP does
+    // not determine it; it only drifts slowly towards the barrier's analytic centre).
+    // Force steps count relative to the largest corner-force component of the iterate (the parity tolerance is
+    // relative; forces are ~1-3 N/kg here), states and landing offsets absolutely (metres, m/s: order one or less).
+    float l_st = 0.f, l_sf = 0.f, l_fm = 1.f, l_chk2 = 0.f;
+    for (int e = tid; e < NS * (N + 1); e += NT) { const float ds = c.dS[e]; l_st = fmaxf(l_st, fabsf(ds)); l_chk2 += ds; }
+    for (int e = tid; e < NU * N; e += NT) {
+        const int k = e / NU, m = e % NU;
+        const float du = c.dU[e];
+        l_chk2 += du;
+        if (m < NF) {
+            const float* f = c.dU + NU * k + 12 * (m / 12) + m % 3;
+            const float mean = 0.25f * (f[0] + f[3] + f[6] + f[9]);
+            l_sf = fmaxf(l_sf, fabsf(du - gam_of(c, m / 12, k) * mean));
+            if (k > 0) l_sf = fmaxf(l_sf, fabsf(du - c.dU[e - NU]));
+            l_fm = fmaxf(l_fm, fabsf(c.U[e]));
+        } else l_st = fmaxf(l_st, fabsf(du));
+    }
+    if (!(fabsf(l_chk2) < INFINITY)) l_st = INFINITY;   // (a step that is not finite is never "small": see the residual pass)
+    float m3[3] = {l_st, l_sf, l_fm};
+    block_maxn<NT, 3>(m3, c.red, tid);   // (the largest force is uniform: max(l_st, l_sf / fm) over threads = max(max l_st, max l_sf / fm))
+    return ap * fmaxf(m3[0], m3[1] / m3[2]);
+}
+
+// ---- the last step of a converged solve (out of line: it runs once, and the driver keeps its register allocation): the affine-scaling
+// step that phase_forward(affine) has just computed is applied -- primal only -- and, where the tail asks for it, the tail is polished.
+// Returns true if the tail was polished. ----
+template <int NT, int NC, bool FG>
+__device__ __attribute__((noinline)) bool phase_finish(lds_t lds, int Nrt, float* fg_base)
+{
+    CMPC_PHASE_PROLOGUE;
+    float ap, ad;
+    step_lengths<NT>(c, tid, 0.999f, ap, ad);
+    // size of the step: over everything (NaN-aware: a step that is not finite is not taken -- the converged iterate stands) and over
+    // the forces of the last tail_stages stages, relative to the largest force
+    const int kt = N - prm.tail_stages;
+    float l_all = 0.f, l_tail = 0.f, l_fm = 1.f;
+    for (int e = tid; e < NS * (N + 1); e += NT) l_all = amax_nan(l_all, c.dS[e]);
+    for (int e = tid; e < NU * N; e += NT) {
+        const float du = c.dU[e];
+        l_all = amax_nan(l_all, du);
+        if (e % NU < NF) {
+            l_fm = fmaxf(l_fm, fabsf(c.U[e]));
+            if (e >= NU * kt) l_tail = fmaxf(l_tail, fabsf(du));
+        }
+    }
+    float m3[3] = {l_all, l_tail, l_fm};
+    block_maxn<NT, 3>(m3, c.red, tid);
+    if (!(m3[0] < INFINITY)) return false;
+    // A large extrapolation step in the tail: nearly degenerate rows there (see tail_polish).  The FULL step is measured, not ap x step:
+    // such a row is exactly what blocks the step length, and a blocked extrapolation leaves the whole bias in place (measured: the
+    // worst problem of 512 had ap = 0.002 and was missed by the scaled test).
+    const int k0 = (prm.tail_stages > 0 && m3[1] > prm.tail_trigger * m3[2]) ? kt : N;
+    // the tail then goes its own way, and the step of the stages before it is limited by their own rows only (with the common step
+    // length the 27 stages that had nothing wrong got no extrapolation at all on such a problem)
+    if (k0 < N) step_lengths<NT>(c, tid, 0.999f, ap, ad, 0, k0);
+    for (int e = tid; e < NS * (k0 < N ? k0 + 1 : N + 1); e += NT) c.S[e] += ap * c.dS[e];
+    for (int e = tid; e < NU * k0; e += NT) c.U[e] += ap * c.dU[e];
+    __syncthreads();
+    if (k0 == N) return false;
+    tail_polish<NT, NC, FG>(lds, N, fg_base, k0);
+    return true;
+}
+
+// ---- the remaining pieces of the driver, out of line for the same reason as the passes above: the kernel body below is control flow
+// over a dozen scalars and holds no LDS map of its own (with the ~45 pointers of Ctx live across every phase call the 168-register
+// variants spilled SGPRs into VGPR lanes and those VGPRs into scratch memory, reloaded in front of every use: -1.7 % on configs 3-5) ----
+template <int NT, int NC, bool FG>
+__device__ __attribute__((noinline)) void phase_setup(lds_t lds, int Nrt, float* fg_base, const float* gp)
+{
+    CMPC_PHASE_PROLOGUE;
+    float* spw = const_cast<float*>(c.sp);
+    // one-off tables, parameter vector (coalesced)
+    for (int e = tid; e < NTRI; e += NT) {
+        int i = (int)((sqrtf(8.f * (float)e + 1.f) - 1.f) * 0.5f);
+        while ((i + 1) * (i + 2) / 2 <= e) ++i;
+        while (i * (i + 1) / 2 > e) --i;
+        c.tri[e] = (unsigned short)((i << 8) | (e - i * (i + 1) / 2));
+    }
+    // (zero blocks of the factor records: LDS was zeroed by the kernel; HBM scratch is zeroed once, at cmpc_create)
+    for (int e = tid; e < c.L.np(); e += NT) spw[e] = gp[e];
+    __syncthreads();
+    if (tid < N) {
+        int m = 0;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) m |= qfree_compute(c, tid, q) ? (1 << q) : 0;
+        c.qmask[tid] = m;
+    }
+    __syncthreads();
+}
+
+// initial iterate from x0 (or, cold: the cold start of SURVEY 8d built in place: CoM at com0, feet at nominal, f_z = g/8); returns the
+// number of inequality rows in use
+template <int NT, int NC, bool FG>
+__device__ __attribute__((noinline)) int phase_init(lds_t lds, int Nrt, float* fg_base, const float* x0, const float* dprev, int flags, float mu_init,
+                                                    float t_floor)
+{
+    CMPC_PHASE_PROLOGUE;
+    const bool cold = (flags & 1) != 0, use_duals = (flags & 2) != 0, use_mult = (flags & 4) != 0;
+    for (int e = tid; e < NS * (N + 1); e += NT) {
+        const int k = e / NS, i = e % NS;
+        float v;
+        if (k == 0) {  // initial-condition rows of g hold exactly
+            if (i < 9) v = c.sp[c.L.pCom0() + i];
+            else v = c.sp[c.L.pCur((i - 9) / 3) + (i - 9) % 3];
+        } else if (cold) v = i < 3 ? c.sp[c.L.pCom0() + i] : (i < 9 ? 0.f : c.sp[c.L.pNom((i - 9) / 3) + 3 * k + (i - 9) % 3]);
+        else if (i < 9) v = x0[c.L.oCom() + 3 * (N + 1) * (i / 3) + 3 * k + i % 3];
+        else v = x0[c.L.oPos((i - 9) / 3) + 3 * k + (i - 9) % 3];
+        c.S[e] = v;
+        // costates: zero, or -- warm start with duals -- the previous solve's shifted by one knot (they only enter the
+        // first iteration's exact-Hessian term; every iteration recomputes them)
+        c.LAM[e] = (use_duals && !cold) ? dprev[NS * (k < N ? k + 1 : N) + i] : 0.f;
+    }
+    for (int e = tid; e < NU * N; e += NT) {
+        const int k = e / NU, m = e % NU;
+        float v = 0.f;
+        if (m < NF) v = cold ? (m % 3 == 2 ? 0.125f * prm.grav : 0.f) : x0[c.L.oF(m / 12, (m % 12) / 3) + 3 * k + m % 3];
+        else {
+            const int q = m - 24, ct = q / 3, i = q % 3;
+            if (qfree(c, k, q)) {
+                const float* R = c.sp + c.L.pR(ct) + 9 * k;
+                const float lo = qlo(c, k, q), hi = qhi(c, k, q), push = 0.01f * (hi - lo);
+                for (int a = 0; a < 3 && !cold; ++a)
+                    v += Rm(R, a, i) * (x0[c.L.oPos(ct) + 3 * (k + 1) + a] - c.sp[c.L.pNom(ct) + 3 * (k + 1) + a]);
+                v = fminf(fmaxf(v, lo + push), hi - push);
+            } else if (gam_of(c, ct, k) < 0.5f) v = qlo(c, k, q);
+        }
+        c.U[e] = v;
+    }
+    __syncthreads();
+    for (int e = tid; e < NI * N; e += NT) {
+        const int k = e / NI, i = e % NI;
+        float t = 1.f, z = 0.f;
+        if (row_active(c, k, i)) {
+            t = -row_val(c, prm, k, i, c.U + NU * k);
+            if (i < 32) t = fmaxf(t, t_floor);
+            z = mu_init / t;
+            if (use_mult && !cold) {
+                // multiplier of the same row one knot later in the previous solve, where it is the larger (an active
+                // row keeps its multiplier; inactive ones keep the centred value mu / t)
+                const int kk = k + 1 < N ? k + 1 : N - 1;
+                z = fmaxf(z, dprev[NS * (N + 1) + NI * N + NI * kk + i]);
+            }
+        }
+        c.T[e] = t; c.Z[e] = z;
+    }
+    __syncthreads();
+    int nrow = 0;
+    for (int k = 0; k < N; ++k)
+        for (int i = 32; i < NI; ++i) nrow += row_active(c, k, i) ? 1 : 0;
+    return __builtin_amdgcn_readfirstlane(nrow + 32 * N);
+}
+
+// mode 0: every multiplier scaled by `a` (cold start: the initial barrier parameter follows the initial infeasibility).
+// mode 1: emergency re-centring -- multipliers with t z > 10 a pulled back to 10 a / t; returns the new mean t z.
+// mode 2: every row's complementarity target set to `a` (plain centring step).
+template <int NT, int NC, bool FG>
+__device__ __attribute__((noinline)) float phase_multipliers(lds_t lds, int Nrt, float* fg_base, int mode_in, float a_in, int nrow_in)
+{
+    CMPC_PHASE_PROLOGUE;
+    const int mode = __builtin_amdgcn_readfirstlane(mode_in), nrow = __builtin_amdgcn_readfirstlane(nrow_in);
+    const float a = uniform_f(a_in);
+    float out = a;
+    if (mode == 0) {
+        for (int e = tid; e < NI * N; e += NT) c.Z[e] *= a;
+    } else if (mode == 1) {
+        double l2 = 0.0;
+        for (int e = tid; e < NI * N; e += NT)
+            if (row_active(c, e / NI, e % NI)) {
+                const float t = c.T[e];
+                float z = c.Z[e];
+                if (t * z > 10.f * a) { z = 10.f * a / t; c.Z[e] = z; }
+                l2 += (double)t * z;
+            }
+        out = (float)(block_sum<NT>(l2, c.redd, tid) / (double)nrow);
+    } else {
+        for (int e = tid; e < NI * N; e += NT) c.dZ[e] = row_active(c, e / NI, e % NI) ? a : 0.f;
+    }
+    __syncthreads();
+    return out;
+}
+
+template <int NT, int NC, bool FG>
+__device__ __attribute__((noinline)) int phase_backward(lds_t lds, int Nrt, float* fg_base, bool exact_in, float reg, float cmu)
+{
+    CMPC_PHASE_PROLOGUE;
+    const bool exact = __builtin_amdgcn_readfirstlane((int)exact_in) != 0;
+    return riccati_backward<NT, NC, FG>(lds, c, prm, tid, fg_base, exact, reg, cmu);
+}
+
+struct StepLen { float ap, ad; };
+template <int NT, int NC, bool FG>
+__device__ __attribute__((noinline)) StepLen phase_step_lengths(lds_t lds, int Nrt, float* fg_base, float tau)
+{
+    CMPC_PHASE_PROLOGUE;
+    StepLen r;
+    step_lengths<NT>(c, tid, uniform_f(tau), r.ap, r.ad);
+    return r;
+}
+
+// Mehrotra's centring parameter from the affine step (step lengths ap, ad), then the corrector's per-row complementarity targets
+struct Centre { float sigma, mu_t; };
+template <int NT, int NC, bool FG>
+__device__ __attribute__((noinline)) Centre phase_corrector_targets(lds_t lds, int Nrt, float* fg_base, float ap_in, float ad_in, float mu_in, int nrow_in)
+{
+    CMPC_PHASE_PROLOGUE;
+    const float ap = uniform_f(ap_in), ad = uniform_f(ad_in), mu_cur = uniform_f(mu_in);
+    const int nrow = __builtin_amdgcn_readfirstlane(nrow_in);
+    double l_aff = 0.0;
+    for (int e = tid; e < NI * N; e += NT)
+        if (row_active(c, e / NI, e % NI)) l_aff += (double)(c.T[e] + ap * c.dT[e]) * (double)(c.Z[e] + ad * c.dZ[e]);
+    const float mu_aff = (float)(block_sum<NT>(l_aff, c.redd, tid) / (double)nrow);
+    Centre r;
+    r.sigma = mu_aff / mu_cur;
+    r.sigma = r.sigma * r.sigma * r.sigma;
+    r.mu_t = fmaxf(fmaxf(r.sigma, prm.sigma_min) * mu_cur, prm.mu_min);
+    for (int e = tid; e < NI * N; e += NT) {
+        const float cmu = row_active(c, e / NI, e % NI) ? r.mu_t - c.dT[e] * c.dZ[e] : 0.f;  // complementarity target
+        c.dZ[e] = cmu;
+        c.dT[e] = cmu / c.T[e];   // row coefficient change, read by the corrector sweep (dT is rebuilt by the forward sweep)
+    }
+    __syncthreads();
+    return r;
+}
+
+// x in the reference layout (and, warm starts with duals, the costates, slacks and multipliers)
+template <int NT, int NC, bool FG>
+__device__ __attribute__((noinline)) void phase_export(lds_t lds, int Nrt, float* fg_base, float* x, float* dq)
+{
+    CMPC_PHASE_PROLOGUE;
+    for (int e = tid; e < NS * (N + 1); e += NT) {
+        const int k = e / NS, i = e % NS;
+        if (i < 9) x[c.L.oCom() + 3 * (N + 1) * (i / 3) + 3 * k + i % 3] = c.S[e];
+        else x[c.L.oPos((i - 9) / 3) + 3 * k + (i - 9) % 3] = c.S[e];
+    }
+    for (int e = tid; e < NU * N; e += NT) {
+        const int k = e / NU, m = e % NU;
+        if (m < NF) x[c.L.oF(m / 12, (m % 12) / 3) + 3 * k + m % 3] = c.U[e];
+        else {
+            const int q = m - 24, ct = q / 3, i = q % 3;
+            const float v = gam_of(c, ct, k) < 0.5f ? (c.S[NS * (k + 1) + 9 + q] - c.S[NS * k + 9 + q]) / prm.dt : 0.f;
+            x[c.L.oVel(ct) + 3 * k + i] = v;
+        }
+    }
+    if (dq) {
+        __syncthreads();   // (the warm-start reads of this block's own record are long done; other blocks own other rows)
+        for (int e = tid; e < NS * (N + 1); e += NT) dq[e] = c.LAM[e];
+        for (int e = tid; e < NI * N; e += NT) { dq[NS * (N + 1) + e] = c.T[e]; dq[NS * (N + 1) + NI * N + e] = c.Z[e]; }
+    }
+    if (prm.dev[2] != 0.f) {  // developer probe: where the hardware put each wave (overwrites x[0..3]; HW_ID: wave slot
+        __syncthreads();      // [3:0], SIMD [5:4], CU [11:8], SH [12], SE [15:13])
+        if ((threadIdx.x & 63) == 0) x[threadIdx.x >> 6] = (float)(__builtin_amdgcn_s_getreg((31 << 11) | 4) & 0xffff);
     }
 }
 
@@ -1716,160 +2039,57 @@ __global__ __launch_bounds__(NT, FG ? 3 : 1) void cmpc_solve_kernel(CmpcParams k
     }
     __syncthreads();
     // constants first in LDS
-    CmpcConsts& prmw = *reinterpret_cast<CmpcConsts*>(smem);
     {
         const int* src = reinterpret_cast<const int*>(kp.kc);
         int* dst = reinterpret_cast<int*>(smem);
         for (int e = tid; e < (int)(sizeof(CmpcConsts) / 4); e += NT) dst[e] = src[e];
     }
-    const CmpcConsts& prm = prmw;
+    const CmpcConsts& prm = *reinterpret_cast<const CmpcConsts*>(smem);
     const long long t_start = __builtin_amdgcn_s_memtime();
-    Ctx c;
     // (made opaque: interprocedural constant propagation would otherwise hand every phase the dynamic-LDS symbol
     // back and with it a table lookup per call)
     unsigned ldsv = (unsigned)(unsigned long long)(lds_t)smem;
     asm volatile("" : "+s"(ldsv));
     const lds_t lds = (lds_t)(unsigned long long)ldsv;
     float* const fg_base = FG ? kp.scratch + (size_t)b * kp.scratch_stride : nullptr;
-    make_ctx<FG>(c, smem, N, fg_base);
-    float* spw = const_cast<float*>(c.sp);
-
-    // ---- one-off tables, parameter vector (coalesced) ----
-    for (int e = tid; e < NTRI; e += NT) {
-        int i = (int)((sqrtf(8.f * (float)e + 1.f) - 1.f) * 0.5f);
-        while ((i + 1) * (i + 2) / 2 <= e) ++i;
-        while (i * (i + 1) / 2 > e) --i;
-        c.tri[e] = (unsigned short)((i << 8) | (e - i * (i + 1) / 2));
-    }
-    // (zero blocks of the factor records: LDS was zeroed above; HBM scratch is zeroed once, at cmpc_create)
-    {
-        const float* gp = kp.P + (size_t)b * c.L.np();
-        for (int e = tid; e < c.L.np(); e += NT) spw[e] = gp[e];
-    }
+    const CmpcIdx L{N};
     __syncthreads();
-    if (tid < N) {
-        int m = 0;
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) m |= qfree_compute(c, tid, q) ? (1 << q) : 0;
-        c.qmask[tid] = m;
-    }
-    __syncthreads();
+    phase_setup<NT, NC, FG>(lds, N, fg_base, kp.P + (size_t)b * L.np());
     // Two passes at most: a warm-started solve (shifted previous solution) that exhausts its iteration budget is started
     // again from the cold start -- rare (a landing or lift-off tick, 1 in ~60000 solves of a walking roll-out) and cheaper than
     // failing the tick, which is all the caller could do (CentroidalMPCBlock.cpp:615-619 aborts).
-    int status = 1, gn = 0, nrc = 0, restarted = 0, polished = 0, it_total = 0;
+    int status = 1, sg = 0, it_total = 0;   // sg: the safeguard word of info[3] (include/cmpc.h)
     float err = 0.f, ep = 0.f, mu_cur = 0.f, step_out = 0.f, step_prev = 0.f;
+    float* const dq = kp.duals ? kp.duals + (size_t)b * (NS * (N + 1) + 2 * NI * N) : nullptr;
     for (int pass = 0; pass < 2; ++pass) {
         const float mu_init = pass ? 0.1f : kp.mu_init, t_floor = pass ? 1e-2f : kp.t_floor, mu_adapt = pass ? 3.5f : kp.mu_adapt;
         step_out = step_prev = 0.f;
-        // ---- initial iterate from x0 ----
-        {
-            const float* x0 = kp.X0 + (size_t)b * c.L.nx();
-            const bool cold = pass > 0;   // second pass: the cold start of SURVEY 8d built in place (CoM at com0, feet at nominal, f_z = g/8)
-            const bool use_duals = kp.warm && kp.warm_duals && kp.duals;
-            const float* dprev = kp.duals ? kp.duals + (size_t)b * (NS * (N + 1) + 2 * NI * N) : nullptr;
-            for (int e = tid; e < NS * (N + 1); e += NT) {
-                const int k = e / NS, i = e % NS;
-                float v;
-                if (k == 0) {  // initial-condition rows of g hold exactly
-                    if (i < 9) v = c.sp[c.L.pCom0() + i];
-                    else v = c.sp[c.L.pCur((i - 9) / 3) + (i - 9) % 3];
-                } else if (cold) v = i < 3 ? c.sp[c.L.pCom0() + i] : (i < 9 ? 0.f : c.sp[c.L.pNom((i - 9) / 3) + 3 * k + (i - 9) % 3]);
-                else if (i < 9) v = x0[c.L.oCom() + 3 * (N + 1) * (i / 3) + 3 * k + i % 3];
-                else v = x0[c.L.oPos((i - 9) / 3) + 3 * k + (i - 9) % 3];
-                c.S[e] = v;
-                // costates: zero, or -- warm start with duals -- the previous solve's shifted by one knot (they only enter the
-                // first iteration's exact-Hessian term; every iteration recomputes them)
-                c.LAM[e] = (use_duals && !cold) ? dprev[NS * (k < N ? k + 1 : N) + i] : 0.f;
-            }
-            for (int e = tid; e < NU * N; e += NT) {
-                const int k = e / NU, m = e % NU;
-                float v = 0.f;
-                if (m < NF) v = cold ? (m % 3 == 2 ? 0.125f * prm.grav : 0.f) : x0[c.L.oF(m / 12, (m % 12) / 3) + 3 * k + m % 3];
-                else {
-                    const int q = m - 24, ct = q / 3, i = q % 3;
-                    if (qfree(c, k, q)) {
-                        const float* R = c.sp + c.L.pR(ct) + 9 * k;
-                        const float lo = qlo(c, k, q), hi = qhi(c, k, q), push = 0.01f * (hi - lo);
-                        for (int a = 0; a < 3 && !cold; ++a)
-                            v += Rm(R, a, i) * (x0[c.L.oPos(ct) + 3 * (k + 1) + a] - c.sp[c.L.pNom(ct) + 3 * (k + 1) + a]);
-                        v = fminf(fmaxf(v, lo + push), hi - push);
-                    } else if (gam_of(c, ct, k) < 0.5f) v = qlo(c, k, q);
-                }
-                c.U[e] = v;
-            }
-            __syncthreads();
-            for (int e = tid; e < NI * N; e += NT) {
-                const int k = e / NI, i = e % NI;
-                float t = 1.f, z = 0.f;
-                if (row_active(c, k, i)) {
-                    t = -row_val(c, prm, k, i, c.U + NU * k);
-                    if (i < 32) t = fmaxf(t, t_floor);
-                    z = mu_init / t;
-                    if (use_duals && !cold && kp.warm_duals > 1) {
-                        // multiplier of the same row one knot later in the previous solve, where it is the larger (an active
-                        // row keeps its multiplier; inactive ones keep the centred value mu / t)
-                        const int kk = k + 1 < N ? k + 1 : N - 1;
-                        z = fmaxf(z, dprev[NS * (N + 1) + NI * N + NI * kk + i]);
-                    }
-                }
-                c.T[e] = t; c.Z[e] = z;
-            }
-            __syncthreads();
-        }
-        int nrow = 0;
-        for (int k = 0; k < N; ++k)
-            for (int i = 32; i < NI; ++i) nrow += row_active(c, k, i) ? 1 : 0;
-        nrow += 32 * N;
-
+        const bool use_duals = kp.warm && kp.warm_duals && kp.duals;
+        const int nrow = phase_init<NT, NC, FG>(lds, N, fg_base, kp.X0 + (size_t)b * L.nx(), dq,
+                                                (pass > 0 ? 1 : 0) | (use_duals ? 2 : 0) | (use_duals && kp.warm_duals > 1 ? 4 : 0), mu_init, t_floor);
         int it = 0;
         status = 1;
         bool finishing = false;
-        // progress watch of a warm start (kp.stall_window > 0): phi = max(primal residual, max t z) must halve at least once every
-        // stall_window iterations, else the pass is abandoned for the cold start at once instead of after the whole budget
-        float phi_best = INFINITY;
-        int since = 0;
-        for (it = 0; it < prm.max_iter + 1; ++it) {
-            if (it == prm.max_iter && !finishing) break;
+        // (a warm-started pass may be given a smaller budget: kp.warm_budget -- its stragglers are then re-solved from the cold
+        // start, inside this kernel or by the caller, see CmpcParams)
+        const int budget = (kp.warm && pass == 0 && kp.warm_budget > 0 && kp.warm_budget < prm.max_iter) ? kp.warm_budget : prm.max_iter;
+        for (it = 0; it < budget + 1; ++it) {
+            if (it == budget && !finishing) break;
             // ---- residuals of the current iterate ----
             PROF_DECL;
-            float l_ep = 0.f, l_ec = 0.f;
-            double l_mu = 0.0;
-            all_geo<NT>(c, prm, tid);
-            for (int e = tid; e < NS * N; e += NT) {
-                const double dv = defect(c, prm, e / NS, e % NS);
-                c.d[e] = (float)dv;
-                l_ep = amax_nan(l_ep, (float)dv);
-            }
-            for (int e = tid; e < NI * N; e += NT) {
-                const int k = e / NI, i = e % NI;
-                if (row_active(c, k, i)) {
-                    const float t = c.T[e], z = c.Z[e];
-                    l_ep = amax_nan(l_ep, row_val(c, prm, k, i, c.U + NU * k) + t);
-                    l_ec = amax_nan(l_ec, t * z);
-                    l_mu += (double)t * z;
-                }
-            }
-            block_max2_sum<NT>(l_ep, l_ec, l_mu, c.red, c.redd, tid);
-            ep = l_ep;
-            const float ec = l_ec;
-            mu_cur = (float)(l_mu / (double)nrow);
+            const Resid rs = phase_residuals<NT, NC, FG>(lds, N, fg_base, nrow);
+            ep = rs.ep;
+            const float ec = rs.ec;
+            mu_cur = rs.mu;
             // a residual that is not finite (NaN or inf in P or X0, or a step that went wrong): "invalid number" -- the reference's
-            // IPOPT stops there and advance() returns false.  (The maxima above turn NaN into +inf; plain fmaxf would drop it, the
+            // IPOPT stops there and advance() returns false.  (phase_residuals turns NaN into +inf; plain fmaxf would drop it, the
             // iterate would read as converged and NaN forces would go downstream with status 0.)
-            if (!(fmaxf(ep, ec) < INFINITY) || !(mu_cur == mu_cur)) { status = 2; err = INFINITY; break; }
-            if (kp.warm && pass == 0 && kp.stall_window > 0 && !finishing) {
-                const float phi = fmaxf(ep, ec);
-                if (phi < 0.5f * phi_best) { phi_best = phi; since = 0; }
-                else if (++since >= kp.stall_window) break;   // (status 1: the cold pass follows)
-            }
+            if (!(ep < INFINITY)) { status = 2; err = INFINITY; break; }
             if (it == 0 && mu_adapt > 0.f) {
                 // cold start: the initial barrier parameter scales with the squared initial infeasibility (z = mu / t)
                 const float mu0 = fminf(fmaxf(mu_adapt * ep * ep, 0.03f), 0.5f);
-                const float sc = mu0 / mu_cur;
-                for (int e = tid; e < NI * N; e += NT) c.Z[e] *= sc;
+                phase_multipliers<NT, NC, FG>(lds, N, fg_base, 0, mu0 / mu_cur, nrow);
                 mu_cur = mu0;
-                __syncthreads();
             }
             if (kp.warm && pass == 0 && it > 0 && ec > 100.f * mu_cur && ec > 0.1f) {
                 // Emergency re-centring.  Primal and dual step lengths differ; when a blocked primal step (ap ~ 0.2) meets a
@@ -1879,17 +2099,9 @@ __global__ __launch_bounds__(NT, FG ? 3 : 1) void cmpc_solve_kernel(CmpcParams k
                 // without progress).  Pull those multipliers back to 10 mu / t.  Only products of order one count (ec > 0.1):
                 // near the barrier floor a few lagging rows are legitimately 100 x the mean and must be left alone
                 // (re-centring them there cost config 2 five of 4096 problems).  Warm starts only: cold starts pass through such
-            // iterates on their own (5 of 40960 config-2 problems trip the test and then need 20 iterations instead of 12).
-                double l2 = 0.0;
-                for (int e = tid; e < NI * N; e += NT)
-                    if (row_active(c, e / NI, e % NI)) {
-                        const float t = c.T[e];
-                        float z = c.Z[e];
-                        if (t * z > 10.f * mu_cur) { z = 10.f * mu_cur / t; c.Z[e] = z; }
-                        l2 += (double)t * z;
-                    }
-                mu_cur = (float)(block_sum<NT>(l2, c.redd, tid) / (double)nrow);
-                ++nrc;
+                // iterates on their own (5 of 40960 config-2 problems trip the test and then need 20 iterations instead of 12).
+                mu_cur = phase_multipliers<NT, NC, FG>(lds, N, fg_base, 1, mu_cur, nrow);
+                sg += 100;
             }
             PROF(10);
             // The step that produced this iterate was already below the step tolerance and its residuals are converged:
@@ -1918,113 +2130,43 @@ __global__ __launch_bounds__(NT, FG ? 3 : 1) void cmpc_solve_kernel(CmpcParams k
             float reg = prm.reg;
             int fail = 1;
             for (int attempt = 0; attempt < 4; ++attempt) {
-                fail = riccati_backward<NT, NC, FG>(lds, c, prm, tid, fg_base, exact, reg, centring ? prm.mu_min : 0.f);
+                fail = phase_backward<NT, NC, FG>(lds, N, fg_base, exact, reg, centring ? prm.mu_min : 0.f);
                 if (!fail) break;
                 __syncthreads();
-                ++gn; exact = false;
+                ++sg; exact = false;
                 if (attempt > 0) reg *= 1e3f;
             }
             if (fail) { if (!finishing) status = 2; break; }   // (a failed extrapolation step leaves the converged iterate)
             PROF(11);
-            float ap, ad, sigma = 0.f, mu_t = prm.mu_min;
+            float sigma = 0.f, mu_t = prm.mu_min;
             if (centring) {
-                for (int e = tid; e < NI * N; e += NT) c.dZ[e] = row_active(c, e / NI, e % NI) ? prm.mu_min : 0.f;
-                __syncthreads();
+                phase_multipliers<NT, NC, FG>(lds, N, fg_base, 2, prm.mu_min, nrow);
                 phase_forward<NT, NC, FG>(lds, N, fg_base, false);
                 PROF(15);
             } else {
-            phase_forward<NT, NC, FG>(lds, N, fg_base, true);
-            PROF(12);
-            if (finishing) {
-                // last step: affine-scaling extrapolation of the central path to mu = 0 (primal only)
-                step_lengths<NT>(c, tid, 0.999f, ap, ad);
-                // its size: over everything (NaN-aware: a step that is not finite is not taken -- the converged iterate stands) and
-                // over the forces of the last tail_stages stages, relative to the largest force
-                const int kt = N - prm.tail_stages;
-                float l_all = 0.f, l_tail = 0.f, l_fm = 1.f;
-                for (int e = tid; e < NS * (N + 1); e += NT) l_all = amax_nan(l_all, c.dS[e]);
-                for (int e = tid; e < NU * N; e += NT) {
-                    const float du = c.dU[e];
-                    l_all = amax_nan(l_all, du);
-                    if (e % NU < NF) {
-                        l_fm = fmaxf(l_fm, fabsf(c.U[e]));
-                        if (e >= NU * kt) l_tail = fmaxf(l_tail, fabsf(du));
-                    }
+                phase_forward<NT, NC, FG>(lds, N, fg_base, true);
+                PROF(12);
+                if (finishing) {
+                    // last step: affine-scaling extrapolation of the central path to mu = 0 (primal only), and the tail polish behind it
+                    if (phase_finish<NT, NC, FG>(lds, N, fg_base)) sg += 100000;
+                    ++it;
+                    break;
                 }
-                float m3[3] = {l_all, l_tail, l_fm};
-                block_maxn<NT, 3>(m3, c.red, tid);
-                ++it;
-                if (!(m3[0] < INFINITY)) break;
-                // a large extrapolation step in the tail: nearly degenerate rows there (see tail_polish) -- the step is applied up
-                // to the state entering stage k0 and the tail is re-solved from it
-                const int k0 = (prm.tail_stages > 0 && ap * m3[1] > prm.tail_trigger * m3[2]) ? kt : N;
-                for (int e = tid; e < NS * (k0 < N ? k0 + 1 : N + 1); e += NT) c.S[e] += ap * c.dS[e];
-                for (int e = tid; e < NU * k0; e += NT) c.U[e] += ap * c.dU[e];
-                __syncthreads();
-                if (k0 < N) {
-                    tail_polish<NT, NC, FG>(lds, N, fg_base, k0);
-                    polished = 1;
-                }
-                break;
+                const StepLen sa = phase_step_lengths<NT, NC, FG>(lds, N, fg_base, 1.f);
+                const Centre ce = phase_corrector_targets<NT, NC, FG>(lds, N, fg_base, sa.ap, sa.ad, mu_cur, nrow);
+                sigma = ce.sigma; mu_t = ce.mu_t;
+                PROF(13);
+                phase_delta<NT, NC, FG>(lds, N, fg_base);
+                PROF(14);
+                phase_forward<NT, NC, FG>(lds, N, fg_base, false);
+                PROF(15);
             }
-            step_lengths<NT>(c, tid, 1.f, ap, ad);
-            double l_aff = 0.0;
-            for (int e = tid; e < NI * N; e += NT)
-                if (row_active(c, e / NI, e % NI)) l_aff += (double)(c.T[e] + ap * c.dT[e]) * (double)(c.Z[e] + ad * c.dZ[e]);
-            const float mu_aff = (float)(block_sum<NT>(l_aff, c.redd, tid) / (double)nrow);
-            sigma = mu_aff / mu_cur;
-            sigma = sigma * sigma * sigma;
-            mu_t = fmaxf(fmaxf(sigma, prm.sigma_min) * mu_cur, prm.mu_min);
-            // ---- corrector ----
-            for (int e = tid; e < NI * N; e += NT) {
-                const float cmu = row_active(c, e / NI, e % NI) ? mu_t - c.dT[e] * c.dZ[e] : 0.f;  // complementarity target
-                c.dZ[e] = cmu;
-                c.dT[e] = cmu / c.T[e];   // row coefficient change, read by the corrector sweep (dT is rebuilt by the forward sweep)
-            }
-            __syncthreads();
-            PROF(13);
-            phase_delta<NT, NC, FG>(lds, N, fg_base);
-            PROF(14);
-            phase_forward<NT, NC, FG>(lds, N, fg_base, false);
-            PROF(15);
-            }
-            step_lengths<NT>(c, tid, fmaxf(0.99f, 1.f - mu_t), ap, ad);
+            const StepLen sl = phase_step_lengths<NT, NC, FG>(lds, N, fg_base, fmaxf(0.99f, 1.f - mu_t));
+            const float ap = sl.ap, ad = sl.ad;
             // ---- costates, then the iterate ----
             phase_costate<NT, NC, FG>(lds, N, fg_base, ap, exact);
             PROF(16);
-            for (int e = tid; e < NS * (N + 1); e += NT) c.S[e] += ap * c.dS[e];
-            for (int e = tid; e < NU * N; e += NT) c.U[e] += ap * c.dU[e];
-            for (int e = tid; e < NI * N; e += NT) {
-                const float tn = c.T[e] + ap * c.dT[e];
-                float zn = c.Z[e] + ad * c.dZ[e];
-                c.T[e] = tn; c.Z[e] = zn;
-            }
-            // ---- convergence: the Newton step itself is the error estimate.  Flat directions of the cost
-            // (e.g. the internal force along the line joining the feet) are kept quiet by the Levenberg
-            // shift `reg`.  The stationarity residual of a float32-stored iterate cannot go below ~1e-3
-            // (one ulp of com_z moves its gradient by 2 w_z^2 ulp ~ 5e-3), so it is not the test. ----
-            // The step is measured on what the cost and the dynamics see: the states, the deviation of
-            // each corner force from its foot's mean, the force rate, the landing offsets.  A constant
-            // internal force along the line joining two stance feet changes none of them (the NLP does
-            // not determine it; it only drifts slowly towards the barrier's analytic centre).
-            // Force steps count relative to the largest corner-force component of the iterate (the parity tolerance is
-            // relative; forces are ~1-3 N/kg here), states and landing offsets absolutely (metres, m/s: order one or less).
-            float l_st = 0.f, l_sf = 0.f, l_fm = 1.f;
-            for (int e = tid; e < NS * (N + 1); e += NT) l_st = amax_nan(l_st, c.dS[e]);
-            for (int e = tid; e < NU * N; e += NT) {
-                const int k = e / NU, m = e % NU;
-                const float du = c.dU[e];
-                if (m < NF) {
-                    const float* f = c.dU + NU * k + 12 * (m / 12) + m % 3;
-                    const float mean = 0.25f * (f[0] + f[3] + f[6] + f[9]);
-                    l_sf = amax_nan(l_sf, du - gam_of(c, m / 12, k) * mean);
-                    if (k > 0) l_sf = amax_nan(l_sf, du - c.dU[e - NU]);
-                    l_fm = fmaxf(l_fm, fabsf(c.U[e]));
-                } else l_st = amax_nan(l_st, du);
-            }
-            float m3[3] = {l_st, l_sf, l_fm};
-            block_maxn<NT, 3>(m3, c.red, tid);   // (the largest force is uniform: max(l_st, l_sf / fm) over threads = max(max l_st, max l_sf / fm))
-            const float step = ap * fmaxf(m3[0], m3[1] / m3[2]);
+            const float step = phase_update<NT, NC, FG>(lds, N, fg_base, ap, ad);
             step_prev = step_out;
             step_out = step;
             err = fmaxf(ep, ec);
@@ -2042,42 +2184,15 @@ __global__ __launch_bounds__(NT, FG ? 3 : 1) void cmpc_solve_kernel(CmpcParams k
             }
         }
         it_total += it;
-        if (status == 0 || !kp.warm || pass > 0) break;
-        restarted = 1;
+        if (status == 0 || !kp.warm || pass > 0 || kp.warm_no_restart) break;
+        sg += 10000;
         __syncthreads();
     }
-    // ---- export x in the reference layout ----
-    {
-        float* x = kp.X + (size_t)b * c.L.nx();
-        for (int e = tid; e < NS * (N + 1); e += NT) {
-            const int k = e / NS, i = e % NS;
-            if (i < 9) x[c.L.oCom() + 3 * (N + 1) * (i / 3) + 3 * k + i % 3] = c.S[e];
-            else x[c.L.oPos((i - 9) / 3) + 3 * k + (i - 9) % 3] = c.S[e];
-        }
-        for (int e = tid; e < NU * N; e += NT) {
-            const int k = e / NU, m = e % NU;
-            if (m < NF) x[c.L.oF(m / 12, (m % 12) / 3) + 3 * k + m % 3] = c.U[e];
-            else {
-                const int q = m - 24, ct = q / 3, i = q % 3;
-                const float v = gam_of(c, ct, k) < 0.5f ? (c.S[NS * (k + 1) + 9 + q] - c.S[NS * k + 9 + q]) / prm.dt : 0.f;
-                x[c.L.oVel(ct) + 3 * k + i] = v;
-            }
-        }
-        if (kp.duals) {
-            __syncthreads();   // (the warm-start reads of this block's own record above are long done; other blocks own other rows)
-            float* dq = kp.duals + (size_t)b * (NS * (N + 1) + 2 * NI * N);
-            for (int e = tid; e < NS * (N + 1); e += NT) dq[e] = c.LAM[e];
-            for (int e = tid; e < NI * N; e += NT) { dq[NS * (N + 1) + e] = c.T[e]; dq[NS * (N + 1) + NI * N + e] = c.Z[e]; }
-        }
-        if (kp.info && tid == 0) {
-            float* inf = kp.info + (size_t)b * CMPC_INFO_N;
-            inf[0] = (float)it_total; inf[1] = err; inf[2] = mu_cur; inf[3] = (float)(gn + 100 * nrc + 10000 * restarted + 100000 * polished); inf[4] = ep; inf[5] = (float)status;
-            inf[6] = (float)(__builtin_amdgcn_s_memtime() - t_start); inf[7] = step_out;
-        }
-        if (prm.dev[2] != 0.f) {  // developer probe: where the hardware put each wave (overwrites x[0..3]; HW_ID: wave slot
-            __syncthreads();      // [3:0], SIMD [5:4], CU [11:8], SH [12], SE [15:13])
-            if ((threadIdx.x & 63) == 0) x[threadIdx.x >> 6] = (float)(__builtin_amdgcn_s_getreg((31 << 11) | 4) & 0xffff);
-        }
+    phase_export<NT, NC, FG>(lds, N, fg_base, kp.X + (size_t)b * L.nx(), dq);
+    if (kp.info && tid == 0) {
+        float* inf = kp.info + (size_t)b * CMPC_INFO_N;
+        inf[0] = (float)it_total; inf[1] = err; inf[2] = mu_cur; inf[3] = (float)sg; inf[4] = ep; inf[5] = (float)status;
+        inf[6] = (float)(__builtin_amdgcn_s_memtime() - t_start); inf[7] = step_out;
     }
 }
 
@@ -2142,6 +2257,7 @@ extern "C" int cmpc_launch_solver(const CmpcParams* prm, size_t lds_bytes, hipSt
     if (e != hipSuccess) return (int)e;
     CmpcParams kp = *prm;
     kp.lds_words = (int)(lds_bytes / 4);
+    (void)hipGetLastError();   // (a stale error of an earlier, unrelated runtime call must not be read as this launch's)
     hipLaunchKernelGGL(kern, dim3(prm->B), dim3(nthreads), lds_bytes, stream, kp);
     return (int)hipGetLastError();
 }

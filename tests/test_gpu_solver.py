@@ -449,8 +449,8 @@ def test_failed_scratch_allocation_is_an_error_not_a_crash():
 
 
 def test_tail_polish_only_moves_the_tail(monkeypatch):
-    """cmpc_config.tail_stages: the stages before the tail are bit-identical with and without the polish (it holds the state
-    entering the tail), and where it ran the last knots move towards the oracle."""
+    """cmpc_config.tail_stages: problems whose tail is not polished are bit-identical with and without it; where it ran, the
+    stages before the tail barely move and the last knots move towards the oracle."""
     B = 256
     cfg, P, X0 = cm.synthetic.config5_footstep_candidates(B, seed=77)
     N, L = cfg.N, cm.Layout(cfg.N)
@@ -465,11 +465,12 @@ def test_tail_polish_only_moves_the_tail(monkeypatch):
     assert polished.any() and (infa[:, 3] < 100000).all()
     np.testing.assert_array_equal(infa[:, 0], infb[:, 0])                # the polish is not counted as an iteration
     np.testing.assert_array_equal(Xa[~polished], Xb[~polished])
+    # the stages before the tail take the same extrapolation step, at a step length limited by their own rows only: (nearly) the same numbers
     k0 = N - 3
     for c in range(2):
         for j in range(4):
-            np.testing.assert_array_equal(L.x_force(Xa, c, j)[:, :k0], L.x_force(Xb, c, j)[:, :k0])
-    np.testing.assert_array_equal(L.x_com(Xa)[:, :k0 + 1], L.x_com(Xb)[:, :k0 + 1])
+            assert np.abs(L.x_force(Xa, c, j)[:, :k0] - L.x_force(Xb, c, j)[:, :k0]).max() < 1e-3
+    assert np.abs(L.x_com(Xa)[:, :k0 + 1] - L.x_com(Xb)[:, :k0 + 1]).max() < 1e-5
     Xr = _oracle(cfg, P32[polished], X032[polished])
     wa, wb = _worst(cfg, P32[polished], Xa[polished], Xr), _worst(cfg, P32[polished], Xb[polished], Xr)
     assert wb["forces"] < wa["forces"] and wb["dcom"] < wa["dcom"], (wa, wb)

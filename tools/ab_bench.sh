@@ -10,6 +10,6 @@ trap 'cp /tmp/base.so $P/libcmpc_hip.so' EXIT
 for rep in $(seq $REPS); do
   for v in base exp; do
     if [ $v = base ]; then cp /tmp/base.so $P/libcmpc_hip.so; else cp $P/libcmpc_hip_exp.so $P/libcmpc_hip.so; fi
-    python bench.py --workload $WL --no-cpu-baseline --steps 30 --warmup 3 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$v','$WL',d['value'],d['ms_per_step'])"
+    python bench.py --workload $WL --no-cpu-baseline --secondary none --steps 30 --warmup 3 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$v','$WL',d['value'],d['ms_per_step'])"
   done
 done
