@@ -15,7 +15,10 @@ Workloads (BASELINE.json configs):
     config4  65536 Monte-Carlo problems in total (config-3 generator, seed 2), contiguous shards of 65536/N
              problems per GPU (8 x 8192 at N=8)                              (secondary; STRONG scaling)
     config5  B=8192 per GPU, yawed footstep candidates, horizon 30            (secondary; weak)
-plus the single-problem (B=1) solve latency the metric names.
+plus the single-problem (B=1) solve latency the metric names, and
+    rollout  B=1024 per GPU, 60 ticks of the warm-started receding-horizon walking roll-out (the reference's operating mode:
+             is_warm_start_enabled true, ergoCubGazeboV1/centroidal_mpc.ini:9; CentroidalMPCBlock.cpp:586-631 + the plant of
+             WholeBodyQPBlock.cpp:1083-1150): seven launches per tick, everything resident in HBM            (secondary; weak)
 """
 import argparse
 import json
@@ -43,7 +46,7 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=0, help="problems per GPU of the primary workload (0: its BASELINE size)")
     ap.add_argument("--workload", default="config2", choices=["config2", "config3", "config4", "config5"])
-    ap.add_argument("--secondary", default="config3,config5,config4,latency",
+    ap.add_argument("--secondary", default="config3,config5,config4,latency,rollout",
                     help="comma list of extra workloads reported under `secondary` ('' or 'none': skip)")
     ap.add_argument("--secondary-steps", type=int, default=5)
     ap.add_argument("--cpu-sample", type=int, default=6144)
@@ -262,6 +265,41 @@ class Runner:
                 "ms_per_iteration": round(float(ms.sum() / np.sum(its)), 4)}
 
 
+    def rollout(self, B=1024, ticks=60):
+        """The reference's operating mode, timed end to end: every tick = merge the planner's footsteps with the MPC-adjusted current
+        contact, sample the list, write the measured state, shift the previous solution, solve (warm), adjust the next footstep,
+        integrate the plant -- seven launches, then the host reads the status word (as the reference reads advance()'s bool).
+        Same discipline as run(): barrier + synchronize on both sides of the timed region, max over ranks."""
+        torch, cm = self.torch, self.cm
+        cfg = cm.config.ergocub_gazebo_v1(20, 0.06)
+        rng = np.random.default_rng(9 + 1000 * self.rank)
+        com0 = np.array([0.0, 0.0, 0.7]) + rng.uniform(-0.01, 0.01, (B, 3))
+        dcom0 = rng.uniform(-0.05, 0.05, (B, 3)); h0 = rng.uniform(-0.02, 0.02, (B, 3))
+        push = np.zeros((B, 3)); push[:, :2] = rng.uniform(-30.0, 30.0, (B, 2)) / cm.synthetic.ROBOT_MASS
+        ro = cm.rollout.WalkingRollout(cfg, B, plan=cm.rollout.walking_plan(cfg, steps=6), device=self.devidx)
+        ro.run(2, com0, dcom0, h0, push=push, push_ticks=3, record="light")        # untimed warm-up
+        self.barrier()
+        t0 = time.perf_counter()
+        rec = ro.run(ticks, com0, dcom0, h0, push=push, push_ticks=3, record="light")
+        self.barrier()
+        elapsed = self.max_over_ranks(time.perf_counter() - t0)
+        ms = np.array(rec["tick_ms"])
+        pr = np.array(self.gather_floats([float(np.sum(rec["unconverged"])), float(np.max(rec["iterations_max"])), float(np.mean(rec["iterations_mean"])),
+                                          float(ms.max()), float(np.median(ms)), float(np.percentile(ms, 99))]))
+        ro.solver.close()
+        return {"workload": f"warm-started receding-horizon walking roll-out: batch={B}/GPU x {ticks} ticks (3.6 s, six steps, pushes +-30 N for the "
+                            f"first 3 ticks), horizon 20, seven launches per tick (merge, sample, setState, shift, solve, adjust, plant), all in HBM",
+                "value": round(self.world * B * ticks / elapsed, 1), "unit": "solves/s", "scaling": "weak",
+                "ticks_per_s": round(ticks / elapsed, 1), "ticks": ticks, "batch_per_gpu": B,
+                "tick_latency_ms": {"p50": round(float(np.median(pr[:, 4])), 3), "p99": round(float(pr[:, 5].max()), 3), "max": round(float(pr[:, 3].max()), 3),
+                                    "what": "wall clock of one tick on one rank: seven launches + the host's read of the status word"},
+                "iterations_mean_per_tick": round(float(pr[:, 2].mean()), 2), "iterations_max": int(pr[:, 1].max()),
+                "iterations_mean_first_ticks": [round(v, 2) for v in rec["iterations_mean"][:20]],
+                "iterations_max_by_tick": rec["iterations_max"],
+                "unconverged": int(pr[:, 0].sum()), "merge_ok": bool(all(rec["merge_ok"])),
+                "warm_policy": "warm-started pass budget 14 iterations, then the problem starts again from the cold start inside the launch"}
+
+
 # ---- the CPU leg: the only place the oracle (test infrastructure) is used, as baseline and as checker ------------
 def cpu_baseline(cfg, P32, X032, tol, mu_min, sample):
     """oracle/ipm_ref.c (float64 port of the same algorithm) on the host cores, OpenMP over a bounded sample of the
@@ -326,6 +364,9 @@ def main():
             if R.rank == 0:
                 secondary["single_problem_latency"] = R.latency()
             continue
+        if s == "rollout":
+            secondary["rollout"] = R.rollout()
+            continue
         sm, sd = R.run(s, args.secondary_steps, 2)
         secondary[s] = sm
         if R.rank == 0 and R.world == 1 and not args.no_cpu_baseline:
@@ -335,15 +376,17 @@ def main():
     if R.rank == 0:
         # secondaries: HBM bytes per launch from the committed PMC passes of the same workload, where one exists
         for wl, sm in secondary.items():
-            fn = os.path.join(ROOT, "profiles", f"r02_pmc_summary_{wl}.json")
-            if isinstance(sm, dict) and "roofline" in sm and os.path.exists(fn) and R.world == 1:
+            import glob
+            fns = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_summary_{wl}.json")))
+            fn = fns[-1] if fns else ""
+            if isinstance(sm, dict) and "roofline" in sm and fn and R.world == 1:
                 try:
                     pm = json.load(open(fn))
                     if abs(pm.get("algorithmic_bytes_per_launch", 0) - sm["roofline"]["algorithmic_hbm_bytes_per_launch"]) < 1:
                         sm["roofline"]["traffic"] = pm["hbm_bytes_per_launch"]
                         sm["roofline"]["hbm_GBps"] = round(pm["hbm_bytes_per_launch"] / (sm["roofline"]["kernel_ms_avg"] * 1e-3) / 1e9, 1)
                         sm["roofline"]["valu_active_over_wave_cycles"] = round(pm["derived"]["valu_active_over_wave_cycles"], 3)
-                        sm["roofline"]["traffic_source"] = f"profiles/r02_pmc_summary_{wl}.json (committed rocprofv3 --pmc passes; not measured in this run)"
+                        sm["roofline"]["traffic_source"] = f"{os.path.relpath(fn, ROOT)} (committed rocprofv3 --pmc passes; not measured in this run)"
                         sm["roofline"]["traffic_note"] = ("HBM-factor variant: per-stage factor records, slacks and multipliers stream through L2/HBM "
                                                           "(three workgroups per CU); not re-reads of the inputs")
                 except Exception:

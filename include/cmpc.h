@@ -109,7 +109,8 @@ int cmpc_solve_device(cmpc_handle h, const float* dP, const float* dX0, float* d
 int cmpc_solve_device_warm(cmpc_handle h, const float* dP, const float* dX0, float* dX, float* dInfo,
                            void* stream);
 /* What a warm-started problem that does not converge costs (both cmpc_solve_device_warm and the class path): warm_budget =
- * iterations the warm-started pass may take (0: max_iterations); restart_in_kernel != 0 (default): such a problem is then
+ * iterations the warm-started pass may take (0: max_iterations; default 14: healthy warm ticks of the walking roll-out need at
+ * most 13, and a tick is as slow as its slowest problem); restart_in_kernel != 0 (default): such a problem is then
  * started again from the cold start inside the same launch (info: safeguards += 10000); 0: it comes back with status 1 and
  * the caller re-solves it -- in a batch, the few stragglers of a tick in a small launch of their own (one CU each) instead of
  * one workgroup holding its CU for two budgets.  The reference can only abort the tick (CentroidalMPCBlock.cpp:615-619). */

@@ -55,7 +55,7 @@ struct cmpc_handle_s {
     bool have_solution = false, x0_set = false;
     bool warm = false;           // class path only (cmpc_set_initial_guess(.., 1) -> cmpc_advance): the handle's own dX0 is a shifted previous solution
     double mu_warm = 1e-2, floor_warm = 1e-2;  // measured: 1e-2 saves 35 % (standing) / 15 % (walking) of the iterations; 1e-4 can stall
-    int warm_budget = 0, warm_no_restart = 0;   // cmpc_set_warm_policy (CmpcParams)
+    int warm_budget = 14, warm_no_restart = 0;  // cmpc_set_warm_policy (CmpcParams); 14: measured on the walking roll-out (profiles/r03_walking_rollout.txt)
     bool force_warm = false;     // developer knob CMPC_FORCE_WARM (read once, at cmpc_create)
     float mu_adapt = 3.5f;       // cold starts: mu0 = clamp(mu_adapt ep0^2, 0.03, 0.5) (developer knob CMPC_MU_ADAPT, read once)
     size_t lds = 0;

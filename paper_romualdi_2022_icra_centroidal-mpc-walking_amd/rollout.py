@@ -34,13 +34,23 @@ def walking_plan(cfg, steps=6, step_length=0.1, swing=0.48, double_support=0.12,
 
 
 class WalkingRollout:
-    def __init__(self, cfg, batch, plan=None, device=0, substeps=6, com_speed=None, **solver_opts):
+    """warm_budget / retry: what a warm-started problem that does not converge costs its tick (include/cmpc.h, cmpc_set_warm_policy).
+    warm_budget = iterations of the warm-started pass (0: the full budget; 14 = the library's default); retry = "kernel": such a problem starts again from the cold
+    start inside the same launch (one workgroup holds its CU for two budgets); "launch": it comes back unconverged and the tick's few
+    stragglers are solved again from the cold start in a small launch of their own (a CU each); None: they stay unconverged -- which is all
+    the reference can do: its advance() returns false and the tick is aborted (CentroidalMPCBlock.cpp:615-619)."""
+
+    def __init__(self, cfg, batch, plan=None, device=0, substeps=6, com_speed=None, warm_budget=14, retry="kernel", retry_batch=256, **solver_opts):
         import torch
         self.torch = torch
         self.cfg, self.B = cfg, batch
         self.L = Layout(cfg.N)
         self.dev = torch.device("cuda", device)
         self.solver = BatchSolver(cfg, batch, device=device, **solver_opts)
+        assert retry in ("kernel", "launch", None)
+        self.retry, self.retry_batch = retry, min(retry_batch, batch)
+        self.solver.set_warm_policy(warm_budget, restart_in_kernel=(retry == "kernel"))
+        self.solver2 = BatchSolver(cfg, self.retry_batch, device=device, **solver_opts) if retry == "launch" else None
         plan = plan or walking_plan(cfg)
         t, pose, n = pack_lists(cfg, [plan])
         M = t.shape[2] + 1     # the merged list holds at most the current contact + the planner's future contacts
@@ -57,10 +67,12 @@ class WalkingRollout:
             com_speed = last / t_last if t_last > 0 else 0.0
         self.com_speed = com_speed
 
-    def run(self, ticks, com0, dcom0, h0, push=None, push_ticks=0, warm=True, dump=None, replan=None, slow=None):
+    def run(self, ticks, com0, dcom0, h0, push=None, push_ticks=0, warm=True, dump=None, replan=None, slow=None, record="full"):
         """com0/dcom0/h0 [B,3] numpy; push [B,3] (mass-normalised force held for the first `push_ticks` ticks);
         replan {tick: (t, pose, n)}: the planner's lists from that tick on (the reference's generator re-plans while walking);
-        slow (threshold, list): developer hook -- (tick, problem, P row, X0 row, info row) of every solve with more iterations.
+        slow (threshold, list): developer hook -- (tick, problem, P row, X0 row, info row) of every solve with more iterations;
+        record "full": per-tick CoM, ZMP, landing offsets (host loops over the batch); "light": iteration statistics and the tick's
+        wall-clock latency only (what bench.py times).
         Returns a dict of per-tick numpy records."""
         torch, L, cfg, B, N = self.torch, self.L, self.cfg, self.B, self.cfg.N
         dt = cfg.sampling_time
@@ -74,12 +86,16 @@ class WalkingRollout:
         wrench = torch.zeros((B, N, 6), dtype=torch.float32, device=dev)
         dpush = torch.from_numpy(np.asarray(push, np.float32)).to(dev) if push is not None else None
         kk = torch.arange(N + 1, dtype=torch.float32, device=dev)
-        rec = dict(iterations_mean=[], iterations_max=[], converged=[], merge_ok=[], com=[], land=[], landing_offset=[], solve_ms=[], zmp=[])
+        import time
+        rec = dict(iterations_mean=[], iterations_max=[], converged=[], merge_ok=[], com=[], land=[], landing_offset=[], solve_ms=[], zmp=[],
+                   tick_ms=[], retried=[], unconverged=[])
         mpc_prev = None
         box_up = np.array([c.bounding_box_upper_limit for c in cfg.contacts])
         box_lo = np.array([c.bounding_box_lower_limit for c in cfg.contacts])
         for i in range(ticks):
             now = i * dt
+            torch.cuda.synchronize()
+            t_tick = time.perf_counter()
             if replan and i in replan:
                 self.plan = replan[i]
             if mpc_prev is None:
@@ -117,11 +133,33 @@ class WalkingRollout:
             if dump is not None and i == dump[0]:   # developer hook: (tick, path) -> the tick's P and X0
                 np.savez(dump[1], P=dP.cpu().numpy(), X0=dX0.cpu().numpy())
             s.solve_device(dP, dX0, dX, dInfo, warm=shifted)
+            nretry = 0
+            if self.retry == "launch" and shifted:
+                bad = (dInfo[:, 5] != 0).nonzero().flatten()        # (one scalar comes to the host: the count)
+                nretry = int(bad.numel())
+                for lo in range(0, nretry, self.retry_batch):
+                    chunk = bad[lo:lo + self.retry_batch]
+                    idx = torch.cat([chunk, chunk[:1].expand(self.retry_batch - chunk.numel())]) if chunk.numel() < self.retry_batch else chunk
+                    P2 = dP.index_select(0, idx)
+                    X02 = torch.zeros((self.retry_batch, L.nx), dtype=torch.float32, device=dev)       # the cold start of SURVEY 8d
+                    X02[:, L.com:L.com + 3 * (N + 1)] = P2[:, L.p_com0:L.p_com0 + 3].repeat(1, N + 1)
+                    for c in range(2):
+                        X02[:, L.pos[c]:L.pos[c] + 3 * (N + 1)] = P2[:, L.p_nom[c]:L.p_nom[c] + 3 * (N + 1)]
+                        for j in range(4):
+                            X02[:, L.f[c][j] + 2:L.f[c][j] + 3 * N:3] = 9.80665 / 8.0
+                    X2, I2 = self.solver2.solve_device(P2, X02)
+                    I2[:, 0] += dInfo.index_select(0, idx)[:, 0]     # iterations of both attempts
+                    I2[:, 3] += 10000.0                              # safeguard word: solved again from the cold start
+                    dX.index_copy_(0, chunk, X2[:chunk.numel()])
+                    dInfo.index_copy_(0, chunk, I2[:chunk.numel()])
             s.contacts_adjust_device(now, dX, land, lists)
             mpc_prev = lists
             state, zmp = s.plant_step_device(dX, dP, state, step=dt / self.substeps, substeps=self.substeps)
             torch.cuda.synchronize()
+            rec["tick_ms"].append((time.perf_counter() - t_tick) * 1e3)
+            rec["retried"].append(nretry)
             info = dInfo.cpu().numpy()
+            rec["unconverged"].append(int((info[:, 5] != 0).sum()))
             if slow is not None:
                 for b in np.where(info[:, 0] > slow[0])[0]:
                     slow[1].append((i, int(b), dP[b].cpu().numpy(), dX0[b].cpu().numpy(), info[b].copy()))
@@ -131,6 +169,8 @@ class WalkingRollout:
             rec.setdefault("failed_info", []).append(info[info[:, 5] != 0])
             rec["merge_ok"].append(bool(ok.cpu().numpy().all()))
             rec["solve_ms"].append(s.last_solve_ms())
+            if record != "full":
+                continue
             rec["com"].append(state[:, 0:3].cpu().numpy())
             rec["zmp"].append(zmp.cpu().numpy())
             ln = land.cpu().numpy()

@@ -127,6 +127,13 @@ class BatchSolver:
             raise RuntimeError(f"cmpc_solve failed ({rc}): {self.last_error}")
         return X, info, rc
 
+    def set_warm_policy(self, warm_budget: int = 0, restart_in_kernel: bool = True):
+        """cmpc_set_warm_policy: iteration budget of a warm-started pass (0: max_iterations) and whether a warm start that does not
+        converge is started again from the cold start inside the launch (True) or returned with status 1 (False)."""
+        rc = self._lib.cmpc_set_warm_policy(self._h, int(warm_budget), 1 if restart_in_kernel else 0)
+        if rc != 0:
+            raise RuntimeError(f"cmpc_set_warm_policy failed ({rc}): {self.last_error}")
+
     def last_solve_ms(self) -> float:
         return float(self._lib.cmpc_last_solve_ms(self._h))
 

@@ -148,7 +148,7 @@ def standing_known_answer(N=12, dt=0.1, which="tmp"):
     return _finish(cfg, sched, com0, dcom0, np.zeros((1, 3)), ref, np.zeros((1, N + 1, 3)))
 
 
-def walking_push_n12(which="tmp", B=2, seed=41):
+def walking_push_n12(which="tmp", B=16, seed=41):
     """N = 12, dt = 0.1 with the weights baked into the reference's generated code (`which`: tmp.c or
     jit_tmpComMiH.c): a swing phase inside the horizon (left Gamma = 1x3, 0x5, 1x4, next footstep +0.1 m) and an
     external push over the first two knots -- the step adjustment is active.  Small on purpose: these problems are
@@ -164,7 +164,7 @@ def walking_push_n12(which="tmp", B=2, seed=41):
     return _finish(cfg, sched, com0, dcom0, h0, ref, np.zeros((B, N + 1, 3)), f_ext)
 
 
-def yawed_steps_n12(which="tmp", B=2, seed=42):
+def yawed_steps_n12(which="tmp", B=16, seed=42):
     """N = 12, dt = 0.1, generated-code weights: two yawed footsteps (R != I in the friction and bounding-box rows)."""
     N, dt = 12, 0.1
     cfg = _cfg.generated_code_weights(which, N, dt)
@@ -182,4 +182,51 @@ def yawed_steps_n12(which="tmp", B=2, seed=42):
     ref = np.zeros((B, N + 1, 3))
     ref[:, :, 0] = 0.1 * s[:, :, 0]
     ref[:, :, 2] = 0.7
+    return _finish(cfg, sched, com0, dcom0, h0, ref, np.zeros((B, N + 1, 3)))
+
+
+def push_recovery_n12(which="tmp", B=16, seed=43):
+    """N = 12, dt = 0.1, generated-code weights: both feet on the ground and a horizontal push of 120-220 N (2.1-3.9 N/kg against a
+    friction limit of mu g = 3.2 N/kg) over the first three knots -- friction rows are ACTIVE at the optimum (push recovery on the
+    edge of the cone)."""
+    N, dt = 12, 0.1
+    cfg = _cfg.generated_code_weights(which, N, dt)
+    rng = np.random.default_rng(seed)
+    sched = _tile(sample_schedule(cfg, _standing_lists(cfg, N * dt)), B)
+    com0, dcom0, h0 = _perturbed_state(rng, B, (0.0, 0.0, 0.7))
+    ref = np.broadcast_to(np.array([0.0, 0.0, 0.7]), (B, N + 1, 3)).copy()
+    ang, mag = rng.uniform(0.0, 2.0 * np.pi, B), rng.uniform(120.0, 220.0, B) / ROBOT_MASS
+    f_ext = np.zeros((B, N, 3))
+    f_ext[:, :3, 0] = (mag * np.cos(ang))[:, None]
+    f_ext[:, :3, 1] = (mag * np.sin(ang))[:, None]
+    return _finish(cfg, sched, com0, dcom0, h0, ref, np.zeros((B, N + 1, 3)), f_ext)
+
+
+def single_support_end_n12(which="tmp", B=16, seed=44):
+    """N = 12, dt = 0.1, generated-code weights: the left foot lifts at knot 7-9 and is still in the air at the end of the horizon
+    (single support at the horizon end: the landing row constrains the last knot only, landing knot = N); small pushes."""
+    N, dt = 12, 0.1
+    cfg = _cfg.generated_code_weights(which, N, dt)
+    rng = np.random.default_rng(seed)
+    scheds = []
+    for _ in range(B):
+        lift = int(rng.integers(7, 10))
+        scheds.append(sample_schedule(cfg, _walking_lists(cfg, lift, N, step=float(rng.uniform(0.05, 0.12)))))
+    sched = {k: np.stack([sc[k] for sc in scheds]) for k in scheds[0]}
+    com0, dcom0, h0 = _perturbed_state(rng, B, (0.0, -0.02, 0.7))
+    ref = np.broadcast_to(np.array([0.0, -0.04, 0.7]), (B, N + 1, 3)).copy()      # weight shifting onto the stance foot
+    f_ext = np.zeros((B, N, 3))
+    f_ext[:, :2, :2] = (rng.uniform(-25.0, 25.0, (B, 2)) / ROBOT_MASS)[:, None, :]
+    return _finish(cfg, sched, com0, dcom0, h0, ref, np.zeros((B, N + 1, 3)), f_ext)
+
+
+def standing_n12(which="tmp", B=16, seed=45):
+    """N = 12, dt = 0.1, generated-code weights: a batch of the standing problem of SURVEY 8c (iii) with perturbed initial states
+    (config 2 at the horizon and weights of the reference's generated code)."""
+    N, dt = 12, 0.1
+    cfg = _cfg.generated_code_weights(which, N, dt)
+    rng = np.random.default_rng(seed)
+    sched = _tile(sample_schedule(cfg, _standing_lists(cfg, N * dt)), B)
+    com0, dcom0, h0 = _perturbed_state(rng, B, (0.0, 0.0, 0.7))
+    ref = np.broadcast_to(np.array([0.0, 0.0, 0.7]), (B, N + 1, 3)).copy()
     return _finish(cfg, sched, com0, dcom0, h0, ref, np.zeros((B, N + 1, 3)))

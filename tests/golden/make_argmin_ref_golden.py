@@ -5,8 +5,8 @@ minimises exactly what IPOPT minimises in the reference (N = 12, dt = 0.1 and th
 
     python tests/golden/make_argmin_ref_golden.py          (build container only: needs /root/reference)
 
-Problems: a swing phase with a push (step adjustment active) and two yawed footsteps (R != I), each with both baked
-weight sets.  Stored: float32 inputs (P, X0), the float64 argmin, the multipliers of every constraint row, the
+Problems, 16 of each with both baked weight sets (160 in all): a swing phase with a push (step adjustment active), two yawed
+footsteps (R != I), push recovery with active friction rows, single support at the horizon end, the standing problem.  Stored: float32 inputs (P, X0), the float64 argmin, the multipliers of every constraint row, the
 objective, and the KKT residuals of the stored point evaluated with the reference's code (stationarity, feasibility,
 complementarity, smallest eigenvalue of the Hessian reduced to the null space of the active constraints).
 These are data (vectors), not reference source."""
@@ -32,10 +32,15 @@ def kkt_report(ref, x, lam, p, lb, ub):
     ineq = ub - lb > 1e-12
     dist = np.minimum(g - lb, ub - g)
     compl = np.abs(lam[ineq] * dist[ineq]).max() / scale
-    # multiplier signs: lam <= 0 may only sit on the lower bound, lam >= 0 on the upper (g <= ub active => lam >= 0)
-    at_ub = np.abs(g - ub) <= 1e-7
-    at_lb = np.abs(g - lb) <= 1e-7
-    sign_ok = bool(((lam[ineq & ~at_ub] <= 1e-7 * scale) | at_lb[ineq & ~at_ub] | (np.abs(lam[ineq & ~at_ub]) <= 1e-7 * scale)).all())
+    # multiplier signs (lam^T g enters the Lagrangian with +): a row bounded above only carries lam >= 0, below only lam <= 0, and a
+    # two-sided row a multiplier of the sign of its NEARER bound (a weakly active row of an interior-point solution sits t = mu / lam
+    # off its bound: "at the bound to 1e-7" is the wrong test for it, the complementarity product above is the right one)
+    tol = 1e-7 * scale
+    up_only, lo_only = ineq & (lb < -1e19), ineq & (ub > 1e19)
+    two = ineq & ~up_only & ~lo_only
+    nearer_ub = (ub - g) < (g - lb)
+    sign_ok = bool((lam[up_only] >= -tol).all() and (lam[lo_only] <= tol).all()
+                   and ((np.abs(lam[two]) <= tol) | ((lam[two] > 0) == nearer_ub[two])).all())
     # second order: Hessian of the Lagrangian on the null space of the active constraint gradients
     H = ref.hess_l(x, p, 1.0, lam)
     active = (~ineq) | (np.abs(lam) > 1e-7 * scale)
@@ -75,3 +80,6 @@ if __name__ == "__main__":
     for which in ("tmp", "jit"):
         make("walk", which, cm.synthetic.walking_push_n12)
         make("yaw", which, cm.synthetic.yawed_steps_n12)
+        make("push", which, cm.synthetic.push_recovery_n12)
+        make("ssend", which, cm.synthetic.single_support_end_n12)
+        make("stand", which, cm.synthetic.standing_n12)

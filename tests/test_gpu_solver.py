@@ -54,7 +54,7 @@ def test_matches_golden(name, golden_dir):
     s.close()
 
 
-@pytest.mark.parametrize("name,which", [("walk", "tmp"), ("walk", "jit"), ("yaw", "tmp"), ("yaw", "jit")])
+@pytest.mark.parametrize("name,which", [(n, w) for n in ("walk", "yaw", "push", "ssend", "stand") for w in ("tmp", "jit")])
 def test_matches_argmin_computed_on_the_reference_code(name, which, golden_dir):
     """N = 12, dt = 0.1 goldens solved on the reference's own compiled NLP functions (swing + push, yawed footsteps; both
     baked weight sets; tests/golden/make_argmin_ref_golden.py), every knot of every quantity."""

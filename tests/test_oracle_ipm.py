@@ -108,15 +108,17 @@ def test_hip_arithmetic_model_meets_tolerance(name, golden_dir):
 
 
 # ---- argmin vectors computed on the reference's own compiled NLP functions (tests/golden/make_argmin_ref_golden.py) ----
-REF_CASES = [("walk", "tmp"), ("walk", "jit"), ("yaw", "tmp"), ("yaw", "jit")]
-REF_GEN = {"walk": cm.synthetic.walking_push_n12, "yaw": cm.synthetic.yawed_steps_n12}
+REF_GEN = {"walk": cm.synthetic.walking_push_n12, "yaw": cm.synthetic.yawed_steps_n12, "push": cm.synthetic.push_recovery_n12,
+           "ssend": cm.synthetic.single_support_end_n12, "stand": cm.synthetic.standing_n12}
+REF_CASES = [(n, w) for n in REF_GEN for w in ("tmp", "jit")]        # 16 problems per type and baked weight set: 160 argmins
 
 
 @pytest.mark.parametrize("name,which", REF_CASES)
 def test_reference_solved_goldens_satisfy_kkt_on_the_reference_code(name, which, golden_dir):
-    """Swing + push and yawed-footstep problems at N = 12 with both baked weight sets: first- and second-order optimality
-    of the stored argmin, evaluated with the reference's compiled code where it is present (oracle/_ref) and with the
-    restatement (nlp_ref.c) always."""
+    """Five problem types at N = 12 (swing + push, yawed footsteps, push recovery with active friction rows, single support at the
+    horizon end, standing), 16 of each, both baked weight sets: first-order optimality of every stored argmin and second-order
+    optimality of every fourth (the generator asserted it for all 160 on the reference's code), evaluated with the reference's
+    compiled code where it is present (oracle/_ref) and with the restatement (nlp_ref.c) always."""
     d = np.load(os.path.join(golden_dir, f"argmin_ref_{name}_{which}.npz"))
     cfg, P, X0 = REF_GEN[name](which)
     np.testing.assert_array_equal(P.astype(np.float32), d["P"])      # the committed generator makes these inputs
@@ -148,8 +150,13 @@ def test_reference_solved_goldens_satisfy_kkt_on_the_reference_code(name, which,
             assert (g >= lb - 1e-8).all() and (g <= ub + 1e-8).all()             # feasibility
             ineq = ub - lb > 1e-12
             assert (np.abs(lam[ineq] * np.minimum(g[ineq] - lb[ineq], ub[ineq] - g[ineq])) <= 1e-7 * scale).all()
-            at_ub = np.abs(g - ub) <= 1e-7
-            assert (lam[ineq & ~at_ub] <= 1e-7 * scale).all()                    # a positive multiplier only on an active upper bound
+            tol = 1e-7 * scale          # multiplier signs: >= 0 on rows bounded above only (friction), the sign of the nearer bound on two-sided rows
+            up_only, lo_only = ineq & (lb < -1e19), ineq & (ub > 1e19)
+            two = ineq & ~up_only & ~lo_only
+            assert (lam[up_only] >= -tol).all() and (lam[lo_only] <= tol).all()
+            assert ((np.abs(lam[two]) <= tol) | ((lam[two] > 0) == ((ub - g) < (g - lb))[two])).all()
+            if b % 4:
+                continue
             active = (~ineq) | (np.abs(lam) > 1e-7 * scale)
             _, sv, Vt = np.linalg.svd(J[active], full_matrices=True)
             Z = Vt[int((sv > 1e-9 * sv[0]).sum()):].T
