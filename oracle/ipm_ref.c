@@ -18,6 +18,8 @@
  *     force as extra state (the force-rate cost couples f_k and f_{k-1}): nx = 15+24, nu = 24+6.
  *   - exact Lagrangian Hessian (bilinear momentum term) with Gauss-Newton fallback when a stage
  *     Cholesky meets a non-positive pivot.
+ *   - a converged solve ends with one affine-scaling step (mu -> 0, primal only); optionally (opts.tail_stages, what the HIP
+ *     kernel ships) the last stages are then re-solved on their own with per-row barrier targets: tail_polish() below.
  * Compiled twice: REAL=double (oracle / CPU baseline) and REAL=float (precision study).
  */
 #include "cmpc_oracle.h"

@@ -15,9 +15,10 @@
 // Hessian Quu through its Cholesky (barrier terms z/t span 1e-6..1e9 inside one corner's block
 // next to cost curvature of order 10).  Costates are float32: they only enter the exact-Hessian term.
 //
-// Structure.  The kernel body is a driver; the phases live in out-of-line device functions (register
-// allocations of their own) handed the LDS base: two per backward stage (stage_mid: phase 3;
-// stage_post_pre: phase 4 and phases 1-2 of the next stage), one per sweep.  Two variants: "resident"
+// Structure.  The kernel body is control flow over a dozen scalars; EVERY pass lives in an out-of-line device function (a register
+// allocation of its own) handed the LDS base, from which it rebuilds the LDS map: set-up, initial iterate, residuals, multiplier
+// rescaling, two per backward stage (stage_mid: phase 3; stage_post_pre: phase 4 and phases 1-2 of the next stage), one per sweep,
+// step lengths, corrector targets, update + step norms, the last step (extrapolation + tail polish), export.  Two variants: "resident"
 // (512 threads, per-stage factor records in LDS, one workgroup per CU, B <= #CU) and "HBM-factor" (256
 // threads, records in global scratch, three workgroups per CU).  One stage of the backward sweep (wave
 // numbers of the four-wave shape; 4 barriers):

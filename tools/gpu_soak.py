@@ -9,7 +9,7 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 seeds = range(100, 100 + (int(sys.argv[2]) if len(sys.argv) > 2 else 10))
 for name, gen in (("cfg2", cm.synthetic.config2_perturbed_com), ("cfg3", cm.synthetic.config3_external_push),
                   ("cfg4", cm.synthetic.config4_monte_carlo), ("cfg5", cm.synthetic.config5_footstep_candidates)):
-    tot = bad = fb = 0
+    tot = bad = fb = pol = rst = 0
     hist = np.zeros(64, int)
     itmax = 0
     its = []
@@ -19,9 +19,10 @@ for name, gen in (("cfg2", cm.synthetic.config2_perturbed_com), ("cfg3", cm.synt
         if s is None:
             s = cm.BatchSolver(cfg, B)
         X, info, rc = s.solve_host(P.astype(np.float32), X0.astype(np.float32))
-        fb += int((info[:, 3] > 0).sum()); hist += np.bincount(np.minimum(info[:, 0].astype(int), 63), minlength=64)
+        sgw = info[:, 3].astype(np.int64)     # safeguard word (include/cmpc.h): fallbacks + 100 re-centrings + 10000 cold restart + 100000 tail polished
+        fb += int((sgw % 10000 > 0).sum()); rst += int(((sgw // 10000) % 10 > 0).sum()); pol += int((sgw // 100000 > 0).sum()); hist += np.bincount(np.minimum(info[:, 0].astype(int), 63), minlength=64)
         tot += B; bad += int((info[:, 5] != 0).sum()); itmax = max(itmax, int(info[:, 0].max())); its.append(info[:, 0].mean())
         assert np.isfinite(X).all()
-    print(name, "problems", tot, "not converged", bad, "iterations mean %.2f max %d" % (np.mean(its), itmax), "| problems with a fallback (Gauss-Newton / re-centring / cold restart)", fb,
+    print(name, "problems", tot, "not converged", bad, "iterations mean %.2f max %d" % (np.mean(its), itmax), "| problems with a Gauss-Newton fallback or a re-centring", fb, "cold restarts", rst, "tail polished", pol,
           "| iterations >= 14:", int(hist[14:].sum()), "histogram 3..20:", hist[3:21].tolist(), flush=True)
     s.close()
