@@ -133,3 +133,43 @@ def test_walking_rollout_stays_in_hbm_and_on_its_feet():
     it = np.array(rec["iterations_mean"])
     assert it[1:].mean() < it[0], it
     print("iterations per tick (mean):", np.round(it, 2).tolist(), "max:", rec["iterations_max"])
+
+
+def test_warm_policy_budget_restart_and_launch_level_retry():
+    """cmpc_set_warm_policy: a warm-started pass that exhausts its budget is (a) returned with status 1, (b) started again from the
+    cold start inside the launch (safeguard word += 10000), or (c) re-solved by the roll-out in a launch of its own -- with the same
+    answer as a plain cold solve in (b) and (c).  A budget of 3 iterations makes every problem of a landing tick a "straggler"."""
+    import torch
+    cfg, P, X0 = cm.synthetic.config3_external_push(64, seed=5)
+    L = cm.Layout(cfg.N)
+    P32, X032 = P.astype(np.float32), X0.astype(np.float32)
+    s = cm.BatchSolver(cfg, 64)
+    dP, dX0 = torch.from_numpy(P32).cuda(), torch.from_numpy(X032).cuda()
+    Xc, Ic = s.solve_device(dP, dX0)                      # cold reference
+    torch.cuda.synchronize()
+    Xc, Ic = Xc.cpu().numpy(), Ic.cpu().numpy()
+    assert (Ic[:, 5] == 0).all()
+    # the cold-start guess handed over as if it were a shifted solution: far from the central path at mu = 1e-2, 3 iterations are not enough
+    s.set_warm_policy(3, restart_in_kernel=False)
+    Xa, Ia = s.solve_device(dP, dX0, warm=True)
+    torch.cuda.synchronize()
+    Ia = Ia.cpu().numpy()
+    assert (Ia[:, 5] == 1).all() and (Ia[:, 0] == 3).all()
+    s.set_warm_policy(3, restart_in_kernel=True)
+    Xb, Ib = s.solve_device(dP, dX0, warm=True)
+    torch.cuda.synchronize()
+    Xb, Ib = Xb.cpu().numpy(), Ib.cpu().numpy()
+    assert (Ib[:, 5] == 0).all() and ((Ib[:, 3].astype(np.int64) // 10000) % 10 == 1).all()
+    np.testing.assert_array_equal(Ib[:, 0], Ic[:, 0] + 3)            # three warm iterations, then exactly the cold solve
+    np.testing.assert_array_equal(Xb, Xc)
+    # (c) through the roll-out: ticks after the first are warm; with a budget of 3 and retry="launch" every tick re-solves its stragglers
+    B = 32
+    rng = np.random.default_rng(8)
+    com0 = np.array([0.0, 0.0, 0.7]) + rng.uniform(-0.01, 0.01, (B, 3))
+    z = np.zeros((B, 3))
+    ro = cm.rollout.WalkingRollout(cfg, B, warm_budget=3, retry="launch", retry_batch=16)
+    rec = ro.run(4, com0, z, z, record="light")
+    assert all(rec["converged"]) and sum(rec["unconverged"]) == 0 and sum(rec["retried"]) > 0
+    ro2 = cm.rollout.WalkingRollout(cfg, B, warm_budget=3, retry=None)
+    rec2 = ro2.run(3, com0, z, z, record="light")
+    assert sum(rec2["unconverged"]) > 0 and not all(rec2["converged"])
