@@ -35,7 +35,7 @@ sys.path.insert(0, ROOT)
 
 # canonical algorithmic work: F_iter(N) = 4.25e5 * N flop per interior-point iteration
 F_ITER_PER_STAGE = 4.25e5
-PEAK_F32_TFLOPS = 157.3  # MI355X_MICROARCH.md: f32 vector peak (the kernel issues no MFMA: bound = VALU f32)
+PEAK_F32_TFLOPS = 157.3  # MI355X_MICROARCH.md: f32 vector peak = f32-input MFMA peak (phase 4 of the resident variants runs on v_mfma_f32_16x16x4_f32, the rest on the VALU)
 CONFIG4_TOTAL = 65536
 
 
@@ -407,8 +407,8 @@ def main():
         m["roofline"]["traffic"] = traffic
         m["roofline"]["traffic_source"] = (f"{tsrc} (rocprofv3 --pmc passes of this command, committed; not measured in this run)"
                                            if tsrc else None)
-        m["roofline"]["note"] = ("bound = f32 VALU issue (the kernel contains no MFMA instruction; f32-input MFMA peak equals the "
-                                 "vector peak, 157.3 TFLOP/s); flop = executed IP iterations x 4.25e5*N (SURVEY 8d canonical "
+        m["roofline"]["note"] = ("bound = f32 VALU issue (f32-input MFMA -- used for the stage's W^T W in the resident variants -- peaks at the "
+                                 "vector rate, 157.3 TFLOP/s); flop = executed IP iterations x 4.25e5*N (SURVEY 8d canonical "
                                  "count); HBM traffic is ~11 KB/solve")
         out = {
             "metric": "centroidal-MPC solves/sec (batch, horizon=20)",

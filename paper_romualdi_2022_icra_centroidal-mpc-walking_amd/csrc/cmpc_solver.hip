@@ -50,6 +50,9 @@
 #ifndef CMPC_ONE_WAVE_FACTOR
 #define CMPC_ONE_WAVE_FACTOR(FG) (FG)
 #endif
+#ifndef CMPC_PHASE4_MFMA
+#define CMPC_PHASE4_MFMA 1   // phase 4 (W^T W) of the resident variants on v_mfma_f32_16x16x4_f32; 0: the 2x2 register tiles on the VALU everywhere (A/B: DESIGN 6)
+#endif
 #define NTRI 256   // entries of the lower-triangle index table (the users need 210: 2x2 tiles of a 39x39)
 // Per-stage factor record (floats), in LDS or -- FG kernels -- in HBM scratch.  Phase 3 leaves column m of
 // L^{-1} and column j of Ws = L^{-1} Qus in the registers of one lane, so both are stored transposed, one
@@ -88,6 +91,8 @@ __device__ float g_trace[64 * 8];  // per iteration of workgroup 0: mu, ep, ec, 
 #define PROF3(slot) do { long long n_ = __builtin_amdgcn_s_memtime(); if (threadIdx.x == (NT >= 512 ? 320 : 192) && blockIdx.x == 0) g_prof[slot] += n_ - pt2_; pt2_ = n_; } while (0)
 #define PROF4(slot) do { long long n_ = __builtin_amdgcn_s_memtime(); if (threadIdx.x == (NT >= 512 ? 256 : 128) && blockIdx.x == 0) g_prof[slot] += n_ - pt2_; pt2_ = n_; } while (0)
 #define PROF2(slot) do { long long n_ = __builtin_amdgcn_s_memtime(); if (threadIdx.x == 0 && blockIdx.x == 0) g_prof[slot] += n_ - pt2_; pt2_ = n_; } while (0)
+// (first lane of the value-gradient wave of phase 4)
+#define PROF5(slot) do { long long n_ = __builtin_amdgcn_s_memtime(); if (threadIdx.x == (NT >= 512 ? 448 : 216) && blockIdx.x == 0) g_prof[slot] += n_ - pt2_; pt2_ = n_; } while (0)
 #else
 #define PROF_DECL
 #define PROF(slot)
@@ -95,6 +100,7 @@ __device__ float g_trace[64 * 8];  // per iteration of workgroup 0: mu, ep, ec, 
 #define PROF2(slot)
 #define PROF3(slot)
 #define PROF4(slot)
+#define PROF5(slot)
 #endif
 
 struct Ctx {
@@ -1075,6 +1081,64 @@ __device__ inline void stage_post_body(const Ctx& c, const CmpcConsts& prm, int 
     const float* u = c.U + NU * k;
     PROF_DECL;
         // ---- phase 4: P = [Qss 0; 0 D] - W^T W  (rows of the panel are W^T rows; p rows pre-scaled by -D) ----
+        // W^T W on the matrix cores in the resident variants (eight waves, one problem per CU: latency counts): the stage's Schur-complement
+        // ("condensing") GEMM, 39 x 39 x 30 -- v_mfma_f32_16x16x4_f32, the six lower-triangle 16 x 16 tiles of the 48 x 48 cover, one tile per
+        // wave.  Both operands of a tile are rows of the panel (row i = column i of W, 32 floats with columns 30, 31 stored as zeros), so lane
+        // (m = lane & 15, kq = lane >> 4) reads TWO float4 per operand -- panel row 16 I + m, floats 4 kq .. 4 kq + 3 and 16 + 4 kq .. -- and
+        // feeds component t of them to MFMA t: the K index a lane group supplies is then a = 4 kq + t (+ 16), the same map for A and B, and the
+        // eight MFMAs cover a = 0 .. 31 once (two accumulators of four: the dependent latency of 40 cycles sits behind the 32-cycle issue).
+        // Result of lane (m, kq), register i: P[16 I + 4 kq + i][16 J + m].  Every LDS read of the tile -- operands and the four values the
+        // products are subtracted from -- is issued before the first wait, branch-free on clamped indices.  Measured (B = 256, phase 4 per
+        // whole solve, A/B inside one gpurun call): +1.6 % against the 2x2 register tiles (32 ds_read_b128 + 120 FMA per thread), see DESIGN 6;
+        // the value gradient keeps its own wave (folded into row 45 of the tiles (2, J) -- the lq row of the panel -- it lengthens those
+        // tiles' epilogue by more than the wave it frees: measured +0.1 % instead of +1.6 %).  The HBM-factor variants (four waves, three workgroups per CU: throughput counts) keep the register tiles: six tiles of a
+        // 48 x 48 cover are twice the arithmetic of the 39 x 39 triangle and two of them per wave -- measured -1.5 % there.
+        if (CMPC_PHASE4_MFMA && !LEAN) {
+            PROF2_DECL;
+            const bool pk4 = k > 0;
+            const int wv4 = tid >> 6, ln = tid & 63, m4 = ln & 15, kq = ln >> 4;
+            const int ncol4 = pk4 ? NXA : NS, ntile = pk4 ? 6 : 1;   // (the first stage of the horizon keeps a 15 x 15 value function)
+            typedef float v4f __attribute__((ext_vector_type(4)));
+            const float D0 = prm.D[0], D1 = prm.D[1], D2 = prm.D[2];
+            for (int t = wv4; t < ntile; t += NT / 64) {
+                const int I = t >= 3 ? 2 : (t >= 1 ? 1 : 0), J = t - I * (I + 1) / 2;
+                const int i0 = 16 * I + 4 * kq, jj = 16 * J + m4;
+                const float* ra = c.Pan + (16 * I + m4) * RLD + 4 * kq;
+                const float* rb = c.Pan + (16 * J + m4) * RLD + 4 * kq;
+                const float4 a0 = *reinterpret_cast<const float4*>(ra), a1 = *reinterpret_cast<const float4*>(ra + 16);
+                const float4 b0 = *reinterpret_cast<const float4*>(rb), b1 = *reinterpret_cast<const float4*>(rb + 16);
+                // what the products are subtracted from: Qss (rows < 15), D on the diagonal of the force block, 0 elsewhere
+                float bs[4];
+                const int jc = jj < NS ? jj : NS;                    // (Qb rows are 16 floats: column 15 is padding)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int ii = i0 + i;
+                    const float qb = Qb[(ii < NS ? ii : NS - 1) * 16 + jc];
+                    const int r3 = ii - 3 * ((ii * 43) >> 7);        // ii % 3 (= (ii - NS) % 3: NS is a multiple of 3)
+                    const float dd = r3 == 0 ? D0 : (r3 == 1 ? D1 : D2);
+                    bs[i] = ii < NS ? qb : (ii == jj ? dd : 0.f);
+                }
+                v4f c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
+                c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, b0.x, c0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, b1.x, c1, 0, 0, 0);
+                c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, b0.y, c0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, b1.y, c1, 0, 0, 0);
+                c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, b0.z, c0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, b1.z, c1, 0, 0, 0);
+                c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, b0.w, c0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, b1.w, c1, 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int ii = i0 + i;
+                    if (jj <= ii && ii < ncol4) {
+                        const float r = bs[i] - (c0[i] + c1[i]);
+                        Pnew[ii * PLD + jj] = r;
+                        Pnew[jj * PLD + ii] = r;
+                    }
+                }
+            }
+            PROF2(18);
+        } else
         {
             // 2x2 output tiles: thread <-> tile (bi, bj), bj <= bi, of the 39x39 (or 15x15) lower triangle.  With 512 threads
             // a tile belongs to a pair of lanes: each takes half of the 30-term dot products (four of the eight float4
@@ -1149,6 +1213,10 @@ __device__ inline void stage_post_body(const Ctx& c, const CmpcConsts& prm, int 
                 if (!SPLIT || khalf == 0) { put(i0, j0, b00, a00); put(i0, j0 + 1, b01, a01); }
                 if (!SPLIT || khalf == 1) { put(i0 + 1, j0, b10, a10); put(i0 + 1, j0 + 1, b11, a11); }
             }
+        }
+        {
+            PROF2_DECL;
+            constexpr bool SPLIT = NT >= 512;
             // gradient of the value function (float64)
             const int ncol = pk ? NXA : NS;
             constexpr int TG = SPLIT ? 448 : 216;    // threads beyond the tile owners (210, or 420 with split tiles)
@@ -1174,6 +1242,7 @@ __device__ inline void stage_post_body(const Ctx& c, const CmpcConsts& prm, int 
                     }
                 }
                 c.pv[i] = v;   // (the value gradient of stage k+1 was last read in phase 2: written in place, one barrier less)
+                PROF5(19);
             }
         }
         __syncthreads();

@@ -6,7 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch  # noqa: F401  (same HIP runtime)
 import cmpc_amd as cm
-cm._capi.LIB_PATH = os.path.join(os.path.dirname(cm._capi.LIB_PATH), "libcmpc_hip_prof.so")
+cm._capi.LIB_PATH = os.path.join(os.path.dirname(cm._capi.LIB_PATH), os.environ.get("CMPC_PROF_LIB", "libcmpc_hip_prof.so"))
 names = ["(ph0: under ph3 now)", "ph1 G", "ph2 Quu,panel,Pd,qu", "ph3 fused chol+solve", "ph4 P update", "ph2/w0: values", "ph2/w0: stores", "ph2/w2: diag blocks", "ph2/w3: qu", "-",
          "residuals", "backward(total)", "fwd1", "steps+muaff", "delta", "fwd2", "steplen+costate", "update+conv"]
 cfg, P, X0 = cm.synthetic.config2_perturbed_com(256)
@@ -20,6 +20,7 @@ print("iters block0", info[0, 0], "total cycles (sum of phases) %.3g" % tot, "ke
 for n, x in zip(names, v):
     print("%-22s %12.0f  %5.1f%%  per stage-iter %8.0f" % (n, x, 100 * x / tot, x / (info[0, 0] * cfg.N)))
 
+print("  ph4 (MFMA build): tiles on wave 0 %8.0f, value gradient on its wave %8.0f per stage-iter" % (out[18] / (info[0, 0] * cfg.N), out[19] / (info[0, 0] * cfg.N)))
 sub = np.array(out[20:31], float)
 for n, x in zip(["fwd: loop head", "fwd: y = lq + Ws ds + Wp dp", "fwd: du = -Linv^T y", "fwd: AB_step",
                  "delta: loop head", "delta: rhs g + B^T fp", "delta: dl = Linv dq", "delta: fp update", "ph3: load rows", "ph3: cholesky+solve", "ph3: store"], sub):
