@@ -1362,11 +1362,12 @@ __device__ int riccati_backward(lds_t lds, const Ctx& c, const CmpcConsts& prm, 
 //             ds+ = A ds + B du + d                               (9 + 6 lanes, corner sums by DPP)
 // Matrix operands do not depend on the recursion: they are read at the top of the stage. ----
 // k0 > 0 (tail polish): the sweep starts at stage k0 with ds_k0 = 0 and the force step before it zero.
-template <int NT, int UNR, bool G>
+// PART 0: the whole of it; 1: the sweep alone (wave 0, no barrier); 2: the barrier and the element-wise part (all threads).
+template <int NT, int UNR, bool G, int PART = 0>
 __device__ void riccati_forward(const Ctx& c, const CmpcConsts& prm, int tid, bool affine, int k0)
 {
     const int N = c.N;
-    if (tid < 64) {
+    if (PART != 2 && tid < 64) {
         const int r = tid & 31, half = tid >> 5, blk = r >> 2;
         float* xb = c.ybuf;       // [ds (15), 1, -D du_prev (24)]
         float* yb = c.ybuf + 40;  // y (32)
@@ -1467,6 +1468,7 @@ __device__ void riccati_forward(const Ctx& c, const CmpcConsts& prm, int tid, bo
             PROF2(23);
         }
     }
+    if (PART == 1) return;
     __syncthreads();
     for (int e = tid + NI * k0; e < N * NI; e += NT) {
         const int k = e / NI, i = e % NI;
@@ -1487,7 +1489,7 @@ __device__ void riccati_forward(const Ctx& c, const CmpcConsts& prm, int tid, bo
 // holds w (0 on inactive rows).  Updates lq (slot 15 of the Ws rows) in place through the stored factors.
 // Per stage:  g = C^T w + fp_p + B^T fp_s ;  dl = L^{-1} g ;  lq += dl ;
 //             fp_s <- A^T fp_s - Ws^T dl ;  fp_p <- D L^{-T} dl ----
-template <int UNR, bool G>
+template <int UNR, bool G, int PART = 0>
 __device__ void riccati_delta(const Ctx& c, const CmpcConsts& prm, int tid)
 {
     const int N = c.N;
@@ -1591,7 +1593,7 @@ __device__ void riccati_delta(const Ctx& c, const CmpcConsts& prm, int tid)
             PROF2(27);
         }
     }
-    __syncthreads();
+    if (PART == 0) __syncthreads();
 }
 
 // largest step lengths keeping t, z positive (fraction tau to the boundary)
@@ -1699,12 +1701,29 @@ __device__ void costate_update(const Ctx& c, const CmpcConsts& prm, int tid, flo
 }
 
 // ---- out-of-line entry points of the sweeps ----
-template <int NT, int NC, bool FG>
-__device__ __attribute__((noinline)) void phase_forward(lds_t lds, int Nrt, float* fg_base, bool affine_in)
+// The two sweeps run on wave 0.  In the HBM-factor variants (168 registers) the sweep functions use 28 / 16 callee-saved registers, which
+// every wave that ENTERS the function saves to and restores from scratch memory: with all four waves calling, 576 scratch operations per
+// workgroup and iteration -- 2.6 GB written and read back per 4096-problem launch, half of what the counters showed as "factor-record
+// traffic" (found in round 3: one saved register per call stood out in SQ_INSTS_VMEM_WR of the resident variant).  So only wave 0 calls the
+// sweep (CMPC_SWEEP_WAVE0_ONLY); the barrier and the element-wise part behind it are a function of their own that needs no callee-saved
+// register.  (Inlining the sweeps into the kernel body instead was measured: 101 VGPRs of the body spilled, some inside the stage loops.)
+#ifndef CMPC_SWEEP_WAVE0_ONLY
+#define CMPC_SWEEP_WAVE0_ONLY(FG) (FG)
+#endif
+template <int NT, int NC, bool FG, int PART>
+__device__ __attribute__((noinline)) void phase_forward_part(lds_t lds, int Nrt, float* fg_base, bool affine_in)
 {
     CMPC_PHASE_PROLOGUE;
     const bool affine = __builtin_amdgcn_readfirstlane((int)affine_in) != 0;
-    riccati_forward<NT, NC == 0 ? 1 : (FG ? 2 : CMPC_SWEEP_UNROLL), FG>(c, prm, tid, affine, 0);
+    riccati_forward<NT, NC == 0 ? 1 : (FG ? 2 : CMPC_SWEEP_UNROLL), FG, PART>(c, prm, tid, affine, 0);
+}
+template <int NT, int NC, bool FG>
+__device__ __forceinline__ void phase_forward(lds_t lds, int Nrt, float* fg_base, bool affine_in)
+{
+    if constexpr (CMPC_SWEEP_WAVE0_ONLY(FG)) {
+        if (threadIdx.x < 64) phase_forward_part<NT, NC, FG, 1>(lds, Nrt, fg_base, affine_in);
+        phase_forward_part<NT, NC, FG, 2>(lds, Nrt, fg_base, affine_in);
+    } else phase_forward_part<NT, NC, FG, 0>(lds, Nrt, fg_base, affine_in);
 }
 template <int NT, int NC, bool FG>
 __device__ __attribute__((noinline)) void phase_forward_tail(lds_t lds, int Nrt, float* fg_base, bool affine_in, int k0_in)
@@ -1714,11 +1733,19 @@ __device__ __attribute__((noinline)) void phase_forward_tail(lds_t lds, int Nrt,
     const int k0 = __builtin_amdgcn_readfirstlane(k0_in);
     riccati_forward<NT, 1, FG>(c, prm, tid, affine, k0);
 }
-template <int NT, int NC, bool FG>
-__device__ __attribute__((noinline)) void phase_delta(lds_t lds, int Nrt, float* fg_base)
+template <int NT, int NC, bool FG, int PART>
+__device__ __attribute__((noinline)) void phase_delta_part(lds_t lds, int Nrt, float* fg_base)
 {
     CMPC_PHASE_PROLOGUE;
-    riccati_delta<NC == 0 ? 1 : (FG ? 2 : CMPC_SWEEP_UNROLL), FG>(c, prm, tid);
+    riccati_delta<NC == 0 ? 1 : (FG ? 2 : CMPC_SWEEP_UNROLL), FG, PART>(c, prm, tid);
+}
+template <int NT, int NC, bool FG>
+__device__ __forceinline__ void phase_delta(lds_t lds, int Nrt, float* fg_base)
+{
+    if constexpr (CMPC_SWEEP_WAVE0_ONLY(FG)) {
+        if (threadIdx.x < 64) phase_delta_part<NT, NC, FG, 1>(lds, Nrt, fg_base);
+        __syncthreads();
+    } else phase_delta_part<NT, NC, FG, 0>(lds, Nrt, fg_base);
 }
 template <int NT, int NC, bool FG>
 __device__ __attribute__((noinline)) void phase_costate(lds_t lds, int Nrt, float* fg_base, float ap, bool exact_in)
@@ -2211,8 +2238,6 @@ __global__ __launch_bounds__(NT, FG ? 3 : 1) void cmpc_solve_kernel(CmpcParams k
             float sigma = 0.f, mu_t = prm.mu_min;
             if (centring) {
                 phase_multipliers<NT, NC, FG>(lds, N, fg_base, 2, prm.mu_min, nrow);
-                phase_forward<NT, NC, FG>(lds, N, fg_base, false);
-                PROF(15);
             } else {
                 phase_forward<NT, NC, FG>(lds, N, fg_base, true);
                 PROF(12);
@@ -2228,9 +2253,9 @@ __global__ __launch_bounds__(NT, FG ? 3 : 1) void cmpc_solve_kernel(CmpcParams k
                 PROF(13);
                 phase_delta<NT, NC, FG>(lds, N, fg_base);
                 PROF(14);
-                phase_forward<NT, NC, FG>(lds, N, fg_base, false);
-                PROF(15);
             }
+            phase_forward<NT, NC, FG>(lds, N, fg_base, false);   // (one call site for both branches: the sweep may be inlined here)
+            PROF(15);
             const StepLen sl = phase_step_lengths<NT, NC, FG>(lds, N, fg_base, fmaxf(0.99f, 1.f - mu_t));
             const float ap = sl.ap, ad = sl.ad;
             // ---- costates, then the iterate ----

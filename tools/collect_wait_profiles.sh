@@ -29,6 +29,7 @@ SQ_WAVE_CYCLES SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_ADDR_CONFLICT SQ_LD
 TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_READ_sum
 TCC_WRITE_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum TCC_WRITEBACK_sum
 TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_LATENCY_sum
+SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU_MFMA_F32 SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU
 GROUPS
 grep -i -E "barrier|WAIT" $REPO/gpurun_out/counters_list.txt | head -60 > $OUT/wait_counter_names.txt || true
 echo "collected $WL"

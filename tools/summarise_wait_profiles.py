@@ -47,6 +47,14 @@ if wc:
     d["vmem_in_flight_per_wave"] = g("SQ_INST_LEVEL_VMEM") / wc
     d["smem_in_flight_per_wave"] = g("SQ_INST_LEVEL_SMEM") / wc
     d["lds_bank_conflict_share_of_lds_active"] = g("SQ_LDS_BANK_CONFLICT") / max(g("SQ_LDS_IDX_ACTIVE"), 1.0)
+if g("SQ_INSTS_MFMA") or g("SQ_INSTS_VALU_MFMA_F32"):
+    # MFMA share: v_mfma_f32_16x16x4_f32 holds the matrix pipe of its SIMD for 32 cycles = 8 quad-cycles per instruction
+    nm = g("SQ_INSTS_VALU_MFMA_F32") or g("SQ_INSTS_MFMA")
+    d["mfma_instructions_per_launch"] = nm
+    d["mfma_share_of_valu_instructions"] = nm / max(g("SQ_INSTS_VALU"), 1.0)
+    d["mfma_pipe_quadcycles_over_wave_cycles"] = 8.0 * nm / max(wc, 1.0)
+    if g("SQ_VALU_MFMA_BUSY_CYCLES") and g("SQ_BUSY_CYCLES"):
+        d["mfma_busy_over_sq_busy_cycles"] = g("SQ_VALU_MFMA_BUSY_CYCLES") / g("SQ_BUSY_CYCLES")
 hit, miss = g("TCC_HIT_sum"), g("TCC_MISS_sum")
 if hit + miss:
     d["l2_hit_rate"] = hit / (hit + miss)
