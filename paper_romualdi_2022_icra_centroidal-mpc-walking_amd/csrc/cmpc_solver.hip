@@ -924,9 +924,20 @@ __device__ inline void stage_pre_body(const Ctx& c, const CmpcConsts& prm, int t
         // ---- phase 1: G = P [B;E] (39 x 30): thread <-> column, its three non-zeros in registers, rows strided over RG
         // row groups (8 with 256 threads, 16 with 512) ----
         {
-            constexpr int RG = NT / 32, RR = (NXA + RG - 1) / RG;
+            // (eight waves: 14 row groups = 420 threads -- three rows each, as with 16 -- leave the last wave free for Pd = P [d; 0] + pv in float64,
+            // which phase 2's qu wave would otherwise compute first: the longest chain of phase 2, measured 1.97 k of its 2.4 k cycles)
+            constexpr int RG = NT >= 512 ? 14 : NT / 32, RR = (NXA + RG - 1) / RG;
             const int nrow = havep ? NXA : NS;
-            if (tid < RG * NU) {
+            if (NT >= 512 && tid >= 448) {
+                const int r = tid - 448;
+                if (r < NXA) {
+                    double acc = 0.0;
+#pragma unroll
+                    for (int a = 0; a < NS; ++a) acc += (double)Pcur[a * PLD + r] * (double)c.d[NS * k + a];   // (P holds both triangles: row a, column r)
+                    const double pvr = c.pv[r];
+                    c.Pd[r] = (r < NS || havep) ? pvr + acc : pvr;   // (rows >= NS of the terminal P do not exist: discarded)
+                }
+            } else if (tid < RG * NU) {
                 const int i = tid % NU, r0 = tid / NU;
                 const int b0 = c.Brow[3 * i], b1 = c.Brow[3 * i + 1], b2 = c.Brow[3 * i + 2];
                 const float w0 = c.Bval[3 * i], w1 = c.Bval[3 * i + 1], w2 = c.Bval[3 * i + 2];
@@ -1022,7 +1033,7 @@ __device__ inline void stage_pre_body(const Ctx& c, const CmpcConsts& prm, int t
           const bool fr = qfree(c, k, q);
           const int b0 = c.Brow[3 * iq], b1 = c.Brow[3 * iq + 1], b2 = c.Brow[3 * iq + 2];
           const double w0 = c.Bval[3 * iq], w1 = c.Bval[3 * iq + 1], w2 = c.Bval[3 * iq + 2];
-          {
+          if (NT < 512) {   // (eight waves: done in phase 1 on a wave of its own)
             double acc = 0.0;
 #pragma unroll
             for (int a = 0; a < NS; ++a) acc += (double)pc[a] * (double)dc[a];
