@@ -53,6 +53,17 @@
 #ifndef CMPC_PHASE4_MFMA
 #define CMPC_PHASE4_MFMA 1   // phase 4 (W^T W) of the resident variants on v_mfma_f32_16x16x4_f32; 0: the 2x2 register tiles on the VALU everywhere (A/B: DESIGN 6)
 #endif
+// "Square-root" backward stage of the resident eight-wave variants (CMPC_SQ): the value function P = [Qss 0; 0 D] - W^T W is never formed.
+// With T = [B~ A~] (39 x 45, <= 4 non-zeros per column) and Z = W T, the next stage's [Quu Qus; Qsu Qss], qu, qs are
+//   (cost / barrier terms + T^T [Qss 0; 0 D] T)  -  Z^T Z :
+// the bracket needs nothing of this stage's factorisation and is built by the idle waves WHILE it runs; what is left behind it is one sparse
+// row-combination pass (Z) and one 48 x 48 x 32 product on the matrix cores -- two phases and three barriers per stage instead of four and four.
+#ifndef CMPC_SQRT_BACKWARD
+#define CMPC_SQRT_BACKWARD 1
+#endif
+#define CMPC_SQ(NT, FG) (CMPC_SQRT_BACKWARD && !(FG) && (NT) >= 512)
+#define ZLD 36     // leading dim of Z^T (48 rows: 30 u-columns, 15 s-columns, the gradient column, 2 zero rows)
+#define MSET (NU * RLD + NPAN * RLD)   // floats of one set QuuF | Pan (the resident variants hold two: stage k is factorised from set k & 1)
 #define NTRI 256   // entries of the lower-triangle index table (the users need 210: 2x2 tiles of a 39x39)
 // Per-stage factor record (floats), in LDS or -- FG kernels -- in HBM scratch.  Phase 3 leaves column m of
 // L^{-1} and column j of Ws = L^{-1} Qus in the registers of one lane, so both are stored transposed, one
@@ -113,6 +124,8 @@ struct Ctx {
     float *Lf;             // per-stage factor records (REC_N floats each)
     float *geoA;           // N x GEO
     float *P0, *Qb, *G, *QuuF, *Pan, *Bval, *Aval, *arow, *ybuf, *fpv, *fpn;
+    float *ZT;             // (resident variants) Z^T of the square-root backward stage; there Qb and QuuF | Pan exist twice (stride NS * 16, MSET)
+    double *QuuD1, *qs1;   // (resident variants) second set of the float64 diagonal blocks and of qs
     int *Brow, *Arow, *qmask;
     unsigned short* tri;
     double *QuuD, *pv, *pn, *qs, *Pd, *sig, *gco, *redd;
@@ -190,6 +203,8 @@ __device__ inline void make_ctx(Ctx& c, char* smem, int N, float* fg_base)
     c.pv = dp; dp += 40; c.pn = dp; dp += 40; c.qs = dp; dp += 16; c.Pd = dp; dp += 40;
     c.sig = dp; dp += NI; c.gco = dp; dp += NI; dp += 2 * NI;  // (second descriptor set)
     c.redd = dp; dp += 8;
+    c.QuuD1 = c.QuuD; c.qs1 = c.qs;
+    if (!FG) { c.QuuD1 = dp; dp += 90; c.qs1 = dp; dp += 16; }
     float* fp = reinterpret_cast<float*>(dp);
     // workspace of the backward sweep: QuuF | Pan | G | P0 | Qb (5667 floats).  The step arrays dS | dU | dT | dZ live in
     // the same bytes: they are written by the forward sweep and dead again when the next factorisation starts, while the
@@ -197,8 +212,17 @@ __device__ inline void make_ctx(Ctx& c, char* smem, int N, float* fg_base)
     // under a third of a CU's LDS).  NS (N+1) + NU N + 2 NI N <= 5335 floats for N <= CMPC_NMAX.
     c.QuuF = fp; fp += NU * RLD;
     c.Pan = fp; fp += NPAN * RLD;
+    c.ZT = nullptr;
+    if (!FG) {
+        // resident variants: QuuF0 | Pan0 | QuuF1 | Pan1 | Z^T | Qb0 | Qb1 -- G and P0 (only the four-wave developer variant still forms them) lie over set 1 and Z^T
+        c.G = fp; c.P0 = fp + ((NXA * GLD + 3) & ~3);
+        fp += MSET;
+        c.ZT = fp; fp += 48 * ZLD;
+        c.Qb = fp; fp += 2 * NS * 16;
+    } else {
     c.G = fp; fp += (NXA * GLD + 3) & ~3;                   // (sizes rounded to 16 bytes: ybuf and the LDS factor records
     c.P0 = fp; fp += (NXA * PLD + 3) & ~3; c.Qb = fp; fp += NS * 16;   //  behind them are read with ds_read_b128)
+    }
     {
         float* vp = c.QuuF;
         c.dS = vp; vp += NS * (N + 1); c.dU = vp; vp += NU * N; c.dT = vp; vp += NI * N; c.dZ = vp;
@@ -1329,12 +1353,367 @@ __device__ __attribute__((noinline)) void stage_post_pre(lds_t lds, int Nrt, flo
     }
 }
 
+// =====================================================================================================================
+// The square-root backward stage (resident eight-wave variants, CMPC_SQ; see the note at CMPC_SQRT_BACKWARD).
+// Index space of the assembled stage matrix M: [u (30) | s (15) | g (1)].  Stage j is assembled in set j & 1:
+//   uu  lower triangle, float, in QuuF (the slots inside the 3x3 diagonal blocks hold only the -Z^T Z part; their cost / barrier part is float64 in QuuD)
+//   su  Pan rows 0..14 (row s, 30 columns),  gu  Pan row NPAN-1 (qu),  ss  Qb (both triangles),  gs  qs (float64)
+// =====================================================================================================================
+struct Desc3 { int r0, r1, r2; float w0, w1, w2; };
+__device__ inline Desc3 desc_of(const int* rows, const float* vals, int col)
+{
+    Desc3 d;
+    d.r0 = rows[3 * col]; d.r1 = rows[3 * col + 1]; d.r2 = rows[3 * col + 2];
+    d.w0 = vals[3 * col]; d.w1 = vals[3 * col + 1]; d.w2 = vals[3 * col + 2];
+    return d;
+}
+// a^T Q b for two sparse columns (Q: 15 x 15 in rows of 16 floats, both triangles)
+__device__ inline float sandwich(const float* Q, const Desc3& a, const Desc3& b)
+{
+    const float* q0 = Q + 16 * a.r0;
+    const float* q1 = Q + 16 * a.r1;
+    const float* q2 = Q + 16 * a.r2;
+    return a.w0 * (b.w0 * q0[b.r0] + b.w1 * q0[b.r1] + b.w2 * q0[b.r2]) + a.w1 * (b.w0 * q1[b.r0] + b.w1 * q1[b.r1] + b.w2 * q1[b.r2])
+           + a.w2 * (b.w0 * q2[b.r0] + b.w1 * q2[b.r1] + b.w2 * q2[b.r2]);
+}
+
+// ---- the part of stage k's matrix that does not depend on the factorisation of stage k+1:  cost, barrier, Levenberg terms
+// + T^T [Qss 0; 0 D] T (Qss, qs of stage k+1 in Qc, qsc; havep: stage k+1 has a previous-force block, i.e. it is not the terminal stage).
+// 256 threads (t): 0..59 the float64 diagonal blocks of Quu; 64..127 hb = [Qss d + qs; -D (u_k+1 - u_k)] and behind it, on the same wave, qu and qs;
+// then all of them the 405 float tasks: 135 triples of Quu, 150 triples of Qus^T, 120 entries of Qss.  c: descriptor set of stage k selected. ----
+__device__ inline void sq_base_body(const Ctx& c, const CmpcConsts& prm, int t, int k, bool havep, float reg, float* QuuFn, double* QuuDn, float* Pann,
+                                    float* Qbn, double* qsn, const float* Qc, const double* qsc)
+{
+    const bool pk = k > 0;
+    const float* u = c.U + NU * k;
+    const int* Brow = c.Brow;
+    const float* Bval = c.Bval;
+    if (t < 64) {
+        // the ten 3x3 diagonal blocks of Quu in float64 (60 lower entries), branch-free on clamped indices
+        const int tc = t < 60 ? t : 59;
+        const int b = tc / 6, w = tc - 6 * b;
+        const int rr = w >= 3 ? 2 : (w >= 1 ? 1 : 0), cc = w - rr * (rr + 1) / 2;
+        const int i = 3 * b + rr, j = 3 * b + cc;
+        const bool isF = i < NF, dg = i == j;
+        const Desc3 di = desc_of(Brow, Bval, i), dj = desc_of(Brow, Bval, j);
+        const int r0 = isF ? 4 * b : 0;             // friction rows of the corner
+        const int iq = isF ? 0 : i - 24;            // landing-offset component
+        double sg[4], ar[4], ac[4];
+#pragma unroll
+        for (int f = 0; f < 4; ++f) { sg[f] = c.sig[r0 + f]; ar[f] = (double)c.arow[3 * (r0 + f) + rr]; ac[f] = (double)c.arow[3 * (r0 + f) + cc]; }
+        const double slo = c.sig[32 + iq], shi = c.sig[38 + iq];
+        const bool fr = qfree(c, k, iq);
+        const double gam = gam_of(c, isF ? i / 12 : 0, k);
+        const double v = (double)sandwich(Qc, di, dj);
+        double vF = v;
+        if (dg) {
+            vF += 2.0 * prm.w_sym * (1.0 - 0.25 * gam * (2.0 - gam));
+            if (pk) vF += (double)prm.D[i % 3];       // own force-rate cost
+            if (havep) vF += (double)prm.D[i % 3];    // E^T D E: the next stage's force-rate cost
+            vF += (double)reg;
+        }
+#pragma unroll
+        for (int f = 0; f < 4; ++f) vF += sg[f] * ar[f] * ac[f];
+        const double vQ = dg ? (fr ? v + slo + shi + (double)reg : 1.0) : v;   // fixed q: exact identity row
+        if (t < 60) {
+            QuuDn[9 * b + 3 * rr + cc] = isF ? vF : vQ;
+            QuuFn[i * RLD + j] = 0.f;   // the float copy of a diagonal block collects -Z^T Z and the updates by earlier blocks
+        }
+    } else if (t < 128) {
+        const int l = t - 64;
+        double* hb = c.Pd;
+        {
+            const int r = l < NXA ? l : NXA - 1;
+            double hv;
+            if (r < NS) {
+                double acc = 0.0;
+#pragma unroll
+                for (int a = 0; a < NS; ++a) acc += (double)Qc[16 * a + r] * (double)c.d[NS * k + a];
+                hv = qsc[r] + acc;
+            } else {
+                const int m = r - NS;
+                hv = havep ? -(double)prm.D[m % 3] * ((double)c.U[NU * (k + 1) + m] - (double)u[m]) : 0.0;
+            }
+            if (l < NXA) hb[r] = hv;
+        }
+        wave_lds_sync();
+        if (l < 32) {
+            // qu: gradient of the symmetry cost, barrier terms, force-rate term, B~^T hb
+            const int iq = l < NU ? l : NU - 1;
+            const bool isF = iq < NF;
+            const int m = isF ? iq : 0, ct = m / 12, ax = m % 3;
+            const int q = isF ? 0 : iq - 24;
+            const float* uf = u + 12 * ct + ax;
+            const float u0 = uf[0], u1 = uf[3], u2 = uf[6], u3 = uf[9], um = u[m];
+            const float up = c.U[NU * (pk ? k - 1 : 0) + m];
+            const double gam = gam_of(c, ct, k);
+            const int r0 = 4 * (m / 3);
+            double gc[4], ar[4];
+#pragma unroll
+            for (int f = 0; f < 4; ++f) { gc[f] = c.gco[r0 + f]; ar[f] = (double)c.arow[3 * (r0 + f) + ax]; }
+            const double glo = c.gco[32 + q], ghi = c.gco[38 + q];
+            const bool fr = qfree(c, k, q);
+            const Desc3 dq = desc_of(Brow, Bval, iq);
+            const double mean = 0.25 * ((double)u0 + (double)u1 + (double)u2 + (double)u3);
+            const double esum = 4.0 * mean * (1.0 - gam);
+            double gF = 2.0 * prm.w_sym * (((double)um - gam * mean) - 0.25 * gam * esum);
+#pragma unroll
+            for (int f = 0; f < 4; ++f) gF += gc[f] * ar[f];
+            if (pk) gF += (double)prm.D[ax] * ((double)um - (double)up);
+            const double gQ = fr ? glo - ghi : 0.0;
+            double g = isF ? (havep ? gF + hb[NS + m] : gF) : gQ;
+            g += (double)dq.w0 * hb[dq.r0] + (double)dq.w1 * hb[dq.r1] + (double)dq.w2 * hb[dq.r2];
+            if (l < NU) {
+                c.pv[iq] = g;                                         // float64 until -Z^T z_g has been subtracted (sq_mm_body)
+                if (!havep) Pann[(NPAN - 1) * RLD + iq] = (float)g;   // (the terminal stage has no Z)
+            }
+        } else if (l < 32 + NS) {
+            const int sidx = l - 32;
+            qsn[sidx] = grad_track(c, prm, k, sidx) + At_vec<double>(c, prm, k, sidx, hb);
+        }
+    }
+    // float32 entries
+    const int* Arow = c.Arow;
+    const float* Aval = c.Aval;
+    for (int id = t; id < 405; id += 256) {
+        if (id < 285) {
+            const bool kind = id < 135;   // true: Quu triple (row i, block column bj < bi); false: Qus^T triple (row jr, force / offset triple i0)
+            int i, col0;
+            Desc3 dr;
+            float ew = 0.f, symw = 0.f;
+            int eo = 96, symc = -1;
+            float* dst;
+            if (kind) {
+                const int ij = c.tri[id / 3];
+                i = 3 * ((ij >> 8) + 1) + id % 3; col0 = 3 * (ij & 255);
+                dr = desc_of(Brow, Bval, i);
+                // another corner of the same foot, same axis: symmetry-cost coupling
+                const bool sy = i < NF && (i / 12) == (col0 / 12);
+                const float gq = gam_of(c, i < 12 ? 0 : 1, k);
+                symc = i % 3;
+                symw = sy ? 2.f * prm.w_sym * 0.25f * gq * (2.f - gq) : 0.f;
+                dst = QuuFn + i * RLD + col0;
+            } else {
+                const int idp = id - 135, jr = idp / 10;
+                col0 = 3 * (idp % 10);
+                i = jr;
+                dr = desc_of(Arow, Aval, jr);
+                // exact-Hessian cross term -/+ gam Sx between a force and com / its foot's position
+                const int ct = col0 / 12;
+                const int bb = jr < 3 ? jr : jr - 9 - 3 * ct;
+                const bool bin = bb >= 0 && bb < 3;
+                const float sgn = jr < 3 ? -1.f : (bin ? 1.f : 0.f);
+                ew = col0 < NF ? sgn * gam_of(c, ct, k) : 0.f;
+                eo = 96 + (bin ? bb : 0);
+                dst = Pann + jr * RLD + col0;
+            }
+            float o[3];
+#pragma unroll
+            for (int cc = 0; cc < 3; ++cc) {
+                const Desc3 dc = desc_of(Brow, Bval, col0 + cc);
+                float v = sandwich(Qc, dr, dc) + ew * c.arow[eo + 3 * cc];
+                if (cc == symc) v -= symw;
+                o[cc] = v;
+            }
+            dst[0] = o[0]; dst[1] = o[1]; dst[2] = o[2];
+        } else {
+            const int ij = c.tri[id - 285];
+            const int i = ij >> 8, j = ij & 255;
+            const Desc3 da = desc_of(Arow, Aval, i), db = desc_of(Arow, Aval, j);
+            const float v = ((i == j) ? qdiag(prm, k, i) : 0.f) + sandwich(Qc, da, db);
+            Qbn[16 * i + j] = v;
+            Qbn[16 * j + i] = v;
+        }
+    }
+}
+
+// ---- Z^T = T^T W^T: row i < 30 = sum_a Bval[i][a] W^T[Brow[i][a]] (+ W^T[NS + i], the previous-force column, for a force), row 30 + s likewise
+// through column s of A, row 45 = lq + sum_a d_a W^T[a]; rows of 32 floats (columns 30, 31 are zeros in W^T).  One float4 per thread.
+// c: descriptor set and defects of the stage being ASSEMBLED (k - 1); WT: Pan of the stage just factorised. ----
+__device__ inline void sq_z_body(const Ctx& c, int tid, int kasm, const float* WT)
+{
+    const int row = tid >> 3, q4 = tid & 7;
+    if (row >= 48) return;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto fma4 = [&](float w, int r) {
+        const float4 x = *reinterpret_cast<const float4*>(WT + r * RLD + 4 * q4);
+        acc.x += w * x.x; acc.y += w * x.y; acc.z += w * x.z; acc.w += w * x.w;
+    };
+    if (row < NU + NS) {
+        const Desc3 d = row < NU ? desc_of(c.Brow, c.Bval, row) : desc_of(c.Arow, c.Aval, row - NU);
+        const bool pf = row < NF;
+        const float4 e = *reinterpret_cast<const float4*>(WT + (NS + (pf ? row : 0)) * RLD + 4 * q4);
+        fma4(d.w0, d.r0); fma4(d.w1, d.r1); fma4(d.w2, d.r2);
+        if (pf) { acc.x += e.x; acc.y += e.y; acc.z += e.z; acc.w += e.w; }
+    } else if (row == NU + NS) {
+        acc = *reinterpret_cast<const float4*>(WT + (NPAN - 1) * RLD + 4 * q4);
+#pragma unroll
+        for (int a = 0; a < NS; ++a) fma4(c.d[NS * kasm + a], a);
+    }
+    *reinterpret_cast<float4*>(c.ZT + row * ZLD + 4 * q4) = acc;
+}
+
+// ---- M -= Z^T Z on the matrix cores: the six lower 16 x 16 tiles of the 48 x 48 cover, one per wave (v_mfma_f32_16x16x4_f32: lane (m, kq) feeds
+// component t of TWO float4 of a Z^T row to MFMA t, so the K index it supplies is 4 kq + t (+ 16), the same map for both operands; result register i of
+// lane (m, kq) is entry (16 I + 4 kq + i, 16 J + m)).  Every value the products are subtracted from is fetched before the first MFMA. ----
+__device__ inline void sq_mm_body(const Ctx& c, int tid, float* QuuFn, float* Pann, float* Qbn, double* qsn)
+{
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    const int t = tid >> 6, ln = tid & 63, m4 = ln & 15, kq = ln >> 4;
+    if (t >= 6) return;
+    const int I = t >= 3 ? 2 : (t >= 1 ? 1 : 0), J = t - I * (I + 1) / 2;
+    const float* ra = c.ZT + (16 * I + m4) * ZLD + 4 * kq;
+    const float* rb = c.ZT + (16 * J + m4) * ZLD + 4 * kq;
+    const float4 a0 = *reinterpret_cast<const float4*>(ra), a1 = *reinterpret_cast<const float4*>(ra + 16);
+    const float4 b0 = *reinterpret_cast<const float4*>(rb), b1 = *reinterpret_cast<const float4*>(rb + 16);
+    const int jj = 16 * J + m4;
+    float* dst[4];
+    float* dst2[4];
+    float bs[4];
+    bool ok[4];
+    double gb = 0.0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int ii = 16 * I + 4 * kq + i;
+        ok[i] = jj <= ii && ii < NU + NS;
+        float* p = QuuFn + ii * RLD + jj;                                   // uu
+        float* p2 = p;
+        if (ii >= NU) {
+            if (jj < NU) { p = Pann + (ii - NU) * RLD + jj; p2 = p; }       // su
+            else { p = Qbn + 16 * (ii - NU) + (jj - NU); p2 = Qbn + 16 * (jj - NU) + (ii - NU); }   // ss, both triangles
+        }
+        if (!ok[i]) { p = QuuFn; p2 = QuuFn; }
+        dst[i] = p; dst2[i] = p2;
+        bs[i] = *p;
+        if (ii == NU + NS && jj < NU + NS) gb = jj < NU ? c.pv[jj] : qsn[jj - NU];   // gradient row: float64
+    }
+    v4f c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
+    c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, b0.x, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, b1.x, c1, 0, 0, 0);
+    c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, b0.y, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, b1.y, c1, 0, 0, 0);
+    c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, b0.z, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, b1.z, c1, 0, 0, 0);
+    c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, b0.w, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, b1.w, c1, 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int ii = 16 * I + 4 * kq + i;
+        const float v = c0[i] + c1[i];
+        if (ok[i]) {
+            const float r = bs[i] - v;
+            *dst[i] = r;
+            *dst2[i] = r;
+        } else if (ii == NU + NS && jj < NU + NS) {
+            const double r = gb - (double)v;
+            if (jj < NU) Pann[(NPAN - 1) * RLD + jj] = (float)r;
+            else qsn[jj - NU] = r;
+        }
+    }
+}
+
+// A square-root backward stage is two calls.  sq_mid: the factorisation of stage k on waves 0-1, meanwhile the Z-independent part of stage k-1 on
+// waves 2, 3, 6, 7 (waves 4, 5 share their SIMDs with the factorising waves and stay idle), and the barrier behind them.  sq_post: Z, barrier, -Z^T Z
+// into stage k-1 on waves 0-5 and the descriptors of stage k-2 on waves 6-7, barrier.
+template <int NT, int NC, bool FG>
+__device__ __attribute__((noinline)) void sq_mid(lds_t lds, int Nrt, float* fg_base, int k_in, int kbase_in, bool havep_in, float reg)
+{
+    CMPC_PHASE_PROLOGUE;
+    const int k = __builtin_amdgcn_readfirstlane(k_in);           // stage to factorise (N: none, only the terminal stage's successor is assembled)
+    const int kb = __builtin_amdgcn_readfirstlane(kbase_in);      // stage to assemble (-1: none)
+    const bool havep = __builtin_amdgcn_readfirstlane((int)havep_in) != 0;
+    PROF_DECL;
+    if (tid < 128) {
+        if (k < N) {
+            const int s = k & 1;
+            const int fixedmask = (~c.qmask[k]) & 63;
+            stage_factor<false, FG>(c.QuuF + s * MSET, s ? c.QuuD1 : c.QuuD, c.Pan + s * MSET, RecRef<FG>(c.Lf, N, k), prm.D[0], prm.D[1], prm.D[2], c.flag, tid, fixedmask);
+        }
+    } else if (kb >= 0 && (tid < 256 || tid >= 384)) {
+        const int t = tid < 256 ? tid - 128 : tid - 256;   // waves 2, 3 -> 0..127, waves 6, 7 -> 128..255
+        const int s = kb & 1, sc = s ^ 1;
+        use_desc_set(c, s);
+        sq_base_body(c, prm, t, kb, havep, reg, c.QuuF + s * MSET, s ? c.QuuD1 : c.QuuD, c.Pan + s * MSET, c.Qb + s * NS * 16, s ? c.qs1 : c.qs,
+                     c.Qb + sc * NS * 16, sc ? c.qs1 : c.qs);
+#ifdef CMPC_PROFILE
+        if (tid == 128 && blockIdx.x == 0) g_prof[5] += __builtin_amdgcn_s_memtime() - pt_;   // the assembly on its waves
+#endif
+    }
+    PROF(9);           // (wave 0: the factorisation alone)
+    __syncthreads();
+    PROF(3);
+}
+template <int NT, int NC, bool FG>
+__device__ __attribute__((noinline)) void sq_post(lds_t lds, int Nrt, float* fg_base, int k_in, int kdesc_in, bool exact_in, float cmu)
+{
+    CMPC_PHASE_PROLOGUE;
+    const int k = __builtin_amdgcn_readfirstlane(k_in);           // stage just factorised; stage k-1 is completed
+    const int kd = __builtin_amdgcn_readfirstlane(kdesc_in);      // stage whose descriptors are built meanwhile (-1: none)
+    const bool use_exact = __builtin_amdgcn_readfirstlane((int)exact_in) != 0;
+    PROF_DECL;
+    {
+        Ctx ca = c;
+        use_desc_set(ca, (k - 1) & 1);
+        sq_z_body(ca, tid, k - 1, c.Pan + (k & 1) * MSET);
+    }
+    __syncthreads();
+    PROF(1);
+    if (tid < 384) {
+        const int s = (k - 1) & 1;
+        sq_mm_body(c, tid, c.QuuF + s * MSET, c.Pan + s * MSET, c.Qb + s * NS * 16, s ? c.qs1 : c.qs);
+    } else if (kd >= 0) {
+        Ctx cd = c;
+        use_desc_set(cd, kd & 1);
+        stage_desc_body(cd, prm, tid - 384, kd, use_exact, cmu);
+    }
+    PROF(2);           // (wave 0: its tile alone)
+    __syncthreads();
+    PROF(4);
+}
+// terminal "stage": Qss_N = diag(Q_N), qs_N = gradient of the terminal cost, in set N & 1; descriptors of the last two stages
+template <int NT, int NC, bool FG>
+__device__ __attribute__((noinline)) void sq_init(lds_t lds, int Nrt, float* fg_base, int k0_in, bool exact_in, float cmu)
+{
+    CMPC_PHASE_PROLOGUE;
+    const int k0 = __builtin_amdgcn_readfirstlane(k0_in);
+    const bool use_exact = __builtin_amdgcn_readfirstlane((int)exact_in) != 0;
+    {
+        float* QN = c.Qb + (N & 1) * NS * 16;
+        double* qN = (N & 1) ? c.qs1 : c.qs;
+        if (tid < NS * 16) QN[tid] = (tid >> 4) == (tid & 15) ? qdiag(prm, N, tid & 15) : 0.f;
+        else if (tid >= 256 && tid < 256 + NS) qN[tid - 256] = grad_track(c, prm, N, tid - 256);
+        if (tid == 0) *c.flag = 0;
+    }
+    if (tid >= 256) {
+        const int kd = tid >= 384 ? N - 1 : N - 2;
+        if (kd >= k0) {
+            use_desc_set(c, kd & 1);
+            stage_desc_body(c, prm, tid & 127, kd, use_exact, cmu);
+        }
+    }
+    __syncthreads();
+}
+template <int NT, int NC, bool FG>
+__device__ inline int riccati_backward_sq(lds_t lds, const Ctx& c, float* fg_base, bool use_exact, float reg, float cmu, int k0)
+{
+    const int N = c.N;
+    sq_init<NT, NC, FG>(lds, N, fg_base, k0, use_exact, cmu);
+    sq_mid<NT, NC, FG>(lds, N, fg_base, N, N - 1, false, reg);                       // assemble stage N-1 (no Z: the terminal cost has no factors)
+    for (int k = N - 1; k >= k0; --k) {
+        sq_mid<NT, NC, FG>(lds, N, fg_base, k, k > k0 ? k - 1 : -1, true, reg);
+        if (k > k0) sq_post<NT, NC, FG>(lds, N, fg_base, k, k - 2 >= k0 ? k - 2 : -1, use_exact, cmu);
+    }
+    // (a non-positive pivot raises the flag and the stages after it run on garbage, harmlessly -- every array they write is rebuilt by the retry)
+    return *c.flag ? 1 : 0;
+}
+
 // ---- Riccati backward sweep (matrices + right-hand side of the affine step, or of a centring step with target
 // cmu).  Returns (uniformly) 0 ok, 1 non-positive pivot. ----
 // k0 > 0: only stages N-1 .. k0 (the tail polish: the state entering stage k0 is held, so nothing before it is needed).
 template <int NT, int NC, bool FG>
 __device__ int riccati_backward(lds_t lds, const Ctx& c, const CmpcConsts& prm, int tid, float* fg_base, bool use_exact, float reg, float cmu, int k0 = 0)
 {
+    if constexpr (CMPC_SQ(NT, FG)) return riccati_backward_sq<NT, NC, FG>(lds, c, fg_base, use_exact, reg, cmu, k0);
     const int N = c.N;
     for (int e = tid; e < NXA * PLD; e += NT) c.P0[e] = 0.f;
     if (tid == 0) *c.flag = 0;
@@ -1721,18 +2100,21 @@ __device__ void costate_update(const Ctx& c, const CmpcConsts& prm, int tid, flo
 #ifndef CMPC_SWEEP_WAVE0_ONLY
 #define CMPC_SWEEP_WAVE0_ONLY(FG) (FG)
 #endif
+#ifndef CMPC_SWEEP_WAVE
+#define CMPC_SWEEP_WAVE 0   // which wave of an HBM-factor workgroup runs the sweeps (the sweep code sees tid - 64 * CMPC_SWEEP_WAVE)
+#endif
 template <int NT, int NC, bool FG, int PART>
 __device__ __attribute__((noinline)) void phase_forward_part(lds_t lds, int Nrt, float* fg_base, bool affine_in)
 {
     CMPC_PHASE_PROLOGUE;
     const bool affine = __builtin_amdgcn_readfirstlane((int)affine_in) != 0;
-    riccati_forward<NT, NC == 0 ? 1 : (FG ? 2 : CMPC_SWEEP_UNROLL), FG, PART>(c, prm, tid, affine, 0);
+    riccati_forward<NT, NC == 0 ? 1 : (FG ? 2 : CMPC_SWEEP_UNROLL), FG, PART>(c, prm, PART == 1 ? tid - 64 * CMPC_SWEEP_WAVE : tid, affine, 0);
 }
 template <int NT, int NC, bool FG>
 __device__ __forceinline__ void phase_forward(lds_t lds, int Nrt, float* fg_base, bool affine_in)
 {
     if constexpr (CMPC_SWEEP_WAVE0_ONLY(FG)) {
-        if (threadIdx.x < 64) phase_forward_part<NT, NC, FG, 1>(lds, Nrt, fg_base, affine_in);
+        if ((threadIdx.x >> 6) == CMPC_SWEEP_WAVE) phase_forward_part<NT, NC, FG, 1>(lds, Nrt, fg_base, affine_in);
         phase_forward_part<NT, NC, FG, 2>(lds, Nrt, fg_base, affine_in);
     } else phase_forward_part<NT, NC, FG, 0>(lds, Nrt, fg_base, affine_in);
 }
@@ -1748,13 +2130,13 @@ template <int NT, int NC, bool FG, int PART>
 __device__ __attribute__((noinline)) void phase_delta_part(lds_t lds, int Nrt, float* fg_base)
 {
     CMPC_PHASE_PROLOGUE;
-    riccati_delta<NC == 0 ? 1 : (FG ? 2 : CMPC_SWEEP_UNROLL), FG, PART>(c, prm, tid);
+    riccati_delta<NC == 0 ? 1 : (FG ? 2 : CMPC_SWEEP_UNROLL), FG, PART>(c, prm, PART == 1 ? tid - 64 * CMPC_SWEEP_WAVE : tid);
 }
 template <int NT, int NC, bool FG>
 __device__ __forceinline__ void phase_delta(lds_t lds, int Nrt, float* fg_base)
 {
     if constexpr (CMPC_SWEEP_WAVE0_ONLY(FG)) {
-        if (threadIdx.x < 64) phase_delta_part<NT, NC, FG, 1>(lds, Nrt, fg_base);
+        if ((threadIdx.x >> 6) == CMPC_SWEEP_WAVE) phase_delta_part<NT, NC, FG, 1>(lds, Nrt, fg_base);
         __syncthreads();
     } else phase_delta_part<NT, NC, FG, 0>(lds, Nrt, fg_base);
 }
@@ -2309,10 +2691,11 @@ extern "C" size_t cmpc_solver_lds_bytes(int N, int factors_global)
 {
     CmpcLayout L;
     cmpc_layout_init(L, N);
-    const size_t dbl = 90 + 40 + 40 + 16 + 40 + 4 * NI + 8;
+    const size_t dbl = 90 + 40 + 40 + 16 + 40 + 4 * NI + 8 + (factors_global ? 0 : 90 + 16);
+    const size_t work = factors_global ? ((NXA * PLD + 3) & ~3) + NS * 16 + ((NXA * GLD + 3) & ~3) : (size_t)MSET + 48 * ZLD + 2 * NS * 16;   // (see make_ctx)
     const size_t flt = (size_t)NU * RLD + (size_t)NPAN * RLD + 96 + ((L.np + 3) & ~3)
                        + ((size_t)NS * (N + 1) + (size_t)NU * N + ((factors_global && N > CMPC_TZ_LDS_NMAX) ? 0 : 2 * (size_t)NI * N)) + (size_t)NS * N + (size_t)NS * (N + 1)
-                       + (size_t)GEO * N + ((NXA * PLD + 3) & ~3) + NS * 16 + ((NXA * GLD + 3) & ~3) + 2 * DSET_F + 40 + 40 + 24
+                       + (size_t)GEO * N + work + 2 * DSET_F + 40 + 40 + 24
                        + 2 * DSET_I + 4 + CMPC_NMAX + NTRI / 2 + (factors_global ? 0 : (size_t)REC_N * N);
     return ((sizeof(CmpcConsts) + 15) & ~(size_t)15) + dbl * 8 + flt * 4;
 }
