@@ -93,7 +93,7 @@ namespace {
 
 #ifdef CMPC_PROFILE
 // diagnostic build only: per-phase shader-clock sums of workgroup 0
-__device__ long long g_prof[32];
+__device__ long long g_prof[64];
 __device__ float g_trace[64 * 8];  // per iteration of workgroup 0: mu, ep, ec, step, ap, ad, sigma, mu_t
 #define PROF_DECL long long pt_ = __builtin_amdgcn_s_memtime()
 #define PROF(slot) do { long long n_ = __builtin_amdgcn_s_memtime(); if (threadIdx.x == 0 && blockIdx.x == 0) g_prof[slot] += n_ - pt_; pt_ = n_; } while (0)
@@ -104,7 +104,10 @@ __device__ float g_trace[64 * 8];  // per iteration of workgroup 0: mu, ep, ec, 
 #define PROF2(slot) do { long long n_ = __builtin_amdgcn_s_memtime(); if (threadIdx.x == 0 && blockIdx.x == 0) g_prof[slot] += n_ - pt2_; pt2_ = n_; } while (0)
 // (first lane of the value-gradient wave of phase 4)
 #define PROF5(slot) do { long long n_ = __builtin_amdgcn_s_memtime(); if (threadIdx.x == (NT >= 512 ? 448 : 216) && blockIdx.x == 0) g_prof[slot] += n_ - pt2_; pt2_ = n_; } while (0)
+// fire-and-forget stamp of the consumer waves (no wait on the atomic): slot 32 + 5 * wave + i
+#define CPROF(i) do { if (ln == 0 && blockIdx.x == 0 && k < N) atomicAdd(reinterpret_cast<unsigned long long*>(&g_prof[32 + 5 * wv + (i)]), (unsigned long long)(__builtin_amdgcn_s_memtime() - pc0_)); } while (0)
 #else
+#define CPROF(i)
 #define PROF_DECL
 #define PROF(slot)
 #define PROF2_DECL
@@ -131,6 +134,7 @@ struct Ctx {
     double *QuuD, *pv, *pn, *qs, *Pd, *sig, *gco, *redd;
     float* red;
     int* flag;
+    int* prog;             // (resident variants) progress words of the two factorising waves, one copy per lane
 };
 
 // LDS operations of one wave execute in issue order, so a write followed by reads of other lanes of the
@@ -217,7 +221,7 @@ __device__ inline void make_ctx(Ctx& c, char* smem, int N, float* fg_base)
         // resident variants: QuuF0 | Pan0 | QuuF1 | Pan1 | Z^T | Qb0 | Qb1 -- G and P0 (only the four-wave developer variant still forms them) lie over set 1 and Z^T
         c.G = fp; c.P0 = fp + ((NXA * GLD + 3) & ~3);
         fp += MSET;
-        c.ZT = fp; fp += 48 * ZLD;
+        c.ZT = fp; fp += 10 * NPAN * 4 + 128 * 4;   // Z^T (48 x ZLD) or -- streaming stage -- the published W^T, [block][panel row][4]
         c.Qb = fp; fp += 2 * NS * 16;
     } else {
     c.G = fp; fp += (NXA * GLD + 3) & ~3;                   // (sizes rounded to 16 bytes: ybuf and the LDS factor records
@@ -246,6 +250,8 @@ __device__ inline void make_ctx(Ctx& c, char* smem, int N, float* fg_base)
     c.Brow = reinterpret_cast<int*>(fp); fp += 3 * NU;
     c.Arow = reinterpret_cast<int*>(fp); fp += 3 * NS + 3; fp += DSET_I;  // (second descriptor set)
     c.flag = reinterpret_cast<int*>(fp); fp += 4;
+    c.prog = c.flag;
+    if (!FG) { c.prog = reinterpret_cast<int*>(fp); fp += 128; }
     c.qmask = reinterpret_cast<int*>(fp); fp += CMPC_NMAX;
     c.tri = reinterpret_cast<unsigned short*>(fp); fp += NTRI / 2;   // (i, j) of the first NTRI lower-triangle entries
 }
@@ -642,8 +648,11 @@ typedef float float2v __attribute__((ext_vector_type(2)));
 #define LATE_B 6
 #define LATE_M0 18
 #define NLATE (NU - LATE_M0)
-template <bool ONE>
-__device__ __forceinline__ bool chol_solve_fused(float2v (&vv)[NU / 2], double (&dd)[3], int lane, int fixedmask)
+// PUB (streaming square-root stage): after every pivot block the finished entries x0..x2 of this lane's panel row go to pub[(46 b + prow) * 4 ..]
+// and the wave's progress word *pflag is set to seq0 + b + 1.  LDS operations of one wave execute in issue order: whoever sees the flag sees the data.
+template <bool ONE, bool PUB = false>
+__device__ __forceinline__ bool chol_solve_fused(float2v (&vv)[NU / 2], double (&dd)[3], int lane, int fixedmask, float* pub = nullptr, int prow = 0,
+                                                 int pubstride = 0, int* pflag = nullptr, int seq0 = 0, float* publate = nullptr)
 {
     const int myblk = lane / 3;
     bool bad = false;
@@ -655,6 +664,7 @@ __device__ __forceinline__ bool chol_solve_fused(float2v (&vv)[NU / 2], double (
                 const unsigned hot = 1u << (LATE_M0 + lane);   // (bit-field extract + convert: two instructions per entry, no
 #pragma unroll                                                  //  compare -> mask hazard slots)
                 for (int cc = 0; cc < NU; ++cc) VE(cc) = (float)((hot >> cc) & 1u);
+                if (PUB) { pub = publate; pubstride = NPAN * 4; }   // (the identity row this lane now holds: its entries of the earlier blocks are zeros, kept zero in the buffer)
             }
         }
         // (opaque copies: the lane predicates are recomputed per block instead of living in hoisted, spilled SGPR pairs)
@@ -693,6 +703,12 @@ __device__ __forceinline__ bool chol_solve_fused(float2v (&vv)[NU / 2], double (
         // (the block's own three lanes get meaningless x here -- their slots of the block are zero -- and that is fine: L itself
         // is not kept, broadcasts only come from rows below the pivot block, so a lane's registers are dead once its block is done)
         VE(j0) = x0; VE(j0 + 1) = x1; VE(j0 + 2) = x2;
+        if (PUB) {
+            // (no lane predicates here: a lane without a panel row writes to a slot of its own behind the blocks, and every lane keeps its own copy of the progress word)
+            *reinterpret_cast<float4*>(pub + pubstride * b) = make_float4(x0, x1, x2, 0.f);
+            asm volatile("" ::: "memory");
+            __hip_atomic_store(pflag, seq0 + b + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
         // rank-3 update of the trailing columns: a leading odd column alone, then two columns per packed FMA.  Each
         // update is pinned here: left alone, the optimiser sinks the FMAs to the block that next reads the column and
         // the broadcast scalars (81 per block) wait for them in SGPRs spilled to VGPR lanes
@@ -723,9 +739,9 @@ __device__ __forceinline__ bool chol_solve_fused(float2v (&vv)[NU / 2], double (
 
 // phase 3 of a backward stage, kept out of line so that its ~40 VGPRs of matrix rows and its
 // stream of v_readlane broadcasts get a register allocation of their own
-template <bool ONE, bool G>
+template <bool ONE, bool G, bool PUB = false>
 __device__ __forceinline__ void stage_factor(const float* QuuF, const double* QuuD, float* Pan, const RecRef<G>& rec,
-                                          float D0, float D1, float D2, int* flag, int tid, int fixedmask)
+                                          float D0, float D1, float D2, int* flag, int tid, int fixedmask, float* pub = nullptr, int* pflag = nullptr, int seq0 = 0)
 {
     const int lane = tid & 63, wv = tid >> 6;
     // panel row of lanes >= 30.  Two waves: rows 0..33 on wave 0, 34..45 on wave 1 (both repeat the L rows).  One wave: Qus rows
@@ -758,7 +774,12 @@ __device__ __forceinline__ void stage_factor(const float* QuuF, const double* Qu
         }
     }
     PROF2(28);
-    const bool bad = chol_solve_fused<ONE>(vv, dd, lane, fixedmask);
+    // PUB: where this lane's entries of a pivot block go: its panel row in block 0 (+ NPAN * 4 * b per block), or -- lanes without a panel row -- a slot of
+    // their own behind the ten blocks (block stride 0)
+    float* pubp = pub;
+    if (PUB) pubp = (!isL && active) ? pub + prow * 4 : pub + (10 * NPAN + 64 * wv + lane) * 4;
+    const bool bad = chol_solve_fused<ONE, PUB>(vv, dd, lane, fixedmask, pubp, prow, (!isL && active) ? NPAN * 4 : 0, pflag, seq0,
+                                                PUB ? pub + (NS + LATE_M0 + (lane < NLATE ? lane : 0)) * 4 : nullptr);
     PROF2(29);
     if (bad && tid == 0) *flag = 1;
     const bool late = ONE && lane < NLATE;             // this lane now holds identity row LATE_M0 + lane
@@ -783,7 +804,7 @@ __device__ __forceinline__ void stage_factor(const float* QuuF, const double* Qu
             w.x = vv[2 * q].x; w.y = vv[2 * q].y;
             w.z = 2 * q + 1 < NU / 2 ? vv[(2 * q + 1) % (NU / 2)].x : 0.f;
             w.w = 2 * q + 1 < NU / 2 ? vv[(2 * q + 1) % (NU / 2)].y : 0.f;
-            *reinterpret_cast<float4*>(prow_p + 4 * q) = make_float4(sc * w.x, sc * w.y, sc * w.z, sc * w.w);
+            if (!PUB) *reinterpret_cast<float4*>(prow_p + 4 * q) = make_float4(sc * w.x, sc * w.y, sc * w.z, sc * w.w);   // (PUB: nobody reads the panel copy)
             rec.st4(q >= I ? rrow + 4 * (q ^ sw) : trash, w);
         }
     }
@@ -798,6 +819,13 @@ __device__ __forceinline__ void stage_factor(const float* QuuF, const double* Qu
 //   stage_post_body  phase 4: P <- [Qss 0; 0 D] - W^T W, value gradient ----
 // ---- column descriptors of A_k and B_k (closed forms; <= 3 non-zeros per column), barrier coefficients z/t and the
 // friction rows, the exact-Hessian block: 128 threads (t = 0..127), into the descriptor set selected in c ----
+// (the four roles of stage_desc_body -- t ranges 0..29, 32..46, 48..91, 96..104 -- can be given a wave each: role r of lane l is t = base_r + l)
+__device__ inline int desc_role_t(int role, int lane)
+{
+    const int base = role == 0 ? 0 : (role == 1 ? 32 : (role == 2 ? 48 : 96));
+    const int n = role == 0 ? NU : (role == 1 ? NS : (role == 2 ? NI : 9));
+    return lane < n ? base + lane : 127;   // (127: no role)
+}
 __device__ inline void stage_desc_body(const Ctx& c, const CmpcConsts& prm, int t, int k, bool use_exact, float cmu)
 {
     const float* u = c.U + NU * k;
@@ -1381,8 +1409,23 @@ __device__ inline float sandwich(const float* Q, const Desc3& a, const Desc3& b)
 // + T^T [Qss 0; 0 D] T (Qss, qs of stage k+1 in Qc, qsc; havep: stage k+1 has a previous-force block, i.e. it is not the terminal stage).
 // 256 threads (t): 0..59 the float64 diagonal blocks of Quu; 64..127 hb = [Qss d + qs; -D (u_k+1 - u_k)] and behind it, on the same wave, qu and qs;
 // then all of them the 405 float tasks: 135 triples of Quu, 150 triples of Qus^T, 120 entries of Qss.  c: descriptor set of stage k selected. ----
+// Y^T = (Qc T_s)^T, T_s = [B A] (15 x 45): row col of Y^T = sum_b w_b(col) Qc[r_b(col)][:] (Qc is symmetric), 16 floats; one float4 per thread, 180 threads.
+// With it a sandwich entry T_i^T Qc T_col is three loads instead of nine (and the column's descriptor is not needed).
+__device__ inline void sq_y_body(const Ctx& c, int t, const float* Qc, float* YT)
+{
+    if (t < 0 || t >= 4 * (NU + NS)) return;
+    const int col = t >> 2, q = t & 3;
+    const Desc3 d = desc_of(c.Brow, c.Bval, col);
+    const float4 x0 = *reinterpret_cast<const float4*>(Qc + 16 * d.r0 + 4 * q);
+    const float4 x1 = *reinterpret_cast<const float4*>(Qc + 16 * d.r1 + 4 * q);
+    const float4 x2 = *reinterpret_cast<const float4*>(Qc + 16 * d.r2 + 4 * q);
+    *reinterpret_cast<float4*>(YT + 16 * col + 4 * q) = make_float4(d.w0 * x0.x + d.w1 * x1.x + d.w2 * x2.x, d.w0 * x0.y + d.w1 * x1.y + d.w2 * x2.y,
+                                                                     d.w0 * x0.z + d.w1 * x1.z + d.w2 * x2.z, d.w0 * x0.w + d.w1 * x1.w + d.w2 * x2.w);
+}
+__device__ inline float sandwich_y(const float* YT, const Desc3& a, int col) { const float* y = YT + 16 * col; return a.w0 * y[a.r0] + a.w1 * y[a.r1] + a.w2 * y[a.r2]; }
+template <int NTB = 256, bool USEY = false>
 __device__ inline void sq_base_body(const Ctx& c, const CmpcConsts& prm, int t, int k, bool havep, float reg, float* QuuFn, double* QuuDn, float* Pann,
-                                    float* Qbn, double* qsn, const float* Qc, const double* qsc)
+                                    float* Qbn, double* qsn, const float* Qc, const double* qsc, const float* YT = nullptr)
 {
     const bool pk = k > 0;
     const float* u = c.U + NU * k;
@@ -1404,7 +1447,7 @@ __device__ inline void sq_base_body(const Ctx& c, const CmpcConsts& prm, int t, 
         const double slo = c.sig[32 + iq], shi = c.sig[38 + iq];
         const bool fr = qfree(c, k, iq);
         const double gam = gam_of(c, isF ? i / 12 : 0, k);
-        const double v = (double)sandwich(Qc, di, dj);
+        const double v = (double)(USEY ? sandwich_y(YT, di, j) : sandwich(Qc, di, dj));
         double vF = v;
         if (dg) {
             vF += 2.0 * prm.w_sym * (1.0 - 0.25 * gam * (2.0 - gam));
@@ -1472,58 +1515,50 @@ __device__ inline void sq_base_body(const Ctx& c, const CmpcConsts& prm, int t, 
             qsn[sidx] = grad_track(c, prm, k, sidx) + At_vec<double>(c, prm, k, sidx, hb);
         }
     }
-    // float32 entries
-    const int* Arow = c.Arow;
-    const float* Aval = c.Aval;
-    for (int id = t; id < 405; id += 256) {
-        if (id < 285) {
-            const bool kind = id < 135;   // true: Quu triple (row i, block column bj < bi); false: Qus^T triple (row jr, force / offset triple i0)
-            int i, col0;
-            Desc3 dr;
-            float ew = 0.f, symw = 0.f;
-            int eo = 96, symc = -1;
-            float* dst;
-            if (kind) {
-                const int ij = c.tri[id / 3];
-                i = 3 * ((ij >> 8) + 1) + id % 3; col0 = 3 * (ij & 255);
-                dr = desc_of(Brow, Bval, i);
-                // another corner of the same foot, same axis: symmetry-cost coupling
-                const bool sy = i < NF && (i / 12) == (col0 / 12);
-                const float gq = gam_of(c, i < 12 ? 0 : 1, k);
-                symc = i % 3;
-                symw = sy ? 2.f * prm.w_sym * 0.25f * gq * (2.f - gq) : 0.f;
-                dst = QuuFn + i * RLD + col0;
-            } else {
-                const int idp = id - 135, jr = idp / 10;
-                col0 = 3 * (idp % 10);
-                i = jr;
-                dr = desc_of(Arow, Aval, jr);
-                // exact-Hessian cross term -/+ gam Sx between a force and com / its foot's position
-                const int ct = col0 / 12;
-                const int bb = jr < 3 ? jr : jr - 9 - 3 * ct;
-                const bool bin = bb >= 0 && bb < 3;
-                const float sgn = jr < 3 ? -1.f : (bin ? 1.f : 0.f);
-                ew = col0 < NF ? sgn * gam_of(c, ct, k) : 0.f;
-                eo = 96 + (bin ? bb : 0);
-                dst = Pann + jr * RLD + col0;
-            }
-            float o[3];
-#pragma unroll
-            for (int cc = 0; cc < 3; ++cc) {
-                const Desc3 dc = desc_of(Brow, Bval, col0 + cc);
-                float v = sandwich(Qc, dr, dc) + ew * c.arow[eo + 3 * cc];
-                if (cc == symc) v -= symw;
-                o[cc] = v;
-            }
-            dst[0] = o[0]; dst[1] = o[1]; dst[2] = o[2];
+    // float32 entries: 360 triples of consecutive entries -- 135 of Quu (row i, block column bj < bi), 150 of Qus^T (row jr, the xyz of one corner / one foot's
+    // offset), 75 of Qss (row i, columns 3 jb .. 3 jb + 2: both triangles) -- by one branch-free formula on the descriptor table [B columns | A columns]:
+    //   out_c = row^T Qc col_c + ew E[3 c] - [c == symc] symw + [c == qc] qd
+    for (int id = t; id < 360; id += NTB) {
+        const bool isuu = id < 135, isss = id >= 285;
+        // (block row, block column) of the p-th strictly-lower block pair, p = 0..44, in closed form
+        const int p = isuu ? id / 3 : 0;
+        const int bi = 1 + (p >= 1) + (p >= 3) + (p >= 6) + (p >= 10) + (p >= 15) + (p >= 21) + (p >= 28) + (p >= 36);
+        const int bj = p - bi * (bi - 1) / 2;
+        const int idp = isuu ? 0 : (isss ? id - 285 : id - 135);
+        const int pr = isss ? idp / 5 : idp / 10, pc = isss ? idp % 5 : idp % 10;      // Qus^T: row jr = pr, triple pc; Qss: row pr, triple pc
+        const int i = isuu ? 3 * bi + id % 3 : pr;
+        const int col0 = isuu ? 3 * bj : 3 * pc;
+        const int drow = isuu ? i : NU + pr;                    // descriptor of the row: column i of B, or column pr of A
+        const int dcol = isss ? NU + col0 : col0;               // descriptors of the three columns
+        float* dst = isuu ? QuuFn + i * RLD + col0 : (isss ? Qbn + 16 * pr + col0 : Pann + pr * RLD + col0);
+        // Quu: another corner of the same foot, same axis: symmetry-cost coupling
+        const bool sy = isuu && i < NF && (i / 12) == (col0 / 12);
+        const float gq = gam_of(c, (isuu && i >= 12) ? 1 : 0, k);
+        const int symc = isuu ? i % 3 : -1;
+        const float symw = sy ? 2.f * prm.w_sym * 0.25f * gq * (2.f - gq) : 0.f;
+        // Qus^T: exact-Hessian cross term -/+ gam Sx between a force and com / its foot's position
+        const int ct = col0 / 12;
+        const int bb = pr < 3 ? pr : pr - 9 - 3 * ct;
+        const bool bin = bb >= 0 && bb < 3;
+        const float sgn = pr < 3 ? -1.f : (bin ? 1.f : 0.f);
+        const float ew = (!isuu && !isss && col0 < NF) ? sgn * gam_of(c, ct < 2 ? ct : 0, k) : 0.f;
+        const float* E = c.arow + 96 + (bin ? bb : 0);
+        // Qss: the stage cost on the diagonal
+        const int qc = isss ? pr - col0 : -1;
+        const float qd = isss ? qdiag(prm, k, pr) : 0.f;
+        const Desc3 dr = desc_of(Brow, Bval, drow);
+        const float e0 = E[0], e1 = E[3], e2 = E[6];
+        float o0, o1, o2;
+        if (USEY) {
+            o0 = sandwich_y(YT, dr, dcol) + ew * e0; o1 = sandwich_y(YT, dr, dcol + 1) + ew * e1; o2 = sandwich_y(YT, dr, dcol + 2) + ew * e2;
         } else {
-            const int ij = c.tri[id - 285];
-            const int i = ij >> 8, j = ij & 255;
-            const Desc3 da = desc_of(Arow, Aval, i), db = desc_of(Arow, Aval, j);
-            const float v = ((i == j) ? qdiag(prm, k, i) : 0.f) + sandwich(Qc, da, db);
-            Qbn[16 * i + j] = v;
-            Qbn[16 * j + i] = v;
+            const Desc3 d0 = desc_of(Brow, Bval, dcol), d1 = desc_of(Brow, Bval, dcol + 1), d2 = desc_of(Brow, Bval, dcol + 2);
+            o0 = sandwich(Qc, dr, d0) + ew * e0; o1 = sandwich(Qc, dr, d1) + ew * e1; o2 = sandwich(Qc, dr, d2) + ew * e2;
         }
+        o0 += (qc == 0 ? qd : 0.f) - (symc == 0 ? symw : 0.f);
+        o1 += (qc == 1 ? qd : 0.f) - (symc == 1 ? symw : 0.f);
+        o2 += (qc == 2 ? qd : 0.f) - (symc == 2 ? symw : 0.f);
+        dst[0] = o0; dst[1] = o1; dst[2] = o2;
     }
 }
 
@@ -1670,6 +1705,239 @@ __device__ __attribute__((noinline)) void sq_post(lds_t lds, int Nrt, float* fg_
     __syncthreads();
     PROF(4);
 }
+// ---- The streaming form of the square-root stage (CMPC_SQ_STREAM): ONE call and ONE barrier per stage.  The factorising waves publish the three finished
+// columns of W^T after every pivot block (chol_solve_fused<.., PUB>); waves 2-7 first assemble the Z-independent part of the next stage (and the descriptors
+// of the one after it), then follow the factorisation block by block: each owns one 16 x 16 tile of Z^T Z and, per block, forms the two operand entries
+// its lanes feed to the matrix core -- sparse combinations of the published rows -- and issues one v_mfma_f32_16x16x4_f32 (K = the block's three columns
+// and a zero).  When the last block is out, what remains is one tile update and the read-modify-write of the tile's entries.
+// Synchronisation inside the stage is by three LDS words: the progress of wave 0 and of wave 1 (monotonic over the backward pass: 16 ord + block + 1) and a
+// count of consumer waves whose part of the assembly is complete (6 per stage).  Every wait is bounded: a wave that gives up raises the failure flag. ----
+#ifndef CMPC_SQ_STREAM
+#define CMPC_SQ_STREAM 1
+#endif
+__device__ inline int lds_peek(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+// the operand row of Z^T a lane feeds: up to four published rows with weights (the row's column of B or A, and the previous-force column for a force)
+struct ZRow { int r0, r1, r2, r3; float w0, w1, w2, w3; };
+__device__ inline ZRow zrow_of(const Ctx& c, const CmpcConsts& prm, int row)
+{
+    ZRow z;
+    z.r0 = z.r1 = z.r2 = z.r3 = 0; z.w0 = z.w1 = z.w2 = z.w3 = 0.f;
+    if (row < NU + NS) {
+        const Desc3 d = row < NU ? desc_of(c.Brow, c.Bval, row) : desc_of(c.Arow, c.Aval, row - NU);
+        z.r0 = d.r0; z.r1 = d.r1; z.r2 = d.r2; z.w0 = d.w0; z.w1 = d.w1; z.w2 = d.w2;
+        if (row < NF) { z.r3 = NS + row; z.w3 = -prm.D[row % 3]; }   // W_p = -L^{-1}[:, :24] D: the identity rows are published unscaled
+    }
+    return z;   // (the gradient column, row 45, is not part of the tiles: see the gradient role of sq_consume)
+}
+template <int NT, int NC, bool FG>
+__device__ __attribute__((noinline)) void sq_factor(lds_t lds, int Nrt, float* fg_base, int k_in, int ord_in)
+{
+    CMPC_PHASE_PROLOGUE;
+    const int k = __builtin_amdgcn_readfirstlane(k_in);           // stage to factorise
+    const int ord = __builtin_amdgcn_readfirstlane(ord_in);       // ordinal of the stage call within the backward pass
+    const int s = k & 1;
+    const int fixedmask = (~c.qmask[k]) & 63;
+    PROF_DECL;
+#ifndef CMPC_FACT_PRIO
+#define CMPC_FACT_PRIO 3
+#endif
+    __builtin_amdgcn_s_setprio(CMPC_FACT_PRIO);
+    // (one wave: its second SIMD's worth of issue slots goes to the consumers -- the eight-wave shape is bound by what waves 1-7 can issue under the factorisation)
+    stage_factor<true, FG, true>(c.QuuF + s * MSET, s ? c.QuuD1 : c.QuuD, c.Pan + s * MSET, RecRef<FG>(c.Lf, N, k), prm.D[0], prm.D[1], prm.D[2], c.flag, tid,
+                                 fixedmask, c.ZT, c.prog + tid, 16 * ord);
+    __builtin_amdgcn_s_setprio(0);
+    PROF(9);           // (wave 0: the factorisation alone)
+}
+template <int NT, int NC, bool FG>
+__device__ __attribute__((noinline)) void sq_consume(lds_t lds, int Nrt, float* fg_base, int k_in, int kbase_in, int kdesc_in, int ord_in, bool havep_in, bool exact_in,
+                                                     float reg, float cmu)
+{
+    CMPC_PHASE_PROLOGUE;
+    const int k = __builtin_amdgcn_readfirstlane(k_in);           // stage being factorised meanwhile (N: none, only the terminal stage's successor is assembled)
+    const int kb = __builtin_amdgcn_readfirstlane(kbase_in);      // stage to assemble
+    const int kd = __builtin_amdgcn_readfirstlane(kdesc_in);      // stage whose descriptors are built meanwhile (-1: none)
+    const int ord = __builtin_amdgcn_readfirstlane(ord_in);       // ordinal of the stage call within the backward pass
+    const bool havep = __builtin_amdgcn_readfirstlane((int)havep_in) != 0, use_exact = __builtin_amdgcn_readfirstlane((int)exact_in) != 0;
+    const float* Wb = c.ZT;                                       // published W^T, [block][panel row][4]
+    const int* prog = c.prog;                                     // progress of wave 0 (prog[0..63]) and wave 1 (prog[64..127]); c.flag[3]: consumer waves done with the assembly
+    // waves 1, 2, 3, 5, 6, 7 own a tile each (wv = 0..5) and share the assembly; wave 4 -- on the factorising wave's SIMD, a fraction of the issue slots -- only builds
+    // the descriptors of stage kd, which nobody reads before the next stage
+    const int w7 = tid >> 6, ln = tid & 63, m4 = ln & 15, kq = ln >> 4;
+    const int wv = w7 < 4 ? w7 - 1 : w7 - 2, t = 64 * wv + ln;
+    if (w7 == 4) {
+        if (kd >= 0) {
+            use_desc_set(c, kd & 1);
+            // (one role per trip -- B columns, A columns, barrier rows, exact-Hessian block -- each on lanes 0..n-1.  The same work as two calls with t = lane and
+            //  t = 64 + lane gave different descriptors in this place (deterministically: walking problems then needed up to 4x the iterations); the cause was
+            //  not found, the role loop is what the tests pin)
+#pragma unroll 1
+            for (int r = 0; r < 4; ++r) stage_desc_body(c, prm, desc_role_t(r, ln), kd, use_exact, cmu);
+        }
+        return;
+    }
+#ifdef CMPC_PROFILE
+    const long long pc0_ = __builtin_amdgcn_s_memtime();
+#endif
+    const int s = kb & 1, sc = s ^ 1;
+    float* QuuFn = c.QuuF + s * MSET;
+    float* Pann = c.Pan + s * MSET;
+    float* Qbn = c.Qb + s * NS * 16;
+    double* qsn = s ? c.qs1 : c.qs;
+    CPROF(0);
+    use_desc_set(c, s);
+    // Y = Qss T_s first (180 threads), then -- behind a count of the consumer waves -- everything that reads it.  Y^T lives in the panel rows of the set being
+    // assembled that hold nothing in the streaming stage (the identity rows exist in registers only and W^T is published, not stored there)
+    float* YT = Pann + NS * RLD;
+    sq_y_body(c, t - 192, c.Qb + sc * NS * 16, YT);   // (waves 5, 6, 7: the float64 parts of the assembly sit on waves 1 and 2)
+    asm volatile("" ::: "memory");
+    if (ln == 0) __hip_atomic_fetch_add(c.flag + 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    {
+        const int want = 6 * (ord + 1);
+        int spins = 0;
+        while (lds_peek(c.flag + 2) < want) {
+            if (++spins > (1 << 20)) { if (ln == 0) *c.flag = 1; break; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        asm volatile("" ::: "memory");
+    }
+    sq_base_body<384, true>(c, prm, t, kb, havep, reg, QuuFn, s ? c.QuuD1 : c.QuuD, Pann, Qbn, qsn, c.Qb + sc * NS * 16, sc ? c.qs1 : c.qs, YT);
+    asm volatile("" ::: "memory");
+    if (ln == 0) __hip_atomic_fetch_add(c.flag + 3, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    CPROF(1);
+    if (k < N) {
+        typedef float v4f __attribute__((ext_vector_type(4)));
+        const int I = wv >= 3 ? 2 : (wv >= 1 ? 1 : 0), J = wv - I * (I + 1) / 2;
+        const ZRow za = zrow_of(c, prm, 16 * I + m4), zb = zrow_of(c, prm, 16 * J + m4);
+        const int fixedmask = (~c.qmask[k]) & 63;
+        v4f acc = {0.f, 0.f, 0.f, 0.f};
+        bool gaveup = false;
+        const int seq0 = 16 * ord;
+        int avail = 0;                       // pivot blocks known to be published
+        // blocks 0 .. nblk-1 published?  One look at the two progress words; nothing at all while the last look already covers the request
+        auto need = [&](int nblk) {
+            if (avail >= nblk) return;
+            int spins = 0;
+            for (;;) {
+                avail = lds_peek(prog) - seq0;
+                if (avail >= nblk) break;
+                if (++spins > (1 << 20)) { gaveup = true; avail = 16; break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            asm volatile("" ::: "memory");
+        };
+        // the two operand entries of pivot block b (one for a diagonal tile)
+        // (the eight addresses of block 0 in registers: with the block number a constant, every load below is base + immediate offset)
+        const float* pa0 = Wb + kq + 4 * za.r0; const float* pa1 = Wb + kq + 4 * za.r1; const float* pa2 = Wb + kq + 4 * za.r2; const float* pa3 = Wb + kq + 4 * za.r3;
+        const float* pb0 = Wb + kq + 4 * zb.r0; const float* pb1 = Wb + kq + 4 * zb.r1; const float* pb2 = Wb + kq + 4 * zb.r2; const float* pb3 = Wb + kq + 4 * zb.r3;
+        auto operands = [&](int b, float& a, float& bv) {
+            const int o = NPAN * 4 * b;
+            const float x0 = pa0[o], x1 = pa1[o], x2 = pa2[o], x3 = pa3[o];
+            const float y0 = pb0[o], y1 = pb1[o], y2 = pb2[o], y3 = pb3[o];   // (a diagonal tile loads the same four again: no branch in the load stream)
+            a = za.w0 * x0 + za.w1 * x1 + za.w2 * x2 + za.w3 * x3;
+            bv = zb.w0 * y0 + zb.w1 * y1 + zb.w2 * y2 + zb.w3 * y3;
+        };
+        // The gradient column (row 45 of M) is not a tile row: z_g = lq + Ws d needs a 16-term combination per block.  The wave of tile (0, 0) -- one
+        // operand, the lightest -- carries it instead as v = W^T z_g: lane <-> published row (0..14 Ws, 15 lq, 16..45 the identity rows), z_g of the block
+        // by a 16-lane DPP sum, v += x . z_g; at the end M[45][j] -= sum_a w_a(j) v[r_a(j)], the same sparse combination as a row of Z^T.
+        const bool grole = wv == 5;
+        const int grow = ln < NS ? ln : (ln == NS ? NPAN - 1 : (ln < NPAN ? ln - 1 : 0));
+        const float gw = grole ? (ln < NS ? c.d[NS * kb + ln] : (ln == NS ? 1.f : 0.f)) : 0.f;
+        float vacc = 0.f;
+        auto gradient = [&](int b) {
+            const float4 x = *reinterpret_cast<const float4*>(Wb + (NPAN * b + grow) * 4);
+            float t0 = gw * x.x, t1 = gw * x.y, t2 = gw * x.z;
+            t0 += dpp_f<0x111>(t0); t1 += dpp_f<0x111>(t1); t2 += dpp_f<0x111>(t2);   // row_shr:1, 2, 4, 8: lane 15 ends with the sum of lanes 0..15
+            t0 += dpp_f<0x112>(t0); t1 += dpp_f<0x112>(t1); t2 += dpp_f<0x112>(t2);
+            t0 += dpp_f<0x114>(t0); t1 += dpp_f<0x114>(t1); t2 += dpp_f<0x114>(t2);
+            t0 += dpp_f<0x118>(t0); t1 += dpp_f<0x118>(t1); t2 += dpp_f<0x118>(t2);
+            vacc += x.x * readlane_f(t0, 15) + x.y * readlane_f(t1, 15) + x.z * readlane_f(t2, 15);
+        };
+        CPROF(2);
+        // blocks 0..7 (the forces: never skipped) in pairs: the loads of both in flight, two chained MFMAs
+#pragma unroll
+        for (int b = 0; b < 8; b += 2) {
+            need(b + 2);
+            float a0, b0, a1, b1;
+            operands(b, a0, b0);
+            operands(b + 1, a1, b1);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc, 0, 0, 0);
+            if (grole) { gradient(b); gradient(b + 1); }
+        }
+        CPROF(3);
+        // every consumer wave's part of the assembly must be in LDS before the tiles are subtracted from it; then what the tile is subtracted from
+        // is fetched -- ahead of the last blocks, off the tail of the stage
+        {
+            const int want = 6 * (ord + 1);
+            int spins = 0;
+            while (lds_peek(c.flag + 3) < want) {
+                if (++spins > (1 << 20)) { gaveup = true; break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            asm volatile("" ::: "memory");
+        }
+        const int jj = 16 * J + m4;
+        float* dst[4];
+        float* dst2[4];
+        float bs[4];
+        bool ok[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int ii = 16 * I + 4 * kq + i;
+            ok[i] = jj <= ii && ii < NU + NS;
+            float* p = QuuFn + ii * RLD + jj;                                   // uu
+            float* p2 = p;
+            if (ii >= NU) {
+                if (jj < NU) { p = Pann + (ii - NU) * RLD + jj; p2 = p; }       // su
+                else { p = Qbn + 16 * (ii - NU) + (jj - NU); p2 = Qbn + 16 * (jj - NU) + (ii - NU); }   // ss, both triangles
+            }
+            if (!ok[i]) { p = QuuFn; p2 = QuuFn; }
+            dst[i] = p; dst2[i] = p2;
+            bs[i] = *p;
+        }
+        // blocks 8, 9: the landing offsets of the two feet (a stance foot's block is skipped by the factorisation: nothing is published)
+        {
+            const bool sk8 = ((fixedmask >> 0) & 7) == 7, sk9 = ((fixedmask >> 3) & 7) == 7;
+            if (!sk8 && !sk9) {
+                need(10);
+                float a0, b0, a1, b1;
+                operands(8, a0, b0);
+                operands(9, a1, b1);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc, 0, 0, 0);
+                if (grole) { gradient(8); gradient(9); }
+            } else if (!sk8 || !sk9) {
+                const int b = sk8 ? 9 : 8;
+                need(b + 1);
+                float a0, b0;
+                operands(b, a0, b0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc, 0, 0, 0);
+                if (grole) gradient(b);
+            }
+        }
+        if (gaveup && ln == 0) *c.flag = 1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (ok[i]) {
+                const float r = bs[i] - acc[i];
+                *dst[i] = r;
+                *dst2[i] = r;
+            }
+        }
+        if (grole) {
+            float* vb = c.fpv;                     // (80 floats with fpn behind it; the sweeps' buffer, idle during the backward pass)
+            if (ln < NPAN) vb[grow] = vacc;
+            wave_lds_sync();
+            if (ln < NU + NS) {
+                const ZRow zj = zrow_of(c, prm, ln);
+                const float val = zj.w0 * vb[zj.r0] + zj.w1 * vb[zj.r1] + zj.w2 * vb[zj.r2] + zj.w3 * vb[zj.r3];
+                if (ln < NU) Pann[(NPAN - 1) * RLD + ln] = (float)(c.pv[ln] - (double)val);
+                else qsn[ln - NU] -= (double)val;
+            }
+        }
+        CPROF(4);
+    }
+}
 // terminal "stage": Qss_N = diag(Q_N), qs_N = gradient of the terminal cost, in set N & 1; descriptors of the last two stages
 template <int NT, int NC, bool FG>
 __device__ __attribute__((noinline)) void sq_init(lds_t lds, int Nrt, float* fg_base, int k0_in, bool exact_in, float cmu)
@@ -1682,7 +1950,13 @@ __device__ __attribute__((noinline)) void sq_init(lds_t lds, int Nrt, float* fg_
         double* qN = (N & 1) ? c.qs1 : c.qs;
         if (tid < NS * 16) QN[tid] = (tid >> 4) == (tid & 15) ? qdiag(prm, N, tid & 15) : 0.f;
         else if (tid >= 256 && tid < 256 + NS) qN[tid - 256] = grad_track(c, prm, N, tid - 256);
-        if (tid == 0) *c.flag = 0;
+        if (tid < 4) c.flag[tid] = 0;   // failure flag | - | - | assembly count (streaming stage)
+        if (tid >= 128 && tid < 256) c.prog[tid - 128] = 0;   // progress of the factorising wave
+        // the identity rows 18..29 take over lanes of finished L rows at block LATE_B: their entries of the blocks before it are zeros nobody ever writes
+        if (tid >= 256 && tid < 256 + LATE_B * NLATE) {
+            const int e = tid - 256, b = e / NLATE, r = e % NLATE;
+            *reinterpret_cast<float4*>(c.ZT + (NPAN * b + NS + LATE_M0 + r) * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
     }
     if (tid >= 256) {
         const int kd = tid >= 384 ? N - 1 : N - 2;
@@ -1698,6 +1972,19 @@ __device__ inline int riccati_backward_sq(lds_t lds, const Ctx& c, float* fg_bas
 {
     const int N = c.N;
     sq_init<NT, NC, FG>(lds, N, fg_base, k0, use_exact, cmu);
+    if (CMPC_SQ_STREAM) {
+        const int tid = threadIdx.x;
+        int ord = 0;
+        if (tid >= 64) sq_consume<NT, NC, FG>(lds, N, fg_base, N, N - 1, -1, ord, false, use_exact, reg, cmu);   // assemble stage N-1 (no Z: the terminal cost has no factors)
+        __syncthreads();
+        for (int k = N - 1; k >= k0; --k) {
+            ++ord;
+            if (tid < 64) sq_factor<NT, NC, FG>(lds, N, fg_base, k, ord);
+            else if (k > k0) sq_consume<NT, NC, FG>(lds, N, fg_base, k, k - 1, k - 2 >= k0 ? k - 2 : -1, ord, true, use_exact, reg, cmu);
+            __syncthreads();
+        }
+        return *c.flag ? 1 : 0;
+    }
     sq_mid<NT, NC, FG>(lds, N, fg_base, N, N - 1, false, reg);                       // assemble stage N-1 (no Z: the terminal cost has no factors)
     for (int k = N - 1; k >= k0; --k) {
         sq_mid<NT, NC, FG>(lds, N, fg_base, k, k > k0 ? k - 1 : -1, true, reg);
@@ -2442,6 +2729,12 @@ __device__ __attribute__((noinline)) int phase_backward(lds_t lds, int Nrt, floa
 {
     CMPC_PHASE_PROLOGUE;
     const bool exact = __builtin_amdgcn_readfirstlane((int)exact_in) != 0;
+#ifdef CMPC_PROFILE
+    const long long pb_ = __builtin_amdgcn_s_memtime();
+    const int rb_ = riccati_backward<NT, NC, FG>(lds, c, prm, tid, fg_base, exact, reg, cmu);
+    if (tid == 0 && blockIdx.x == 0) { g_prof[31] += 1; g_prof[63] += __builtin_amdgcn_s_memtime() - pb_; }   // backward passes of workgroup 0 and their cycles
+    return rb_;
+#endif
     return riccati_backward<NT, NC, FG>(lds, c, prm, tid, fg_base, exact, reg, cmu);
 }
 
@@ -2692,7 +2985,7 @@ extern "C" size_t cmpc_solver_lds_bytes(int N, int factors_global)
     CmpcLayout L;
     cmpc_layout_init(L, N);
     const size_t dbl = 90 + 40 + 40 + 16 + 40 + 4 * NI + 8 + (factors_global ? 0 : 90 + 16);
-    const size_t work = factors_global ? ((NXA * PLD + 3) & ~3) + NS * 16 + ((NXA * GLD + 3) & ~3) : (size_t)MSET + 48 * ZLD + 2 * NS * 16;   // (see make_ctx)
+    const size_t work = factors_global ? ((NXA * PLD + 3) & ~3) + NS * 16 + ((NXA * GLD + 3) & ~3) : (size_t)MSET + 10 * NPAN * 4 + 128 * 4 + 2 * NS * 16 + 128;   // (see make_ctx)
     const size_t flt = (size_t)NU * RLD + (size_t)NPAN * RLD + 96 + ((L.np + 3) & ~3)
                        + ((size_t)NS * (N + 1) + (size_t)NU * N + ((factors_global && N > CMPC_TZ_LDS_NMAX) ? 0 : 2 * (size_t)NI * N)) + (size_t)NS * N + (size_t)NS * (N + 1)
                        + (size_t)GEO * N + work + 2 * DSET_F + 40 + 40 + 24
@@ -2703,8 +2996,8 @@ extern "C" size_t cmpc_solver_lds_bytes(int N, int factors_global)
 #ifdef CMPC_PROFILE
 extern "C" int cmpc_profile_read(long long* out, int reset)
 {
-    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof), sizeof(long long) * 32);
-    if (reset) { long long z[32] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof(z)); }
+    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof), sizeof(long long) * 64);
+    if (reset) { long long z[64] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof(z)); }
     return (int)e;
 }
 extern "C" int cmpc_trace_read(float* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_trace), sizeof(float) * 64 * 8); }

@@ -363,7 +363,9 @@ def test_hbm_factor_and_resident_variants_agree(N, monkeypatch):
         assert rc == 0 and (info[:, 5] == 0).all(), (factors, s.last_error)
         out[factors] = (X, info)
         s.close()
-    assert np.abs(out["lds"][1][:, 0] - out["hbm"][1][:, 0]).max() <= 1
+    # (the resident variants assemble a stage in the square-root form, the HBM-factor variants through the value function: the same optimum -- checked
+    #  below -- by different float32 algebra, and the lagged termination test may then fire an iteration or two apart on a borderline problem)
+    assert np.abs(out["lds"][1][:, 0] - out["hbm"][1][:, 0]).max() <= 2
     for b in range(32):
         e = parity.errors(cfg.N, P32[b], out["hbm"][0][b], out["lds"][0][b])
         assert e["com"] < 2e-5 and e["forces"] < 5e-5 and e["pos"] < 2e-5, (b, e)
