@@ -1729,35 +1729,38 @@ __device__ inline ZRow zrow_of(const Ctx& c, const CmpcConsts& prm, int row)
     }
     return z;   // (the gradient column, row 45, is not part of the tiles: see the gradient role of sq_consume)
 }
+// The factorising wave's side of a backward pass: ONE call for all stages (the stage loop and its barriers inside: a call per stage cost the critical wave the
+// rebuilding of the LDS map every stage).
 template <int NT, int NC, bool FG>
-__device__ __attribute__((noinline)) void sq_factor(lds_t lds, int Nrt, float* fg_base, int k_in, int ord_in)
+__device__ __attribute__((noinline)) void sq_factor_loop(lds_t lds, int Nrt, float* fg_base, int k0_in)
 {
     CMPC_PHASE_PROLOGUE;
-    const int k = __builtin_amdgcn_readfirstlane(k_in);           // stage to factorise
-    const int ord = __builtin_amdgcn_readfirstlane(ord_in);       // ordinal of the stage call within the backward pass
-    const int s = k & 1;
-    const int fixedmask = (~c.qmask[k]) & 63;
-    PROF_DECL;
+    const int k0 = __builtin_amdgcn_readfirstlane(k0_in);
+    __syncthreads();                                   // (the consumers assemble stage N-1 from the terminal cost meanwhile)
+    int ord = 0;                                       // ordinal of the stage within the backward pass
 #ifndef CMPC_FACT_PRIO
 #define CMPC_FACT_PRIO 3
 #endif
     __builtin_amdgcn_s_setprio(CMPC_FACT_PRIO);
-    // (one wave: its second SIMD's worth of issue slots goes to the consumers -- the eight-wave shape is bound by what waves 1-7 can issue under the factorisation)
-    stage_factor<true, FG, true>(c.QuuF + s * MSET, s ? c.QuuD1 : c.QuuD, c.Pan + s * MSET, RecRef<FG>(c.Lf, N, k), prm.D[0], prm.D[1], prm.D[2], c.flag, tid,
-                                 fixedmask, c.ZT, c.prog + tid, 16 * ord);
+#pragma unroll 1
+    for (int k = N - 1; k >= k0; --k) {
+        ++ord;
+        const int s = k & 1;
+        const int fixedmask = (~c.qmask[k]) & 63;
+        PROF_DECL;
+        // (one wave: its second SIMD's worth of issue slots goes to the consumers -- the eight-wave shape is bound by what waves 1-7 can issue under the factorisation)
+        stage_factor<true, FG, true>(c.QuuF + s * MSET, s ? c.QuuD1 : c.QuuD, c.Pan + s * MSET, RecRef<FG>(c.Lf, N, k), prm.D[0], prm.D[1], prm.D[2], c.flag, tid,
+                                     fixedmask, c.ZT, c.prog + tid, 16 * ord);
+        PROF(9);           // (wave 0: the factorisation alone)
+        __syncthreads();
+        PROF(3);
+    }
     __builtin_amdgcn_s_setprio(0);
-    PROF(9);           // (wave 0: the factorisation alone)
 }
-template <int NT, int NC, bool FG>
-__device__ __attribute__((noinline)) void sq_consume(lds_t lds, int Nrt, float* fg_base, int k_in, int kbase_in, int kdesc_in, int ord_in, bool havep_in, bool exact_in,
-                                                     float reg, float cmu)
+// k: stage being factorised meanwhile (N: none, only the terminal stage's successor is assembled); kb: stage to assemble; kd: stage whose descriptors are built
+// meanwhile (-1: none); ord: ordinal of the stage within the backward pass.  All uniform.  (c by value: the descriptor set is selected in the copy)
+__device__ inline void sq_consume_body(Ctx c, const CmpcConsts& prm, int tid, int N, int k, int kb, int kd, int ord, bool havep, bool use_exact, float reg, float cmu)
 {
-    CMPC_PHASE_PROLOGUE;
-    const int k = __builtin_amdgcn_readfirstlane(k_in);           // stage being factorised meanwhile (N: none, only the terminal stage's successor is assembled)
-    const int kb = __builtin_amdgcn_readfirstlane(kbase_in);      // stage to assemble
-    const int kd = __builtin_amdgcn_readfirstlane(kdesc_in);      // stage whose descriptors are built meanwhile (-1: none)
-    const int ord = __builtin_amdgcn_readfirstlane(ord_in);       // ordinal of the stage call within the backward pass
-    const bool havep = __builtin_amdgcn_readfirstlane((int)havep_in) != 0, use_exact = __builtin_amdgcn_readfirstlane((int)exact_in) != 0;
     const float* Wb = c.ZT;                                       // published W^T, [block][panel row][4]
     const int* prog = c.prog;                                     // progress of wave 0 (prog[0..63]) and wave 1 (prog[64..127]); c.flag[3]: consumer waves done with the assembly
     // waves 1, 2, 3, 5, 6, 7 own a tile each (wv = 0..5) and share the assembly; wave 4 -- on the factorising wave's SIMD, a fraction of the issue slots -- only builds
@@ -1938,6 +1941,23 @@ __device__ __attribute__((noinline)) void sq_consume(lds_t lds, int Nrt, float* 
         CPROF(4);
     }
 }
+// The consumers' side of a backward pass (waves 1..7), one call: the assembly of stage N-1 from the terminal cost, then a stage per barrier.
+template <int NT, int NC, bool FG>
+__device__ __attribute__((noinline)) void sq_consume_loop(lds_t lds, int Nrt, float* fg_base, int k0_in, bool exact_in, float reg, float cmu)
+{
+    CMPC_PHASE_PROLOGUE;
+    const int k0 = __builtin_amdgcn_readfirstlane(k0_in);
+    const bool use_exact = __builtin_amdgcn_readfirstlane((int)exact_in) != 0;
+    sq_consume_body(c, prm, tid, N, N, N - 1, -1, 0, false, use_exact, reg, cmu);
+    __syncthreads();
+    int ord = 0;
+#pragma unroll 1
+    for (int k = N - 1; k >= k0; --k) {
+        ++ord;
+        if (k > k0) sq_consume_body(c, prm, tid, N, k, k - 1, k - 2 >= k0 ? k - 2 : -1, ord, true, use_exact, reg, cmu);
+        __syncthreads();
+    }
+}
 // terminal "stage": Qss_N = diag(Q_N), qs_N = gradient of the terminal cost, in set N & 1; descriptors of the last two stages
 template <int NT, int NC, bool FG>
 __device__ __attribute__((noinline)) void sq_init(lds_t lds, int Nrt, float* fg_base, int k0_in, bool exact_in, float cmu)
@@ -1973,16 +1993,8 @@ __device__ inline int riccati_backward_sq(lds_t lds, const Ctx& c, float* fg_bas
     const int N = c.N;
     sq_init<NT, NC, FG>(lds, N, fg_base, k0, use_exact, cmu);
     if (CMPC_SQ_STREAM) {
-        const int tid = threadIdx.x;
-        int ord = 0;
-        if (tid >= 64) sq_consume<NT, NC, FG>(lds, N, fg_base, N, N - 1, -1, ord, false, use_exact, reg, cmu);   // assemble stage N-1 (no Z: the terminal cost has no factors)
-        __syncthreads();
-        for (int k = N - 1; k >= k0; --k) {
-            ++ord;
-            if (tid < 64) sq_factor<NT, NC, FG>(lds, N, fg_base, k, ord);
-            else if (k > k0) sq_consume<NT, NC, FG>(lds, N, fg_base, k, k - 1, k - 2 >= k0 ? k - 2 : -1, ord, true, use_exact, reg, cmu);
-            __syncthreads();
-        }
+        if (threadIdx.x < 64) sq_factor_loop<NT, NC, FG>(lds, N, fg_base, k0);
+        else sq_consume_loop<NT, NC, FG>(lds, N, fg_base, k0, use_exact, reg, cmu);
         return *c.flag ? 1 : 0;
     }
     sq_mid<NT, NC, FG>(lds, N, fg_base, N, N - 1, false, reg);                       // assemble stage N-1 (no Z: the terminal cost has no factors)
