@@ -17,11 +17,14 @@
 //
 // Structure.  The kernel body is control flow over a dozen scalars; EVERY pass lives in an out-of-line device function (a register
 // allocation of its own) handed the LDS base, from which it rebuilds the LDS map: set-up, initial iterate, residuals, multiplier
-// rescaling, two per backward stage (stage_mid: phase 3; stage_post_pre: phase 4 and phases 1-2 of the next stage), one per sweep,
-// step lengths, corrector targets, update + step norms, the last step (extrapolation + tail polish), export.  Two variants: "resident"
-// (512 threads, per-stage factor records in LDS, one workgroup per CU, B <= #CU) and "HBM-factor" (256
-// threads, records in global scratch, three workgroups per CU).  One stage of the backward sweep (wave
-// numbers of the four-wave shape; 4 barriers):
+// rescaling, the backward sweep, one per sweep, step lengths, corrector targets, update + step norms, the last step (extrapolation + tail
+// polish), export.  Two variants: "resident" (512 threads, per-stage factor records in LDS, one workgroup per CU, B <= #CU) and
+// "HBM-factor" (256 threads, records in global scratch, three workgroups per CU).
+// Backward sweep of the resident variants: the streaming square-root stage (see CMPC_SQRT_BACKWARD and sq_consume_body) -- wave 0
+// factorises and publishes its columns block by block, waves 1-7 assemble the next stage's Z-independent part meanwhile and subtract
+// Z^T Z from it one MFMA tile per wave as the blocks come; one barrier per stage, one call per pass and role (sq_factor_loop,
+// sq_consume_loop).  Backward sweep of the HBM-factor variants: two calls per stage (stage_mid: phase 3; stage_post_pre: phase 4 and
+// phases 1-2 of the next stage), four barriers (wave numbers of the four-wave shape):
 //   1. G = P [B;E]                        sparse: every column of A, B has <= 3 non-zeros
 //   2. Quu, Qus (waves 0-1, float32), Quu diagonal blocks (wave 2, float64), Pd and qu (wave 3, float64)
 //   3. fused Cholesky + panel solve       waves 0-1, matrix rows in registers: lanes 0-29 hold the rows of
@@ -1745,6 +1748,12 @@ __device__ __attribute__((noinline)) void sq_factor_loop(lds_t lds, int Nrt, flo
 #pragma unroll 1
     for (int k = N - 1; k >= k0; --k) {
         ++ord;
+        lds_t lk = lds;                                // (an opaque copy of the LDS base per stage: see sq_consume_loop)
+        asm volatile("" : "+v"(lk));
+        char* smk = (char*)lk;
+        Ctx c;
+        make_ctx<FG>(c, smk, N, fg_base);
+        const CmpcConsts& prm = *reinterpret_cast<const CmpcConsts*>(smk);
         const int s = k & 1;
         const int fixedmask = (~c.qmask[k]) & 63;
         PROF_DECL;
@@ -1954,7 +1963,16 @@ __device__ __attribute__((noinline)) void sq_consume_loop(lds_t lds, int Nrt, fl
 #pragma unroll 1
     for (int k = N - 1; k >= k0; --k) {
         ++ord;
-        if (k > k0) sq_consume_body(c, prm, tid, N, k, k - 1, k - 2 >= k0 ? k - 2 : -1, ord, true, use_exact, reg, cmu);
+        if (k > k0) {
+            // (the LDS map is rebuilt from an opaque copy of the base every stage -- constant offsets, a handful of adds -- instead of living in ~60 registers across the loop:
+            //  held live it pushed the function into the callee-saved registers, 33 of them saved to scratch per lane and pass: 56 MB of scratch writes per B = 256 launch)
+            lds_t lk = lds;
+            asm volatile("" : "+v"(lk));
+            char* smk = (char*)lk;
+            Ctx ck;
+            make_ctx<FG>(ck, smk, N, fg_base);
+            sq_consume_body(ck, *reinterpret_cast<const CmpcConsts*>(smk), tid, N, k, k - 1, k - 2 >= k0 ? k - 2 : -1, ord, true, use_exact, reg, cmu);
+        }
         __syncthreads();
     }
 }

@@ -7,7 +7,9 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: F401  (same HIP runtime)
 import cmpc_amd as cm
 cm._capi.LIB_PATH = os.path.join(os.path.dirname(cm._capi.LIB_PATH), os.environ.get("CMPC_PROF_LIB", "libcmpc_hip_prof.so"))
-names = ["(ph0: under ph3 now)", "ph1 G", "ph2 Quu,panel,Pd,qu", "ph3 fused chol+solve", "ph4 P update", "ph2/w0: values", "ph2/w0: stores", "ph2/w2: diag blocks", "ph2/w3: qu", "-",
+# (resident variants, streaming square-root stage: slots 1, 2, 4..8 are unused, slot 3 is wave 0's wait at the stage barrier, slot 9 its factorisation; the HBM-factor
+#  variants and a -DCMPC_SQRT_BACKWARD=0 build fill the ph1..ph4 slots instead)
+names = ["(ph0: under ph3 now)", "ph1 G", "ph2 Quu,panel,Pd,qu", "ph3 chol+solve | sq: barrier wait", "ph4 P update", "ph2/w0: values", "ph2/w0: stores", "ph2/w2: diag blocks", "ph2/w3: qu", "sq: factorisation (w0)",
          "residuals", "backward(total)", "fwd1", "steps+muaff", "delta", "fwd2", "steplen+costate", "update+conv"]
 if os.environ.get("CMPC_PROBE") == "push":
     cfg, P, X0 = cm.synthetic.walking_push_n12("tmp")
