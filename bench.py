@@ -407,7 +407,7 @@ def main():
         m["roofline"]["traffic"] = traffic
         m["roofline"]["traffic_source"] = (f"{tsrc} (rocprofv3 --pmc passes of this command, committed; not measured in this run)"
                                            if tsrc else None)
-        m["roofline"]["note"] = ("bound = f32 VALU issue (f32-input MFMA -- used for the stage's W^T W in the resident variants -- peaks at the "
+        m["roofline"]["note"] = ("bound = f32 VALU issue (f32-input MFMA -- used for the stage's Schur-complement product Z^T Z in the resident variants -- peaks at the "
                                  "vector rate, 157.3 TFLOP/s); flop = executed IP iterations x 4.25e5*N (SURVEY 8d canonical "
                                  "count); HBM traffic is ~11 KB/solve")
         out = {

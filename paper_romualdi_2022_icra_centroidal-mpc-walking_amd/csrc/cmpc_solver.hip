@@ -1708,13 +1708,16 @@ __device__ __attribute__((noinline)) void sq_post(lds_t lds, int Nrt, float* fg_
     __syncthreads();
     PROF(4);
 }
-// ---- The streaming form of the square-root stage (CMPC_SQ_STREAM): ONE call and ONE barrier per stage.  The factorising waves publish the three finished
-// columns of W^T after every pivot block (chol_solve_fused<.., PUB>); waves 2-7 first assemble the Z-independent part of the next stage (and the descriptors
-// of the one after it), then follow the factorisation block by block: each owns one 16 x 16 tile of Z^T Z and, per block, forms the two operand entries
-// its lanes feed to the matrix core -- sparse combinations of the published rows -- and issues one v_mfma_f32_16x16x4_f32 (K = the block's three columns
-// and a zero).  When the last block is out, what remains is one tile update and the read-modify-write of the tile's entries.
-// Synchronisation inside the stage is by three LDS words: the progress of wave 0 and of wave 1 (monotonic over the backward pass: 16 ord + block + 1) and a
-// count of consumer waves whose part of the assembly is complete (6 per stage).  Every wait is bounded: a wave that gives up raises the failure flag. ----
+// ---- The streaming form of the square-root stage (CMPC_SQ_STREAM): ONE barrier per stage, one call per backward pass and role.  The factorisation runs on wave 0
+// (the one-wave scheme: 76 rows in 64 lanes) and publishes the three finished columns of W^T after every pivot block (chol_solve_fused<.., PUB>).  Waves 1, 2, 3, 5, 6, 7
+// first assemble the Z-independent part of the next stage (Y = Qss [B A], then 360 float32 triples, the float64 diagonal blocks, q_u and q_s), then follow the
+// factorisation two blocks at a time: each owns one 16 x 16 tile of Z^T Z and, per block, forms the two operand entries its lanes feed to the matrix core -- sparse
+// combinations of the published rows -- and issues one v_mfma_f32_16x16x4_f32 (K = the block's three columns and a zero); the wave of tile (2, 2) also carries the
+// gradient column.  When the last block is out, what remains is one tile update and the read-modify-write of the tile's entries.  Wave 4 shares its SIMD with the
+// factorising wave and only builds the descriptors of the stage after next.
+// Synchronisation inside the stage is by LDS words: the progress of wave 0 (monotonic over the backward pass: 16 ord + block + 1; one copy per lane, so that the store
+// needs no lane predicate), a count of consumer waves done with Y, and a count of those whose part of the assembly is complete (6 per stage each).  Every wait is
+// bounded: a wave that gives up raises the failure flag. ----
 #ifndef CMPC_SQ_STREAM
 #define CMPC_SQ_STREAM 1
 #endif
@@ -1771,7 +1774,7 @@ __device__ __attribute__((noinline)) void sq_factor_loop(lds_t lds, int Nrt, flo
 __device__ inline void sq_consume_body(Ctx c, const CmpcConsts& prm, int tid, int N, int k, int kb, int kd, int ord, bool havep, bool use_exact, float reg, float cmu)
 {
     const float* Wb = c.ZT;                                       // published W^T, [block][panel row][4]
-    const int* prog = c.prog;                                     // progress of wave 0 (prog[0..63]) and wave 1 (prog[64..127]); c.flag[3]: consumer waves done with the assembly
+    const int* prog = c.prog;                                     // progress of the factorising wave (lane 0's copy); c.flag[2]: consumer waves done with Y, c.flag[3]: with the assembly
     // waves 1, 2, 3, 5, 6, 7 own a tile each (wv = 0..5) and share the assembly; wave 4 -- on the factorising wave's SIMD, a fraction of the issue slots -- only builds
     // the descriptors of stage kd, which nobody reads before the next stage
     const int w7 = tid >> 6, ln = tid & 63, m4 = ln & 15, kq = ln >> 4;
@@ -1825,7 +1828,7 @@ __device__ inline void sq_consume_body(Ctx c, const CmpcConsts& prm, int tid, in
         bool gaveup = false;
         const int seq0 = 16 * ord;
         int avail = 0;                       // pivot blocks known to be published
-        // blocks 0 .. nblk-1 published?  One look at the two progress words; nothing at all while the last look already covers the request
+        // blocks 0 .. nblk-1 published?  One look at the progress word; nothing at all while the last look already covers the request
         auto need = [&](int nblk) {
             if (avail >= nblk) return;
             int spins = 0;
@@ -1837,7 +1840,7 @@ __device__ inline void sq_consume_body(Ctx c, const CmpcConsts& prm, int tid, in
             }
             asm volatile("" ::: "memory");
         };
-        // the two operand entries of pivot block b (one for a diagonal tile)
+        // the two operand entries of pivot block b
         // (the eight addresses of block 0 in registers: with the block number a constant, every load below is base + immediate offset)
         const float* pa0 = Wb + kq + 4 * za.r0; const float* pa1 = Wb + kq + 4 * za.r1; const float* pa2 = Wb + kq + 4 * za.r2; const float* pa3 = Wb + kq + 4 * za.r3;
         const float* pb0 = Wb + kq + 4 * zb.r0; const float* pb1 = Wb + kq + 4 * zb.r1; const float* pb2 = Wb + kq + 4 * zb.r2; const float* pb3 = Wb + kq + 4 * zb.r3;
@@ -1848,8 +1851,8 @@ __device__ inline void sq_consume_body(Ctx c, const CmpcConsts& prm, int tid, in
             a = za.w0 * x0 + za.w1 * x1 + za.w2 * x2 + za.w3 * x3;
             bv = zb.w0 * y0 + zb.w1 * y1 + zb.w2 * y2 + zb.w3 * y3;
         };
-        // The gradient column (row 45 of M) is not a tile row: z_g = lq + Ws d needs a 16-term combination per block.  The wave of tile (0, 0) -- one
-        // operand, the lightest -- carries it instead as v = W^T z_g: lane <-> published row (0..14 Ws, 15 lq, 16..45 the identity rows), z_g of the block
+        // The gradient column (row 45 of M) is not a tile row: z_g = lq + Ws d would need a 16-term combination per block in three tiles.  The wave of tile (2, 2)
+        // carries it instead as v = W^T z_g: lane <-> published row (0..14 Ws, 15 lq, 16..45 the identity rows), z_g of the block
         // by a 16-lane DPP sum, v += x . z_g; at the end M[45][j] -= sum_a w_a(j) v[r_a(j)], the same sparse combination as a row of Z^T.
         const bool grole = wv == 5;
         const int grow = ln < NS ? ln : (ln == NS ? NPAN - 1 : (ln < NPAN ? ln - 1 : 0));

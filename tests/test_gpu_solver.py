@@ -371,6 +371,27 @@ def test_hbm_factor_and_resident_variants_agree(N, monkeypatch):
         assert e["com"] < 2e-5 and e["forces"] < 5e-5 and e["pos"] < 2e-5, (b, e)
 
 
+@pytest.mark.parametrize("gen", ["push_recovery_n12", "walking_push_n12", "yawed_steps_n12"])
+def test_streaming_stage_matches_the_value_function_stage_on_stepping_problems(gen, monkeypatch):
+    """Problems with free landing offsets (pivot blocks 8 and 9 of the stage Hessian are factorised, a foot at a time) through both backward stages: the
+    streaming square-root stage of the resident variants (N = 12 instantiation) and the value-function stage of the HBM-factor variants.  Same optimum, iteration
+    counts within two.  (A wrong descriptor set in the streaming stage showed here first: 9 -> 12..40 iterations on these very problems.)"""
+    cfg, P, X0 = getattr(cm.synthetic, gen)("tmp")
+    P32, X032 = P.astype(np.float32), X0.astype(np.float32)
+    out = {}
+    for factors in ("lds", "hbm"):
+        monkeypatch.setenv("CMPC_FACTORS", factors)
+        s = cm.BatchSolver(cfg, P32.shape[0])
+        X, info, rc = s.solve_host(P32, X032)
+        assert rc == 0 and (info[:, 5] == 0).all(), (factors, info[:, 5], s.last_error)
+        out[factors] = (X, info)
+        s.close()
+    assert np.abs(out["lds"][1][:, 0] - out["hbm"][1][:, 0]).max() <= 2, (out["lds"][1][:, 0], out["hbm"][1][:, 0])
+    for b in range(P32.shape[0]):
+        e = parity.errors(cfg.N, P32[b], out["hbm"][0][b], out["lds"][0][b])
+        assert e["com"] < 3e-5 and e["forces"] < 1e-4 and e["pos"] < 3e-5, (b, e)
+
+
 @pytest.mark.parametrize("B", [5, 1024])
 @pytest.mark.parametrize("where", ["com_ref", "f_ext", "x0"])
 def test_a_single_nan_is_reported_not_returned_as_converged(B, where):
