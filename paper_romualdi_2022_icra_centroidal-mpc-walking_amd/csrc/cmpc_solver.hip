@@ -308,9 +308,14 @@ __device__ inline void fric_row(const Ctx& c, const CmpcConsts& prm, int k, int 
     const float* R = c.sp + c.L.pR(ct) + 9 * k;
     const float sx = (face == 0 || face == 3) ? 1.f : -1.f;
     const float sy = (face < 2) ? 1.f : -1.f;
-    a0 = sx * Rm(R, 0, 0) + sy * Rm(R, 0, 1) - prm.mu_fr * Rm(R, 0, 2);
-    a1 = sx * Rm(R, 1, 0) + sy * Rm(R, 1, 1) - prm.mu_fr * Rm(R, 1, 2);
-    a2 = sx * Rm(R, 2, 0) + sy * Rm(R, 2, 1) - prm.mu_fr * Rm(R, 2, 2);
+    // Explicit fused multiply-adds, here and in row_val / row_dot: these are inlined in half a dozen places (initial slacks, residuals, the barrier gradient z/t (a u - b + t)
+    // of the descriptors, the slack step of the forward sweep) whose roundings must AGREE -- the gradient multiplies the residual by z/t, up to 1e9, and the forward
+    // sweep subtracts the same residual again.  Left to the compiler, one inlined copy contracted a*b + c differently from the others (a variant of the descriptor
+    // builder, round 3): one ulp of a u, times z/t, is a spurious gradient, and walking problems needed 12-40 iterations instead of 9.
+    const float nmu = -prm.mu_fr;
+    a0 = __builtin_fmaf(nmu, Rm(R, 0, 2), __builtin_fmaf(sy, Rm(R, 0, 1), sx * Rm(R, 0, 0)));
+    a1 = __builtin_fmaf(nmu, Rm(R, 1, 2), __builtin_fmaf(sy, Rm(R, 1, 1), sx * Rm(R, 1, 0)));
+    a2 = __builtin_fmaf(nmu, Rm(R, 2, 2), __builtin_fmaf(sy, Rm(R, 2, 1), sx * Rm(R, 2, 0)));
 }
 
 __device__ inline bool row_active(const Ctx& c, int k, int i) { return i < 32 ? true : qfree(c, k, (i - 32) % 6); }
@@ -322,7 +327,7 @@ __device__ inline float row_val(const Ctx& c, const CmpcConsts& prm, int k, int 
         float a0, a1, a2;
         fric_row(c, prm, k, i, a0, a1, a2);
         const float* f = u + 3 * (i >> 2);
-        return a0 * f[0] + a1 * f[1] + a2 * f[2];
+        return __builtin_fmaf(a2, f[2], __builtin_fmaf(a1, f[1], a0 * f[0]));
     }
     if (i < 38) return u[24 + i - 32] - qhi(c, k, i - 32);
     return qlo(c, k, i - 38) - u[24 + i - 38];
@@ -333,7 +338,7 @@ __device__ inline float row_dot(const Ctx& c, const CmpcConsts& prm, int k, int 
         float a0, a1, a2;
         fric_row(c, prm, k, i, a0, a1, a2);
         const float* f = du + 3 * (i >> 2);
-        return a0 * f[0] + a1 * f[1] + a2 * f[2];
+        return __builtin_fmaf(a2, f[2], __builtin_fmaf(a1, f[1], a0 * f[0]));
     }
     if (i < 38) return du[24 + i - 32];
     return -du[24 + i - 38];
@@ -1782,9 +1787,7 @@ __device__ inline void sq_consume_body(Ctx c, const CmpcConsts& prm, int tid, in
     if (w7 == 4) {
         if (kd >= 0) {
             use_desc_set(c, kd & 1);
-            // (one role per trip -- B columns, A columns, barrier rows, exact-Hessian block -- each on lanes 0..n-1.  The same work as two calls with t = lane and
-            //  t = 64 + lane gave different descriptors in this place (deterministically: walking problems then needed up to 4x the iterations); the cause was
-            //  not found, the role loop is what the tests pin)
+            // (one role per trip -- B columns, A columns, barrier rows, exact-Hessian block -- each on lanes 0..n-1)
 #pragma unroll 1
             for (int r = 0; r < 4; ++r) stage_desc_body(c, prm, desc_role_t(r, ln), kd, use_exact, cmu);
         }
