@@ -109,7 +109,29 @@ __device__ float g_trace[64 * 8];  // per iteration of workgroup 0: mu, ep, ec, 
 #define PROF5(slot) do { long long n_ = __builtin_amdgcn_s_memtime(); if (threadIdx.x == (NT >= 512 ? 448 : 216) && blockIdx.x == 0) g_prof[slot] += n_ - pt2_; pt2_ = n_; } while (0)
 // fire-and-forget stamp of the consumer waves (no wait on the atomic): slot 32 + 5 * wave + i
 #define CPROF(i) do { if (ln == 0 && blockIdx.x == 0 && k < N) atomicAdd(reinterpret_cast<unsigned long long*>(&g_prof[32 + 5 * wv + (i)]), (unsigned long long)(__builtin_amdgcn_s_memtime() - pc0_)); } while (0)
+// -DCMPC_PROFILE_LIGHT: only the stamps of the driver and the one per backward pass (the stamps inside a stage cost ~10 % of it)
+#ifdef CMPC_PROFILE_LIGHT
+#undef PROF2_DECL
+#undef PROF2
+#undef PROF3
+#undef PROF4
+#undef PROF5
+#undef CPROF
+#define PROF2_DECL
+#define PROF2(slot)
+#define PROF3(slot)
+#define PROF4(slot)
+#define PROF5(slot)
+#define CPROF(i)
+#define SQPROF_DECL
+#define SQPROF(slot)
 #else
+#define SQPROF_DECL PROF_DECL
+#define SQPROF(slot) PROF(slot)
+#endif
+#else
+#define SQPROF_DECL
+#define SQPROF(slot)
 #define CPROF(i)
 #define PROF_DECL
 #define PROF(slot)
@@ -1764,18 +1786,21 @@ __device__ __attribute__((noinline)) void sq_factor_loop(lds_t lds, int Nrt, flo
         const CmpcConsts& prm = *reinterpret_cast<const CmpcConsts*>(smk);
         const int s = k & 1;
         const int fixedmask = (~c.qmask[k]) & 63;
-        PROF_DECL;
+        SQPROF_DECL;
         // (one wave: its second SIMD's worth of issue slots goes to the consumers -- the eight-wave shape is bound by what waves 1-7 can issue under the factorisation)
         stage_factor<true, FG, true>(c.QuuF + s * MSET, s ? c.QuuD1 : c.QuuD, c.Pan + s * MSET, RecRef<FG>(c.Lf, N, k), prm.D[0], prm.D[1], prm.D[2], c.flag, tid,
                                      fixedmask, c.ZT, c.prog + tid, 16 * ord);
-        PROF(9);           // (wave 0: the factorisation alone)
+        SQPROF(9);         // (wave 0: the factorisation alone)
         __syncthreads();
-        PROF(3);
+        SQPROF(3);
     }
     __builtin_amdgcn_s_setprio(0);
 }
 // k: stage being factorised meanwhile (N: none, only the terminal stage's successor is assembled); kb: stage to assemble; kd: stage whose descriptors are built
 // meanwhile (-1: none); ord: ordinal of the stage within the backward pass.  All uniform.  (c by value: the descriptor set is selected in the copy)
+#ifndef CMPC_SQ_DEV
+#define CMPC_SQ_DEV 0    // timing probes of the streaming stage (wrong numerics; read 'cycles per stage of a pass' of a -DCMPC_PROFILE -DCMPC_PROFILE_LIGHT build):
+#endif                   //  1 no assembly, 2 no tiles, 4 no descriptors, 8 no gradient role
 __device__ inline void sq_consume_body(Ctx c, const CmpcConsts& prm, int tid, int N, int k, int kb, int kd, int ord, bool havep, bool use_exact, float reg, float cmu)
 {
     const float* Wb = c.ZT;                                       // published W^T, [block][panel row][4]
@@ -1785,7 +1810,7 @@ __device__ inline void sq_consume_body(Ctx c, const CmpcConsts& prm, int tid, in
     const int w7 = tid >> 6, ln = tid & 63, m4 = ln & 15, kq = ln >> 4;
     const int wv = w7 < 4 ? w7 - 1 : w7 - 2, t = 64 * wv + ln;
     if (w7 == 4) {
-        if (kd >= 0) {
+        if (!(CMPC_SQ_DEV & 4) && kd >= 0) {
             use_desc_set(c, kd & 1);
             // (one role per trip -- B columns, A columns, barrier rows, exact-Hessian block -- each on lanes 0..n-1)
 #pragma unroll 1
@@ -1818,11 +1843,11 @@ __device__ inline void sq_consume_body(Ctx c, const CmpcConsts& prm, int tid, in
         }
         asm volatile("" ::: "memory");
     }
-    sq_base_body<384, true>(c, prm, t, kb, havep, reg, QuuFn, s ? c.QuuD1 : c.QuuD, Pann, Qbn, qsn, c.Qb + sc * NS * 16, sc ? c.qs1 : c.qs, YT);
+    if (!(CMPC_SQ_DEV & 1)) sq_base_body<384, true>(c, prm, t, kb, havep, reg, QuuFn, s ? c.QuuD1 : c.QuuD, Pann, Qbn, qsn, c.Qb + sc * NS * 16, sc ? c.qs1 : c.qs, YT);
     asm volatile("" ::: "memory");
     if (ln == 0) __hip_atomic_fetch_add(c.flag + 3, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     CPROF(1);
-    if (k < N) {
+    if (!(CMPC_SQ_DEV & 2) && k < N) {
         typedef float v4f __attribute__((ext_vector_type(4)));
         const int I = wv >= 3 ? 2 : (wv >= 1 ? 1 : 0), J = wv - I * (I + 1) / 2;
         const ZRow za = zrow_of(c, prm, 16 * I + m4), zb = zrow_of(c, prm, 16 * J + m4);
@@ -1857,7 +1882,7 @@ __device__ inline void sq_consume_body(Ctx c, const CmpcConsts& prm, int tid, in
         // The gradient column (row 45 of M) is not a tile row: z_g = lq + Ws d would need a 16-term combination per block in three tiles.  The wave of tile (2, 2)
         // carries it instead as v = W^T z_g: lane <-> published row (0..14 Ws, 15 lq, 16..45 the identity rows), z_g of the block
         // by a 16-lane DPP sum, v += x . z_g; at the end M[45][j] -= sum_a w_a(j) v[r_a(j)], the same sparse combination as a row of Z^T.
-        const bool grole = wv == 5;
+        const bool grole = wv == 5 && !(CMPC_SQ_DEV & 8);
         const int grow = ln < NS ? ln : (ln == NS ? NPAN - 1 : (ln < NPAN ? ln - 1 : 0));
         const float gw = grole ? (ln < NS ? c.d[NS * kb + ln] : (ln == NS ? 1.f : 0.f)) : 0.f;
         float vacc = 0.f;
