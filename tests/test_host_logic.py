@@ -126,6 +126,20 @@ def test_c_abi_exports_every_declared_symbol():
         assert hasattr(lib, name), name
 
 
+def test_lds_images_fit_the_cu():
+    """The LDS image the launcher asks for (host function, no GPU): the resident variants -- whole problem and the working sets of the streaming stage in LDS,
+    one workgroup per CU -- fit the 160 KiB of a CU for every horizon the reference ships a configuration for (10..22); the HBM-factor image fits THREE times
+    at the bench horizons (three workgroups per CU is what cmpc_create assumes above the CU count)."""
+    lib = ctypes.CDLL(cm._capi.LIB_PATH)
+    lib.cmpc_solver_lds_bytes.restype = ctypes.c_size_t
+    lib.cmpc_solver_lds_bytes.argtypes = [ctypes.c_int, ctypes.c_int]
+    for N in (10, 12, 13, 15, 20, 22):
+        assert lib.cmpc_solver_lds_bytes(N, 0) <= 160 * 1024, (N, lib.cmpc_solver_lds_bytes(N, 0))
+    for N in (20, 30):
+        assert 3 * lib.cmpc_solver_lds_bytes(N, 1) <= 160 * 1024, (N, lib.cmpc_solver_lds_bytes(N, 1))
+    assert lib.cmpc_solver_lds_bytes(30, 0) > 160 * 1024   # (N = 30 never runs resident: cmpc_create falls back to the HBM-factor variant)
+
+
 def test_dims_and_sparsity_need_no_gpu():
     lib = cm._capi.lib()
     v = [ctypes.c_int() for _ in range(5)]
