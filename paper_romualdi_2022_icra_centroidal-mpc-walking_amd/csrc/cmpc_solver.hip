@@ -65,6 +65,9 @@
 #define CMPC_SQRT_BACKWARD 1
 #endif
 #define CMPC_SQ(NT, FG) (CMPC_SQRT_BACKWARD && !(FG) && (NT) >= 512)
+#define SQ_TILE_WAVES 6        // consumer waves of the streaming stage that own a tile (and a share of the assembly): the two completion counts advance by this per stage
+#define SQ_SPIN_MAX (1 << 20)  // looks at a progress word or a count before a waiting wave gives up (raises the failure flag: the pass ends as a failed factorisation)
+#define SQ_PUB_FLOATS (10 * NPAN * 4 + 128 * 4)   // published W^T: ten pivot blocks x 46 panel rows x float4, and a slot per lane of two waves for lanes without a panel row
 #define ZLD 36     // leading dim of Z^T (48 rows: 30 u-columns, 15 s-columns, the gradient column, 2 zero rows)
 #define MSET (NU * RLD + NPAN * RLD)   // floats of one set QuuF | Pan (the resident variants hold two: stage k is factorised from set k & 1)
 #define NTRI 256   // entries of the lower-triangle index table (the users need 210: 2x2 tiles of a 39x39)
@@ -246,7 +249,7 @@ __device__ inline void make_ctx(Ctx& c, char* smem, int N, float* fg_base)
         // resident variants: QuuF0 | Pan0 | QuuF1 | Pan1 | Z^T | Qb0 | Qb1 -- G and P0 (only the four-wave developer variant still forms them) lie over set 1 and Z^T
         c.G = fp; c.P0 = fp + ((NXA * GLD + 3) & ~3);
         fp += MSET;
-        c.ZT = fp; fp += 10 * NPAN * 4 + 128 * 4;   // Z^T (48 x ZLD) or -- streaming stage -- the published W^T, [block][panel row][4]
+        c.ZT = fp; fp += SQ_PUB_FLOATS;   // Z^T (48 x ZLD) or -- streaming stage -- the published W^T, [block][panel row][4]
         c.Qb = fp; fp += 2 * NS * 16;
     } else {
     c.G = fp; fp += (NXA * GLD + 3) & ~3;                   // (sizes rounded to 16 bytes: ybuf and the LDS factor records
@@ -1835,10 +1838,10 @@ __device__ inline void sq_consume_body(Ctx c, const CmpcConsts& prm, int tid, in
     asm volatile("" ::: "memory");
     if (ln == 0) __hip_atomic_fetch_add(c.flag + 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     {
-        const int want = 6 * (ord + 1);
+        const int want = SQ_TILE_WAVES * (ord + 1);
         int spins = 0;
         while (lds_peek(c.flag + 2) < want) {
-            if (++spins > (1 << 20)) { if (ln == 0) *c.flag = 1; break; }
+            if (++spins > SQ_SPIN_MAX) { if (ln == 0) *c.flag = 1; break; }
             __builtin_amdgcn_s_sleep(1);
         }
         asm volatile("" ::: "memory");
@@ -1863,7 +1866,7 @@ __device__ inline void sq_consume_body(Ctx c, const CmpcConsts& prm, int tid, in
             for (;;) {
                 avail = lds_peek(prog) - seq0;
                 if (avail >= nblk) break;
-                if (++spins > (1 << 20)) { gaveup = true; avail = 16; break; }
+                if (++spins > SQ_SPIN_MAX) { gaveup = true; avail = 16; break; }
                 __builtin_amdgcn_s_sleep(1);
             }
             asm volatile("" ::: "memory");
@@ -1911,10 +1914,10 @@ __device__ inline void sq_consume_body(Ctx c, const CmpcConsts& prm, int tid, in
         // every consumer wave's part of the assembly must be in LDS before the tiles are subtracted from it; then what the tile is subtracted from
         // is fetched -- ahead of the last blocks, off the tail of the stage
         {
-            const int want = 6 * (ord + 1);
+            const int want = SQ_TILE_WAVES * (ord + 1);
             int spins = 0;
             while (lds_peek(c.flag + 3) < want) {
-                if (++spins > (1 << 20)) { gaveup = true; break; }
+                if (++spins > SQ_SPIN_MAX) { gaveup = true; break; }
                 __builtin_amdgcn_s_sleep(1);
             }
             asm volatile("" ::: "memory");
@@ -3046,7 +3049,7 @@ extern "C" size_t cmpc_solver_lds_bytes(int N, int factors_global)
     CmpcLayout L;
     cmpc_layout_init(L, N);
     const size_t dbl = 90 + 40 + 40 + 16 + 40 + 4 * NI + 8 + (factors_global ? 0 : 90 + 16);
-    const size_t work = factors_global ? ((NXA * PLD + 3) & ~3) + NS * 16 + ((NXA * GLD + 3) & ~3) : (size_t)MSET + 10 * NPAN * 4 + 128 * 4 + 2 * NS * 16 + 128;   // (see make_ctx)
+    const size_t work = factors_global ? ((NXA * PLD + 3) & ~3) + NS * 16 + ((NXA * GLD + 3) & ~3) : (size_t)MSET + SQ_PUB_FLOATS + 2 * NS * 16 + 128;   // (see make_ctx)
     const size_t flt = (size_t)NU * RLD + (size_t)NPAN * RLD + 96 + ((L.np + 3) & ~3)
                        + ((size_t)NS * (N + 1) + (size_t)NU * N + ((factors_global && N > CMPC_TZ_LDS_NMAX) ? 0 : 2 * (size_t)NI * N)) + (size_t)NS * N + (size_t)NS * (N + 1)
                        + (size_t)GEO * N + work + 2 * DSET_F + 40 + 40 + 24
