@@ -1991,9 +1991,12 @@ __device__ __attribute__((noinline)) void sq_consume_loop(lds_t lds, int Nrt, fl
     CMPC_PHASE_PROLOGUE;
     const int k0 = __builtin_amdgcn_readfirstlane(k0_in);
     const bool use_exact = __builtin_amdgcn_readfirstlane((int)exact_in) != 0;
-    // (k = N: the assembly of stage N-1 from the terminal cost, no factorisation to follow; the body appears once -- two inlined copies were 20 KB of code more)
+    sq_consume_body(c, prm, tid, N, N, N - 1, -1, 0, false, use_exact, reg, cmu);
+    __syncthreads();
+    int ord = 0;
 #pragma unroll 1
-    for (int k = N; k >= k0; --k) {
+    for (int k = N - 1; k >= k0; --k) {
+        ++ord;
         if (k > k0) {
             // (the LDS map is rebuilt from an opaque copy of the base every stage -- constant offsets, a handful of adds -- instead of living in ~60 registers across the loop:
             //  held live it pushed the function into the callee-saved registers, 33 of them saved to scratch per lane and pass: 56 MB of scratch writes per B = 256 launch)
@@ -2002,7 +2005,7 @@ __device__ __attribute__((noinline)) void sq_consume_loop(lds_t lds, int Nrt, fl
             char* smk = (char*)lk;
             Ctx ck;
             make_ctx<FG>(ck, smk, N, fg_base);
-            sq_consume_body(ck, *reinterpret_cast<const CmpcConsts*>(smk), tid, N, k, k - 1, (k < N && k - 2 >= k0) ? k - 2 : -1, N - k, k < N, use_exact, reg, cmu);
+            sq_consume_body(ck, *reinterpret_cast<const CmpcConsts*>(smk), tid, N, k, k - 1, k - 2 >= k0 ? k - 2 : -1, ord, true, use_exact, reg, cmu);
         }
         __syncthreads();
     }
