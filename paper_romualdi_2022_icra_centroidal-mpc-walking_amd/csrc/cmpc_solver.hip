@@ -671,102 +671,120 @@ __device__ inline double rcp_d(double x)
     const double r = (double)__builtin_amdgcn_rcpf((float)x);
     return r * (2.0 - x * r);
 }
-// The row lives in 15 register pairs (vv[j / 2][j % 2] = entry j) so that the trailing update can use packed FMAs.
-typedef float float2v __attribute__((ext_vector_type(2)));
-#define VE(j) vv[(j) >> 1][(j) & 1]
+// The row lives in eight 4-column groups (acc[g][i] = entry 4 g + i; columns 30, 31 are padding): the accumulators of the trailing update.
+//
+// Trailing update on the matrix pipe (round 4).  v_mfma_f32_4x4x1_16b_f32 computes sixteen independent 4 x 4 outer products, block q on lanes
+// 4 q .. 4 q + 3: acc_l[i] += A[lane 4 q + i] B[lane l].  With cbsz:4 abid:g the A values of block g serve ALL sixteen blocks:
+//     acc_l[i] += A[lane 4 g + i] * B[lane l]        for every lane l, i = 0..3
+// (checked bit for bit against fmaf on MI355X: tools/micro/mfma4x4_probe.hip, profiles/r04_mfma4x4_probe.txt).  The multipliers of a pivot
+// column, L[c][j], are the x of lanes c = j0 + 3 .. 29 -- the L rows live in the lanes of their row number -- so with A = -x (zero outside those
+// lanes) and B = the lane's own x, ONE instruction applies a pivot column to four trailing columns of all 64 rows: three per group and pivot block,
+// 126 per factorisation at 8 cycles each, where rounds 1-3 issued 6 v_readlane + 3 v_pk_fma_f32 per column PAIR (525 + 260 instructions, a third of
+// the phase).  Measured in isolation: 27 cycles per four columns and pivot block against 81.  f32-input MFMA is an exact fmaf chain (MI355X_MICROARCH.md),
+// and the order per entry (pivot columns j0, j0 + 1, j0 + 2) is the one the packed FMAs had: the factors are bit-identical.
+typedef float v4f __attribute__((ext_vector_type(4)));
+#define VE(j) acc[(j) >> 2][(j) & 3]
 // ONE: the whole factorisation on one wave.  76 rows do not fit 64 lanes, but the L rows of the first blocks are finished
-// (and never read again: broadcasts only come from rows below the pivot block, and L itself is not kept) long before the
+// (and never read again: multipliers only come from rows below the pivot block, and L itself is not kept) long before the
 // identity rows of the last columns start to differ from unit vectors: at block LATE_B the lanes of L rows 0..NLATE-1 are
 // re-used for the identity rows LATE_M0..NU-1, which is exact because such a row is e_m until block m / 3.
 #define LATE_B 6
 #define LATE_M0 18
 #define NLATE (NU - LATE_M0)
+// rank-1 update of the column groups G0 .. 7 (av: -x of the L rows below the pivot block, 0 elsewhere; bv: the lane's own x)
+template <int G0>
+__device__ __forceinline__ void trail_rank1(v4f (&acc)[8], float av, float bv)
+{
+#define CMPC_R1(G) if constexpr (G >= G0) acc[G] = __builtin_amdgcn_mfma_f32_4x4x1f32(av, bv, acc[G], 4, G, 0);
+    CMPC_R1(0) CMPC_R1(1) CMPC_R1(2) CMPC_R1(3) CMPC_R1(4) CMPC_R1(5) CMPC_R1(6) CMPC_R1(7)
+#undef CMPC_R1
+}
 // PUB (streaming square-root stage): after every pivot block the finished entries x0..x2 of this lane's panel row go to pub[(46 b + prow) * 4 ..]
 // and the wave's progress word *pflag is set to seq0 + b + 1.  LDS operations of one wave execute in issue order: whoever sees the flag sees the data.
-template <bool ONE, bool PUB = false>
-__device__ __forceinline__ bool chol_solve_fused(float2v (&vv)[NU / 2], double (&dd)[3], int lane, int fixedmask, float* pub = nullptr, int prow = 0,
-                                                 int pubstride = 0, int* pflag = nullptr, int seq0 = 0, float* publate = nullptr)
+struct CholPub { float* pub; int stride; int* pflag; int seq0; float* publate; };
+// pivot block B (columns 3 B .. 3 B + 2).  Returns true if a pivot was not positive.
+template <int B, bool ONE, bool PUB>
+__device__ __forceinline__ bool chol_block(v4f (&acc)[8], double (&dd)[3], int lane, int fixedmask, CholPub& pb)
 {
-    const int myblk = lane / 3;
-    bool bad = false;
-#pragma unroll
-    for (int b = 0; b < NU / 3; ++b) {
-        const int j0 = 3 * b;
-        if (ONE && b == LATE_B) {
-            if (lane < NLATE) {
-                const unsigned hot = 1u << (LATE_M0 + lane);   // (bit-field extract + convert: two instructions per entry, no
-#pragma unroll                                                  //  compare -> mask hazard slots)
-                for (int cc = 0; cc < NU; ++cc) VE(cc) = (float)((hot >> cc) & 1u);
-                if (PUB) { pub = publate; pubstride = NPAN * 4; }   // (the identity row this lane now holds: its entries of the earlier blocks are zeros, kept zero in the buffer)
-            }
-        }
-        // (opaque copies: the lane predicates are recomputed per block instead of living in hoisted, spilled SGPR pairs)
-        int myb = myblk;
-        asm volatile("" : "+v"(myb));
-        const bool inblk = (myb == b);
-        if (inblk) {
-            dd[0] += (double)VE(j0);
-            dd[1] += (double)VE(j0 + 1);
-            dd[2] += (double)VE(j0 + 2);
-        }
-        // a stance foot's landing offsets are identity rows and columns: nothing to do
-        if (j0 >= NF && ((fixedmask >> (j0 - NF)) & 7) == 7) continue;
-        const double d00 = readlane_d(dd[0], j0);
-        const double d10 = readlane_d(dd[0], j0 + 1), d11 = readlane_d(dd[1], j0 + 1);
-        const double d20 = readlane_d(dd[0], j0 + 2), d21 = readlane_d(dd[1], j0 + 2), d22 = readlane_d(dd[2], j0 + 2);
-        // Float64 only where cancellation decides the answer: the Schur pivots p1, p2 of the block (barrier terms ~1e9 next to
-        // cost curvature ~20) through two accurate reciprocals.  The entries of L are float32 numbers anyway (rows are stored
-        // and applied in float32): they come from the float32 casts of the pivots and v_rsq_f32.
-        const double i00 = rcp_d(d00);
-        const double m10 = d10 * i00, m20 = d20 * i00;
-        const double p1 = d11 - m10 * d10;
-        const double t21 = d21 - m10 * d20;
-        const double i11 = rcp_d(p1);
-        const double m21 = t21 * i11;
-        const double p2 = (d22 - m20 * d20) - m21 * t21;
-        const float p0f = (float)d00, p1f = (float)p1, p2f = (float)p2;
-        const float r00 = __builtin_amdgcn_rsqf(p0f), r11 = __builtin_amdgcn_rsqf(p1f), r22 = __builtin_amdgcn_rsqf(p2f);
-        const float l10 = (float)d10 * r00, l20 = (float)d20 * r00, l21 = (float)t21 * r11;
-        // a non-positive pivot: v_rsq_f32 of a negative number is NaN, of zero inf; p1 and p2 inherit a bad d00 through i00
-        bad = bad || !(p0f > 0.f) || !(p1f > 0.f) || !(p2f > 0.f);
-        // rows below the block and panel rows: x = v[j0..j0+2] L_bb^{-T}
-        float x0 = VE(j0) * r00;
-        float x1 = (VE(j0 + 1) - x0 * l10) * r11;
-        float x2 = (VE(j0 + 2) - x0 * l20 - x1 * l21) * r22;
-        // (the block's own three lanes get meaningless x here -- their slots of the block are zero -- and that is fine: L itself
-        // is not kept, broadcasts only come from rows below the pivot block, so a lane's registers are dead once its block is done)
-        VE(j0) = x0; VE(j0 + 1) = x1; VE(j0 + 2) = x2;
-        if (PUB) {
-            // (no lane predicates here: a lane without a panel row writes to a slot of its own behind the blocks, and every lane keeps its own copy of the progress word)
-            *reinterpret_cast<float4*>(pub + pubstride * b) = make_float4(x0, x1, x2, 0.f);
-            asm volatile("" ::: "memory");
-            __hip_atomic_store(pflag, seq0 + b + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
-        // rank-3 update of the trailing columns: a leading odd column alone, then two columns per packed FMA.  Each
-        // update is pinned here: left alone, the optimiser sinks the FMAs to the block that next reads the column and
-        // the broadcast scalars (81 per block) wait for them in SGPRs spilled to VGPR lanes
-        if ((j0 + 3) & 1) {
-            const int cc = j0 + 3;
-            if (cc < NU) {
-                VE(cc) = fmaf(-x2, readlane_f(x2, cc), fmaf(-x1, readlane_f(x1, cc), fmaf(-x0, readlane_f(x0, cc), VE(cc))));
-                asm volatile("" : "+v"(vv[cc >> 1]));
-            }
-        }
-        const float2v nx0 = {-x0, -x0}, nx1 = {-x1, -x1}, nx2 = {-x2, -x2};
-#pragma unroll
-        for (int pp = (j0 + 4) >> 1; pp < NU / 2; ++pp) {
-            const int cc = 2 * pp;
-            const float2v s0 = {readlane_f(x0, cc), readlane_f(x0, cc + 1)};
-            const float2v s1 = {readlane_f(x1, cc), readlane_f(x1, cc + 1)};
-            const float2v s2 = {readlane_f(x2, cc), readlane_f(x2, cc + 1)};
-            float2v acc = vv[pp];
-            acc = __builtin_elementwise_fma(nx0, s0, acc);
-            acc = __builtin_elementwise_fma(nx1, s1, acc);
-            acc = __builtin_elementwise_fma(nx2, s2, acc);
-            vv[pp] = acc;
-            asm volatile("" : "+v"(vv[pp]));
+    constexpr int j0 = 3 * B;
+    if (ONE && B == LATE_B) {
+        if (lane < NLATE) {
+            const unsigned hot = 1u << (LATE_M0 + lane);   // (bit-field extract + convert: two instructions per entry, no
+#pragma unroll                                              //  compare -> mask hazard slots)
+            for (int cc = 0; cc < NU; ++cc) VE(cc) = (float)((hot >> cc) & 1u);
+            if (PUB) { pb.pub = pb.publate; pb.stride = NPAN * 4; }   // (the identity row this lane now holds: its entries of the earlier blocks are zeros, kept zero in the buffer)
         }
     }
+    // (opaque copy: the lane predicates are recomputed per block instead of living in hoisted, spilled SGPR pairs)
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+    if ((unsigned)(ln - j0) < 3u) {
+        dd[0] += (double)VE(j0);
+        dd[1] += (double)VE(j0 + 1);
+        dd[2] += (double)VE(j0 + 2);
+    }
+    // a stance foot's landing offsets are identity rows and columns: nothing to do
+    if (j0 >= NF && ((fixedmask >> (j0 - NF)) & 7) == 7) return false;
+    const double d00 = readlane_d(dd[0], j0);
+    const double d10 = readlane_d(dd[0], j0 + 1), d11 = readlane_d(dd[1], j0 + 1);
+    const double d20 = readlane_d(dd[0], j0 + 2), d21 = readlane_d(dd[1], j0 + 2), d22 = readlane_d(dd[2], j0 + 2);
+    // Float64 only where cancellation decides the answer: the Schur pivots p1, p2 of the block (barrier terms ~1e9 next to
+    // cost curvature ~20) through two accurate reciprocals.  The entries of L are float32 numbers anyway (rows are stored
+    // and applied in float32): they come from the float32 casts of the pivots and v_rsq_f32.
+    const double i00 = rcp_d(d00);
+    const double m10 = d10 * i00, m20 = d20 * i00;
+    const double p1 = d11 - m10 * d10;
+    const double t21 = d21 - m10 * d20;
+    const double i11 = rcp_d(p1);
+    const double m21 = t21 * i11;
+    const double p2 = (d22 - m20 * d20) - m21 * t21;
+    const float p0f = (float)d00, p1f = (float)p1, p2f = (float)p2;
+    const float r00 = __builtin_amdgcn_rsqf(p0f), r11 = __builtin_amdgcn_rsqf(p1f), r22 = __builtin_amdgcn_rsqf(p2f);
+    const float l10 = (float)d10 * r00, l20 = (float)d20 * r00, l21 = (float)t21 * r11;
+    // a non-positive pivot: v_rsq_f32 of a negative number is NaN, of zero inf; p1 and p2 inherit a bad d00 through i00
+    const bool bad = !(p0f > 0.f) || !(p1f > 0.f) || !(p2f > 0.f);
+    // rows below the block and panel rows: x = v[j0..j0+2] L_bb^{-T}
+    const float x0 = VE(j0) * r00;
+    const float x1 = (VE(j0 + 1) - x0 * l10) * r11;
+    const float x2 = (VE(j0 + 2) - x0 * l20 - x1 * l21) * r22;
+    // (the block's own three lanes get meaningless x here -- their slots of the block are zero -- and that is fine: L itself
+    // is not kept, multipliers only come from rows below the pivot block, so a lane's registers are dead once its block is done)
+    VE(j0) = x0; VE(j0 + 1) = x1; VE(j0 + 2) = x2;
+    if (PUB) {
+        // (no lane predicates here: a lane without a panel row writes to a slot of its own behind the blocks, and every lane keeps its own copy of the progress word)
+        *reinterpret_cast<float4*>(pb.pub + pb.stride * B) = make_float4(x0, x1, x2, 0.f);
+        asm volatile("" ::: "memory");
+        __hip_atomic_store(pb.pflag, pb.seq0 + B + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    // rank-3 update of the trailing columns j0 + 3 .. 29 on the matrix pipe (see above): multipliers from the lanes of the L rows below the block.
+    // Pivot-column-major over the groups: the three updates of one group are a dependent chain (20 cycles apart alone, 8 when interleaved).
+    if constexpr (j0 + 3 < NU) {
+        const bool below = (unsigned)(ln - (j0 + 3)) < (unsigned)(NU - (j0 + 3));
+        const float a0 = below ? -x0 : 0.f, a1 = below ? -x1 : 0.f, a2 = below ? -x2 : 0.f;
+        constexpr int G0 = (j0 + 3) >> 2;
+        trail_rank1<G0>(acc, a0, x0);
+        trail_rank1<G0>(acc, a1, x1);
+        trail_rank1<G0>(acc, a2, x2);
+    }
+    return bad;
+}
+// ---- fused Cholesky + panel solve, one wave, rows in registers, 3x3 pivot blocks (see the comment block above rcp_d) ----
+template <bool ONE, bool PUB = false>
+__device__ __forceinline__ bool chol_solve_fused(v4f (&acc)[8], double (&dd)[3], int lane, int fixedmask, float* pub = nullptr, int prow = 0,
+                                                 int pubstride = 0, int* pflag = nullptr, int seq0 = 0, float* publate = nullptr)
+{
+    CholPub pb{pub, pubstride, pflag, seq0, publate};
+    bool bad = false;
+    bad |= chol_block<0, ONE, PUB>(acc, dd, lane, fixedmask, pb);
+    bad |= chol_block<1, ONE, PUB>(acc, dd, lane, fixedmask, pb);
+    bad |= chol_block<2, ONE, PUB>(acc, dd, lane, fixedmask, pb);
+    bad |= chol_block<3, ONE, PUB>(acc, dd, lane, fixedmask, pb);
+    bad |= chol_block<4, ONE, PUB>(acc, dd, lane, fixedmask, pb);
+    bad |= chol_block<5, ONE, PUB>(acc, dd, lane, fixedmask, pb);
+    bad |= chol_block<6, ONE, PUB>(acc, dd, lane, fixedmask, pb);
+    bad |= chol_block<7, ONE, PUB>(acc, dd, lane, fixedmask, pb);
+    bad |= chol_block<8, ONE, PUB>(acc, dd, lane, fixedmask, pb);
+    bad |= chol_block<9, ONE, PUB>(acc, dd, lane, fixedmask, pb);
     return bad;
 }
 
@@ -783,7 +801,7 @@ __device__ __forceinline__ void stage_factor(const float* QuuF, const double* Qu
     const int prow = ONE ? (pi < NS ? pi : (pi == NS ? NPAN - 1 : pi - 1)) : pi + 34 * wv;
     const bool isL = lane < NU;
     const bool active = isL || prow < NPAN;
-    float2v vv[NU / 2];
+    v4f acc[8];
     double dd[3] = {0.0, 0.0, 0.0};
     PROF2_DECL;
     const bool idrow = !isL && prow >= NS && prow < NS + NU;
@@ -792,8 +810,7 @@ __device__ __forceinline__ void stage_factor(const float* QuuF, const double* Qu
 #pragma unroll
         for (int q4 = 0; q4 < 8; ++q4) {
             const float4 t4 = *reinterpret_cast<const float4*>(src + 4 * q4);
-            vv[2 * q4] = float2v{t4.x, t4.y};
-            if (2 * q4 + 1 < NU / 2) vv[(2 * q4 + 1) % (NU / 2)] = float2v{t4.z, t4.w};
+            acc[q4] = v4f{t4.x, t4.y, t4.z, t4.w};
         }
         if (idrow) {
             const unsigned hot = 1u << (prow - NS);
@@ -811,7 +828,7 @@ __device__ __forceinline__ void stage_factor(const float* QuuF, const double* Qu
     // their own behind the ten blocks (block stride 0)
     float* pubp = pub;
     if (PUB) pubp = (!isL && active) ? pub + prow * 4 : pub + (10 * NPAN + 64 * wv + lane) * 4;
-    const bool bad = chol_solve_fused<ONE, PUB>(vv, dd, lane, fixedmask, pubp, prow, (!isL && active) ? NPAN * 4 : 0, pflag, seq0,
+    const bool bad = chol_solve_fused<ONE, PUB>(acc, dd, lane, fixedmask, pubp, prow, (!isL && active) ? NPAN * 4 : 0, pflag, seq0,
                                                 PUB ? pub + (NS + LATE_M0 + (lane < NLATE ? lane : 0)) * 4 : nullptr);
     PROF2(29);
     if (bad && tid == 0) *flag = 1;
@@ -834,9 +851,9 @@ __device__ __forceinline__ void stage_factor(const float* QuuF, const double* Qu
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             float4 w;
-            w.x = vv[2 * q].x; w.y = vv[2 * q].y;
-            w.z = 2 * q + 1 < NU / 2 ? vv[(2 * q + 1) % (NU / 2)].x : 0.f;
-            w.w = 2 * q + 1 < NU / 2 ? vv[(2 * q + 1) % (NU / 2)].y : 0.f;
+            w.x = acc[q][0]; w.y = acc[q][1];
+            w.z = q < 7 ? acc[q][2] : 0.f;   // (columns 30, 31 are padding: stored as zeros)
+            w.w = q < 7 ? acc[q][3] : 0.f;
             if (!PUB) *reinterpret_cast<float4*>(prow_p + 4 * q) = make_float4(sc * w.x, sc * w.y, sc * w.z, sc * w.w);   // (PUB: nobody reads the panel copy)
             rec.st4(q >= I ? rrow + 4 * (q ^ sw) : trash, w);
         }
