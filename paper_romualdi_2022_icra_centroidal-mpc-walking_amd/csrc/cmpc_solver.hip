@@ -99,7 +99,7 @@ namespace {
 
 #ifdef CMPC_PROFILE
 // diagnostic build only: per-phase shader-clock sums of workgroup 0
-__device__ long long g_prof[64];
+__device__ long long g_prof[128];
 __device__ float g_trace[64 * 8];  // per iteration of workgroup 0: mu, ep, ec, step, ap, ad, sigma, mu_t
 #define PROF_DECL long long pt_ = __builtin_amdgcn_s_memtime()
 #define PROF(slot) do { long long n_ = __builtin_amdgcn_s_memtime(); if (threadIdx.x == 0 && blockIdx.x == 0) g_prof[slot] += n_ - pt_; pt_ = n_; } while (0)
@@ -112,6 +112,8 @@ __device__ float g_trace[64 * 8];  // per iteration of workgroup 0: mu, ep, ec, 
 #define PROF5(slot) do { long long n_ = __builtin_amdgcn_s_memtime(); if (threadIdx.x == (NT >= 512 ? 448 : 216) && blockIdx.x == 0) g_prof[slot] += n_ - pt2_; pt2_ = n_; } while (0)
 // fire-and-forget stamp of the consumer waves (no wait on the atomic): slot 32 + 5 * wave + i
 #define CPROF(i) do { if (ln == 0 && blockIdx.x == 0 && k < N) atomicAdd(reinterpret_cast<unsigned long long*>(&g_prof[32 + 5 * wv + (i)]), (unsigned long long)(__builtin_amdgcn_s_memtime() - pc0_)); } while (0)
+// finer stamps of the consumers (slots 64 + 8 * wave + i)
+#define CPROF2(i) do { if (ln == 0 && blockIdx.x == 0 && k < N) atomicAdd(reinterpret_cast<unsigned long long*>(&g_prof[64 + 8 * wv + (i)]), (unsigned long long)(__builtin_amdgcn_s_memtime() - pc0_)); } while (0)
 // -DCMPC_PROFILE_LIGHT: only the stamps of the driver and the one per backward pass (the stamps inside a stage cost ~10 % of it)
 #ifdef CMPC_PROFILE_LIGHT
 #undef PROF2_DECL
@@ -120,6 +122,8 @@ __device__ float g_trace[64 * 8];  // per iteration of workgroup 0: mu, ep, ec, 
 #undef PROF4
 #undef PROF5
 #undef CPROF
+#undef CPROF2
+#define CPROF2(i)
 #define PROF2_DECL
 #define PROF2(slot)
 #define PROF3(slot)
@@ -136,6 +140,7 @@ __device__ float g_trace[64 * 8];  // per iteration of workgroup 0: mu, ep, ec, 
 #define SQPROF_DECL
 #define SQPROF(slot)
 #define CPROF(i)
+#define CPROF2(i)
 #define PROF_DECL
 #define PROF(slot)
 #define PROF2_DECL
@@ -702,9 +707,51 @@ __device__ __forceinline__ void trail_rank1(v4f (&acc)[8], float av, float bv)
 // PUB (streaming square-root stage): after every pivot block the finished entries x0..x2 of this lane's panel row go to pub[(46 b + prow) * 4 ..]
 // and the wave's progress word *pflag is set to seq0 + b + 1.  LDS operations of one wave execute in issue order: whoever sees the flag sees the data.
 struct CholPub { float* pub; int stride; int* pflag; int seq0; float* publate; };
+// Where a lane's finished row goes: one row per lane, 16-byte stores -- the record row for the sweeps and (HBM-factor variants) the panel row for phase 4.
+// The four columns of chunk Q are final as soon as the pivot block holding the last of them is done, so the stores are issued from inside the block loop and
+// drain under the remaining blocks (round 4: behind the last block they were 1.3 k cycles of the critical wave's stage); chunks 6, 7 follow the loop.
+// Float4s left of an identity row's diagonal block go to row 30 of U, a row whose only readers are lanes that discard what they compute (REC_ZERO is row 31).
+template <bool G, bool PUB>
+struct RowStore {
+    static constexpr bool EARLY = !G;   // (measured at B = 256: 247.2 k solves/s with the early stores, 244.8 k without)
+    const RecRef<G>& rec;
+    float* prow_p;      // panel row (not PUB)
+    float sc;           // its scale: the p rows of the panel are kept pre-multiplied by -D
+    unsigned rrow;
+    int I, sw;
+    bool on;
+    float D0, D1, D2;
+    float* Pan;
+    __device__ __forceinline__ RowStore(const RecRef<G>& r, float* Pan_, float d0, float d1, float d2) : rec(r), prow_p(Pan_), sc(1.f), rrow(0), I(0), sw(0), on(false), D0(d0), D1(d1), D2(d2), Pan(Pan_) {}
+    // this lane stores panel row srow (Qus^T rows 0..14, identity rows NS..NS+29 = columns of L^{-1}, the lq row NPAN-1)
+    __device__ __forceinline__ void set_row(int srow)
+    {
+        const int m = srow - NS;                       // identity rows: column m of L^{-1}
+        const bool isId = srow >= NS && srow < NS + NU;
+        sc = 1.f;
+        if (isId) sc = m < NF ? -((m % 3 == 0) ? D0 : ((m % 3 == 1) ? D1 : D2)) : 0.f;
+        const int jw = srow < NS ? srow : 15;          // Ws column j, or the lq row
+        I = isId ? (m >> 2) : 0;
+        prow_p = Pan + srow * RLD;
+        rrow = isId ? ub_row(m) - 4 * I : REC_WT + 32 * jw;
+        sw = isId ? 0 : (jw & 7);
+        on = true;
+    }
+    template <int Q>
+    __device__ __forceinline__ void chunk(const v4f& a) const
+    {
+        if (!on) return;
+        float4 w;
+        w.x = a[0]; w.y = a[1];
+        w.z = Q < 7 ? a[2] : 0.f;   // (columns 30, 31 are padding: stored as zeros)
+        w.w = Q < 7 ? a[3] : 0.f;
+        if (!PUB) *reinterpret_cast<float4*>(prow_p + 4 * Q) = make_float4(sc * w.x, sc * w.y, sc * w.z, sc * w.w);   // (PUB: nobody reads the panel copy)
+        rec.st4(Q >= I ? rrow + 4 * (Q ^ sw) : ub_row(30), w);
+    }
+};
 // pivot block B (columns 3 B .. 3 B + 2).  Returns true if a pivot was not positive.
-template <int B, bool ONE, bool PUB>
-__device__ __forceinline__ bool chol_block(v4f (&acc)[8], double (&dd)[3], int lane, int fixedmask, CholPub& pb)
+template <int B, bool ONE, bool PUB, typename ST>
+__device__ __forceinline__ bool chol_block(v4f (&acc)[8], double (&dd)[3], int lane, int fixedmask, CholPub& pb, ST& st)
 {
     constexpr int j0 = 3 * B;
     if (ONE && B == LATE_B) {
@@ -713,6 +760,7 @@ __device__ __forceinline__ bool chol_block(v4f (&acc)[8], double (&dd)[3], int l
 #pragma unroll                                              //  compare -> mask hazard slots)
             for (int cc = 0; cc < NU; ++cc) VE(cc) = (float)((hot >> cc) & 1u);
             if (PUB) { pb.pub = pb.publate; pb.stride = NPAN * 4; }   // (the identity row this lane now holds: its entries of the earlier blocks are zeros, kept zero in the buffer)
+            if constexpr (ST::EARLY) st.set_row(NS + LATE_M0 + lane);   // (its chunks 0..3, left of the diagonal block, were never stored: they belong to the discarded row anyway)
         }
     }
     // (opaque copy: the lane predicates are recomputed per block instead of living in hoisted, spilled SGPR pairs)
@@ -753,6 +801,10 @@ __device__ __forceinline__ bool chol_block(v4f (&acc)[8], double (&dd)[3], int l
     if (PUB) {
         // (no lane predicates here: a lane without a panel row writes to a slot of its own behind the blocks, and every lane keeps its own copy of the progress word)
         *reinterpret_cast<float4*>(pb.pub + pb.stride * B) = make_float4(x0, x1, x2, 0.f);
+        // The progress word is a RELAXED store behind a compiler fence, on purpose.  A release store is an s_waitcnt lgkmcnt(0) in front of it -- the critical
+        // wave parked until its own 16-byte write has landed, every pivot block: measured 1.4 % of the headline (236.6 k against 233.4 k solves/s, one gpurun
+        // call).  What makes the relaxed form correct on this hardware: the DS instructions of one wave are executed by the LDS unit in issue order, so the
+        // word cannot become visible before the data written just before it; the readers load it with acquire order (lds_peek).
         asm volatile("" ::: "memory");
         __hip_atomic_store(pb.pflag, pb.seq0 + B + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
@@ -766,25 +818,40 @@ __device__ __forceinline__ bool chol_block(v4f (&acc)[8], double (&dd)[3], int l
         trail_rank1<G0>(acc, a1, x1);
         trail_rank1<G0>(acc, a2, x2);
     }
+    // chunks whose last column this block finished (behind the matrix-pipe instructions: the stores drain while those execute).  LDS records only: a
+    // ds_write takes its data when it issues; with the records in HBM (global_store_dwordx4) the same early stores delivered wrong rows -- the accumulator
+    // registers are renamed by the matrix-pipe instructions right behind the store -- so those variants store after the last block, as before.
+    if constexpr (ST::EARLY) {
+        if constexpr (B == 1) st.template chunk<0>(acc[0]);
+        if constexpr (B == 2) st.template chunk<1>(acc[1]);
+        if constexpr (B == 3) st.template chunk<2>(acc[2]);
+        if constexpr (B == 5) st.template chunk<3>(acc[3]);
+        if constexpr (B == 6) st.template chunk<4>(acc[4]);
+        if constexpr (B == 7) st.template chunk<5>(acc[5]);
+    }
     return bad;
 }
 // ---- fused Cholesky + panel solve, one wave, rows in registers, 3x3 pivot blocks (see the comment block above rcp_d) ----
-template <bool ONE, bool PUB = false>
-__device__ __forceinline__ bool chol_solve_fused(v4f (&acc)[8], double (&dd)[3], int lane, int fixedmask, float* pub = nullptr, int prow = 0,
+template <bool ONE, bool PUB, typename ST>
+__device__ __forceinline__ bool chol_solve_fused(v4f (&acc)[8], double (&dd)[3], int lane, int fixedmask, ST& st, float* pub = nullptr,
                                                  int pubstride = 0, int* pflag = nullptr, int seq0 = 0, float* publate = nullptr)
 {
     CholPub pb{pub, pubstride, pflag, seq0, publate};
     bool bad = false;
-    bad |= chol_block<0, ONE, PUB>(acc, dd, lane, fixedmask, pb);
-    bad |= chol_block<1, ONE, PUB>(acc, dd, lane, fixedmask, pb);
-    bad |= chol_block<2, ONE, PUB>(acc, dd, lane, fixedmask, pb);
-    bad |= chol_block<3, ONE, PUB>(acc, dd, lane, fixedmask, pb);
-    bad |= chol_block<4, ONE, PUB>(acc, dd, lane, fixedmask, pb);
-    bad |= chol_block<5, ONE, PUB>(acc, dd, lane, fixedmask, pb);
-    bad |= chol_block<6, ONE, PUB>(acc, dd, lane, fixedmask, pb);
-    bad |= chol_block<7, ONE, PUB>(acc, dd, lane, fixedmask, pb);
-    bad |= chol_block<8, ONE, PUB>(acc, dd, lane, fixedmask, pb);
-    bad |= chol_block<9, ONE, PUB>(acc, dd, lane, fixedmask, pb);
+    bad |= chol_block<0, ONE, PUB>(acc, dd, lane, fixedmask, pb, st);
+    bad |= chol_block<1, ONE, PUB>(acc, dd, lane, fixedmask, pb, st);
+    bad |= chol_block<2, ONE, PUB>(acc, dd, lane, fixedmask, pb, st);
+    bad |= chol_block<3, ONE, PUB>(acc, dd, lane, fixedmask, pb, st);
+    bad |= chol_block<4, ONE, PUB>(acc, dd, lane, fixedmask, pb, st);
+    bad |= chol_block<5, ONE, PUB>(acc, dd, lane, fixedmask, pb, st);
+    bad |= chol_block<6, ONE, PUB>(acc, dd, lane, fixedmask, pb, st);
+    bad |= chol_block<7, ONE, PUB>(acc, dd, lane, fixedmask, pb, st);
+    bad |= chol_block<8, ONE, PUB>(acc, dd, lane, fixedmask, pb, st);
+    bad |= chol_block<9, ONE, PUB>(acc, dd, lane, fixedmask, pb, st);
+    if constexpr (ST::EARLY) {
+        st.template chunk<6>(acc[6]);
+        st.template chunk<7>(acc[7]);
+    }
     return bad;
 }
 
@@ -828,34 +895,21 @@ __device__ __forceinline__ void stage_factor(const float* QuuF, const double* Qu
     // their own behind the ten blocks (block stride 0)
     float* pubp = pub;
     if (PUB) pubp = (!isL && active) ? pub + prow * 4 : pub + (10 * NPAN + 64 * wv + lane) * 4;
-    const bool bad = chol_solve_fused<ONE, PUB>(acc, dd, lane, fixedmask, pubp, prow, (!isL && active) ? NPAN * 4 : 0, pflag, seq0,
+    RowStore<G, PUB> st(rec, Pan, D0, D1, D2);
+    typedef RowStore<G, PUB> ST;
+    if (ST::EARLY && !isL && active) st.set_row(prow);
+    const bool bad = chol_solve_fused<ONE, PUB>(acc, dd, lane, fixedmask, st, pubp, (!isL && active) ? NPAN * 4 : 0, pflag, seq0,
                                                 PUB ? pub + (NS + LATE_M0 + (lane < NLATE ? lane : 0)) * 4 : nullptr);
     PROF2(29);
     if (bad && tid == 0) *flag = 1;
-    const bool late = ONE && lane < NLATE;             // this lane now holds identity row LATE_M0 + lane
-    const int srow = late ? NS + LATE_M0 + lane : prow;  // the panel row this lane stores
-    if (late || (!isL && active)) {
-        // one row per lane, 16-byte stores: the panel row for phase 4 and the record row for the sweeps
-        const int m = srow - NS;                       // identity rows: column m of L^{-1}
-        const bool isId = srow >= NS && srow < NS + NU;
-        float sc = 1.f;
-        if (isId) sc = m < NF ? -((m % 3 == 0) ? D0 : ((m % 3 == 1) ? D1 : D2)) : 0.f;
-        const int jw = srow < NS ? srow : 15;          // Ws column j, or the lq row
-        const int I = isId ? (m >> 2) : 0;
-        float* prow_p = Pan + srow * RLD;
-        const unsigned rrow = isId ? ub_row(m) - 4 * I : REC_WT + 32 * jw;
-        // one store per float4 for both kinds of row; float4s left of an identity row's diagonal block go to row 30
-        // of U, a row whose only readers are lanes that discard what they compute (REC_ZERO is row 31)
-        const unsigned trash = ub_row(30);
-        const int sw = isId ? 0 : (jw & 7);
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            float4 w;
-            w.x = acc[q][0]; w.y = acc[q][1];
-            w.z = q < 7 ? acc[q][2] : 0.f;   // (columns 30, 31 are padding: stored as zeros)
-            w.w = q < 7 ? acc[q][3] : 0.f;
-            if (!PUB) *reinterpret_cast<float4*>(prow_p + 4 * q) = make_float4(sc * w.x, sc * w.y, sc * w.z, sc * w.w);   // (PUB: nobody reads the panel copy)
-            rec.st4(q >= I ? rrow + 4 * (q ^ sw) : trash, w);
+    if constexpr (!ST::EARLY) {
+        // (records in HBM: every chunk after the last block, and nothing of the store's addressing alive across the block loop -- the 168-register
+        //  variants have no room for it: held there it pushed stage_mid into the callee-saved registers and their scratch saves)
+        const bool late = ONE && lane < NLATE;             // this lane now holds identity row LATE_M0 + lane
+        if (late || (!isL && active)) {
+            st.set_row(late ? NS + LATE_M0 + lane : prow);
+            st.template chunk<0>(acc[0]); st.template chunk<1>(acc[1]); st.template chunk<2>(acc[2]); st.template chunk<3>(acc[3]);
+            st.template chunk<4>(acc[4]); st.template chunk<5>(acc[5]); st.template chunk<6>(acc[6]); st.template chunk<7>(acc[7]);
         }
     }
     PROF2(30);
@@ -1473,315 +1527,239 @@ __device__ inline void sq_y_body(const Ctx& c, int t, const float* Qc, float* YT
                                                                      d.w0 * x0.z + d.w1 * x1.z + d.w2 * x2.z, d.w0 * x0.w + d.w1 * x1.w + d.w2 * x2.w);
 }
 __device__ inline float sandwich_y(const float* YT, const Desc3& a, int col) { const float* y = YT + 16 * col; return a.w0 * y[a.r0] + a.w1 * y[a.r1] + a.w2 * y[a.r2]; }
-template <int NTB = 256, bool USEY = false>
-__device__ inline void sq_base_body(const Ctx& c, const CmpcConsts& prm, int t, int k, bool havep, float reg, float* QuuFn, double* QuuDn, float* Pann,
-                                    float* Qbn, double* qsn, const float* Qc, const double* qsc, const float* YT = nullptr)
+// ---- the assembly roles of the consumer waves.  c: descriptor set of stage k selected; Qc, qsc: Qss and qs of stage k+1; havep: stage k+1 has a
+// previous-force block (it is not the terminal stage). ----
+// The ten 3x3 diagonal blocks of Quu in float64 (60 lower entries, lane l), branch-free on clamped indices.
+__device__ inline void sq_diag_body(const Ctx& c, const CmpcConsts& prm, int l, int k, bool havep, float reg, float* QuuFn, double* QuuDn, const float* YT)
+{
+    const bool pk = k > 0;
+    const int tc = l < 60 ? l : 59;
+    const int b = tc / 6, w = tc - 6 * b;
+    const int rr = w >= 3 ? 2 : (w >= 1 ? 1 : 0), cc = w - rr * (rr + 1) / 2;
+    const int i = 3 * b + rr, j = 3 * b + cc;
+    const bool isF = i < NF, dg = i == j;
+    const Desc3 di = desc_of(c.Brow, c.Bval, i);
+    const int r0 = isF ? 4 * b : 0;             // friction rows of the corner
+    const int iq = isF ? 0 : i - 24;            // landing-offset component
+    double sg[4], ar[4], ac[4];
+#pragma unroll
+    for (int f = 0; f < 4; ++f) { sg[f] = c.sig[r0 + f]; ar[f] = (double)c.arow[3 * (r0 + f) + rr]; ac[f] = (double)c.arow[3 * (r0 + f) + cc]; }
+    const double slo = c.sig[32 + iq], shi = c.sig[38 + iq];
+    const bool fr = qfree(c, k, iq);
+    const double gam = gam_of(c, isF ? i / 12 : 0, k);
+    const double v = (double)sandwich_y(YT, di, j);
+    double vF = v;
+    if (dg) {
+        vF += 2.0 * prm.w_sym * (1.0 - 0.25 * gam * (2.0 - gam));
+        if (pk) vF += (double)prm.D[i % 3];       // own force-rate cost
+        if (havep) vF += (double)prm.D[i % 3];    // E^T D E: the next stage's force-rate cost
+        vF += (double)reg;
+    }
+#pragma unroll
+    for (int f = 0; f < 4; ++f) vF += sg[f] * ar[f] * ac[f];
+    const double vQ = dg ? (fr ? v + slo + shi + (double)reg : 1.0) : v;   // fixed q: exact identity row
+    if (l < 60) {
+        QuuDn[9 * b + 3 * rr + cc] = isF ? vF : vQ;
+        QuuFn[i * RLD + j] = 0.f;   // the float copy of a diagonal block collects -Z^T Z and the updates by earlier blocks
+    }
+}
+// hb = [Qss d + qs; -D (u_k+1 - u_k)] (float64), rows 0 .. nrow-1, into hb[] (lane l <-> row l); needs nothing but Qss, qs of stage k+1
+__device__ inline void sq_hb_rows(const Ctx& c, const CmpcConsts& prm, int l, int k, bool havep, int nrow, const float* Qc, const double* qsc, double* hb)
+{
+    const int r = l < nrow ? l : nrow - 1;
+    double hv;
+    if (r < NS) {
+        double acc = 0.0;
+#pragma unroll
+        for (int a = 0; a < NS; ++a) acc += (double)Qc[16 * a + r] * (double)c.d[NS * k + a];
+        hv = qsc[r] + acc;
+    } else {
+        const int m = r - NS;
+        hv = havep ? -(double)prm.D[m % 3] * ((double)c.U[NU * (k + 1) + m] - (double)c.U[NU * k + m]) : 0.0;
+    }
+    if (l < nrow) hb[r] = hv;
+    wave_lds_sync();
+}
+// qu (float64, one wave): gradient of the symmetry cost, barrier terms, force-rate term, B~^T hb.  Left in c.pv (float64) until -Z^T z_g has been
+// subtracted (the gradient role); the terminal stage has no Z and writes the panel row itself.
+__device__ inline void sq_rhs_qu_body(const Ctx& c, const CmpcConsts& prm, int l, int k, bool havep, float* Pann, const float* Qc, const double* qsc)
 {
     const bool pk = k > 0;
     const float* u = c.U + NU * k;
-    const int* Brow = c.Brow;
-    const float* Bval = c.Bval;
-    if (t < 64) {
-        // the ten 3x3 diagonal blocks of Quu in float64 (60 lower entries), branch-free on clamped indices
-        const int tc = t < 60 ? t : 59;
-        const int b = tc / 6, w = tc - 6 * b;
-        const int rr = w >= 3 ? 2 : (w >= 1 ? 1 : 0), cc = w - rr * (rr + 1) / 2;
-        const int i = 3 * b + rr, j = 3 * b + cc;
-        const bool isF = i < NF, dg = i == j;
-        const Desc3 di = desc_of(Brow, Bval, i), dj = desc_of(Brow, Bval, j);
-        const int r0 = isF ? 4 * b : 0;             // friction rows of the corner
-        const int iq = isF ? 0 : i - 24;            // landing-offset component
-        double sg[4], ar[4], ac[4];
+    double* hb = c.Pd;
+    sq_hb_rows(c, prm, l, k, havep, NXA, Qc, qsc, hb);
+    const int iq = l < NU ? l : NU - 1;
+    const bool isF = iq < NF;
+    const int m = isF ? iq : 0, ct = m / 12, ax = m % 3;
+    const int q = isF ? 0 : iq - 24;
+    const float* uf = u + 12 * ct + ax;
+    const float u0 = uf[0], u1 = uf[3], u2 = uf[6], u3 = uf[9], um = u[m];
+    const float up = c.U[NU * (pk ? k - 1 : 0) + m];
+    const double gam = gam_of(c, ct, k);
+    const int r0 = 4 * (m / 3);
+    double gc[4], ar[4];
 #pragma unroll
-        for (int f = 0; f < 4; ++f) { sg[f] = c.sig[r0 + f]; ar[f] = (double)c.arow[3 * (r0 + f) + rr]; ac[f] = (double)c.arow[3 * (r0 + f) + cc]; }
-        const double slo = c.sig[32 + iq], shi = c.sig[38 + iq];
-        const bool fr = qfree(c, k, iq);
-        const double gam = gam_of(c, isF ? i / 12 : 0, k);
-        const double v = (double)(USEY ? sandwich_y(YT, di, j) : sandwich(Qc, di, dj));
-        double vF = v;
-        if (dg) {
-            vF += 2.0 * prm.w_sym * (1.0 - 0.25 * gam * (2.0 - gam));
-            if (pk) vF += (double)prm.D[i % 3];       // own force-rate cost
-            if (havep) vF += (double)prm.D[i % 3];    // E^T D E: the next stage's force-rate cost
-            vF += (double)reg;
-        }
+    for (int f = 0; f < 4; ++f) { gc[f] = c.gco[r0 + f]; ar[f] = (double)c.arow[3 * (r0 + f) + ax]; }
+    const double glo = c.gco[32 + q], ghi = c.gco[38 + q];
+    const bool fr = qfree(c, k, q);
+    const Desc3 dq = desc_of(c.Brow, c.Bval, iq);
+    const double mean = 0.25 * ((double)u0 + (double)u1 + (double)u2 + (double)u3);
+    const double esum = 4.0 * mean * (1.0 - gam);
+    double gF = 2.0 * prm.w_sym * (((double)um - gam * mean) - 0.25 * gam * esum);
 #pragma unroll
-        for (int f = 0; f < 4; ++f) vF += sg[f] * ar[f] * ac[f];
-        const double vQ = dg ? (fr ? v + slo + shi + (double)reg : 1.0) : v;   // fixed q: exact identity row
-        if (t < 60) {
-            QuuDn[9 * b + 3 * rr + cc] = isF ? vF : vQ;
-            QuuFn[i * RLD + j] = 0.f;   // the float copy of a diagonal block collects -Z^T Z and the updates by earlier blocks
-        }
-    } else if (t < 128) {
-        const int l = t - 64;
-        double* hb = c.Pd;
-        {
-            const int r = l < NXA ? l : NXA - 1;
-            double hv;
-            if (r < NS) {
-                double acc = 0.0;
-#pragma unroll
-                for (int a = 0; a < NS; ++a) acc += (double)Qc[16 * a + r] * (double)c.d[NS * k + a];
-                hv = qsc[r] + acc;
-            } else {
-                const int m = r - NS;
-                hv = havep ? -(double)prm.D[m % 3] * ((double)c.U[NU * (k + 1) + m] - (double)u[m]) : 0.0;
-            }
-            if (l < NXA) hb[r] = hv;
-        }
-        wave_lds_sync();
-        if (l < 32) {
-            // qu: gradient of the symmetry cost, barrier terms, force-rate term, B~^T hb
-            const int iq = l < NU ? l : NU - 1;
-            const bool isF = iq < NF;
-            const int m = isF ? iq : 0, ct = m / 12, ax = m % 3;
-            const int q = isF ? 0 : iq - 24;
-            const float* uf = u + 12 * ct + ax;
-            const float u0 = uf[0], u1 = uf[3], u2 = uf[6], u3 = uf[9], um = u[m];
-            const float up = c.U[NU * (pk ? k - 1 : 0) + m];
-            const double gam = gam_of(c, ct, k);
-            const int r0 = 4 * (m / 3);
-            double gc[4], ar[4];
-#pragma unroll
-            for (int f = 0; f < 4; ++f) { gc[f] = c.gco[r0 + f]; ar[f] = (double)c.arow[3 * (r0 + f) + ax]; }
-            const double glo = c.gco[32 + q], ghi = c.gco[38 + q];
-            const bool fr = qfree(c, k, q);
-            const Desc3 dq = desc_of(Brow, Bval, iq);
-            const double mean = 0.25 * ((double)u0 + (double)u1 + (double)u2 + (double)u3);
-            const double esum = 4.0 * mean * (1.0 - gam);
-            double gF = 2.0 * prm.w_sym * (((double)um - gam * mean) - 0.25 * gam * esum);
-#pragma unroll
-            for (int f = 0; f < 4; ++f) gF += gc[f] * ar[f];
-            if (pk) gF += (double)prm.D[ax] * ((double)um - (double)up);
-            const double gQ = fr ? glo - ghi : 0.0;
-            double g = isF ? (havep ? gF + hb[NS + m] : gF) : gQ;
-            g += (double)dq.w0 * hb[dq.r0] + (double)dq.w1 * hb[dq.r1] + (double)dq.w2 * hb[dq.r2];
-            if (l < NU) {
-                c.pv[iq] = g;                                         // float64 until -Z^T z_g has been subtracted (sq_mm_body)
-                if (!havep) Pann[(NPAN - 1) * RLD + iq] = (float)g;   // (the terminal stage has no Z)
-            }
-        } else if (l < 32 + NS) {
-            const int sidx = l - 32;
-            qsn[sidx] = grad_track(c, prm, k, sidx) + At_vec<double>(c, prm, k, sidx, hb);
-        }
+    for (int f = 0; f < 4; ++f) gF += gc[f] * ar[f];
+    if (pk) gF += (double)prm.D[ax] * ((double)um - (double)up);
+    const double gQ = fr ? glo - ghi : 0.0;
+    double g = isF ? (havep ? gF + hb[NS + m] : gF) : gQ;
+    g += (double)dq.w0 * hb[dq.r0] + (double)dq.w1 * hb[dq.r1] + (double)dq.w2 * hb[dq.r2];
+    if (l < NU) {
+        c.pv[iq] = g;
+        if (!havep) Pann[(NPAN - 1) * RLD + iq] = (float)g;
     }
-    // float32 entries: 360 triples of consecutive entries -- 135 of Quu (row i, block column bj < bi), 150 of Qus^T (row jr, the xyz of one corner / one foot's
-    // offset), 75 of Qss (row i, columns 3 jb .. 3 jb + 2: both triangles) -- by one branch-free formula on the descriptor table [B columns | A columns]:
-    //   out_c = row^T Qc col_c + ew E[3 c] - [c == symc] symw + [c == qc] qd
-    for (int id = t; id < 360; id += NTB) {
-        const bool isuu = id < 135, isss = id >= 285;
-        // (block row, block column) of the p-th strictly-lower block pair, p = 0..44, in closed form
-        const int p = isuu ? id / 3 : 0;
-        const int bi = 1 + (p >= 1) + (p >= 3) + (p >= 6) + (p >= 10) + (p >= 15) + (p >= 21) + (p >= 28) + (p >= 36);
-        const int bj = p - bi * (bi - 1) / 2;
-        const int idp = isuu ? 0 : (isss ? id - 285 : id - 135);
-        const int pr = isss ? idp / 5 : idp / 10, pc = isss ? idp % 5 : idp % 10;      // Qus^T: row jr = pr, triple pc; Qss: row pr, triple pc
-        const int i = isuu ? 3 * bi + id % 3 : pr;
-        const int col0 = isuu ? 3 * bj : 3 * pc;
-        const int drow = isuu ? i : NU + pr;                    // descriptor of the row: column i of B, or column pr of A
-        const int dcol = isss ? NU + col0 : col0;               // descriptors of the three columns
-        float* dst = isuu ? QuuFn + i * RLD + col0 : (isss ? Qbn + 16 * pr + col0 : Pann + pr * RLD + col0);
-        // Quu: another corner of the same foot, same axis: symmetry-cost coupling
-        const bool sy = isuu && i < NF && (i / 12) == (col0 / 12);
-        const float gq = gam_of(c, (isuu && i >= 12) ? 1 : 0, k);
-        const int symc = isuu ? i % 3 : -1;
-        const float symw = sy ? 2.f * prm.w_sym * 0.25f * gq * (2.f - gq) : 0.f;
-        // Qus^T: exact-Hessian cross term -/+ gam Sx between a force and com / its foot's position
-        const int ct = col0 / 12;
-        const int bb = pr < 3 ? pr : pr - 9 - 3 * ct;
-        const bool bin = bb >= 0 && bb < 3;
-        const float sgn = pr < 3 ? -1.f : (bin ? 1.f : 0.f);
-        const float ew = (!isuu && !isss && col0 < NF) ? sgn * gam_of(c, ct < 2 ? ct : 0, k) : 0.f;
-        const float* E = c.arow + 96 + (bin ? bb : 0);
-        // Qss: the stage cost on the diagonal
-        const int qc = isss ? pr - col0 : -1;
-        const float qd = isss ? qdiag(prm, k, pr) : 0.f;
-        const Desc3 dr = desc_of(Brow, Bval, drow);
-        const float e0 = E[0], e1 = E[3], e2 = E[6];
-        float o0, o1, o2;
-        if (USEY) {
-            o0 = sandwich_y(YT, dr, dcol) + ew * e0; o1 = sandwich_y(YT, dr, dcol + 1) + ew * e1; o2 = sandwich_y(YT, dr, dcol + 2) + ew * e2;
-        } else {
-            const Desc3 d0 = desc_of(Brow, Bval, dcol), d1 = desc_of(Brow, Bval, dcol + 1), d2 = desc_of(Brow, Bval, dcol + 2);
-            o0 = sandwich(Qc, dr, d0) + ew * e0; o1 = sandwich(Qc, dr, d1) + ew * e1; o2 = sandwich(Qc, dr, d2) + ew * e2;
-        }
-        o0 += (qc == 0 ? qd : 0.f) - (symc == 0 ? symw : 0.f);
-        o1 += (qc == 1 ? qd : 0.f) - (symc == 1 ? symw : 0.f);
-        o2 += (qc == 2 ? qd : 0.f) - (symc == 2 ? symw : 0.f);
-        dst[0] = o0; dst[1] = o1; dst[2] = o2;
-    }
+}
+// qs = gradient of the tracking cost + A^T hb[0..14] (float64, another wave than qu: its own copy of the 15 rows of hb it needs, in c.pn), one formula
+// with per-lane coefficients:  qs_j = w_j (s_j - ref_j) + sj v_j + ce v_je + cg (v_{6+a1} F_a2 - v_{6+a2} F_a1)
+__device__ inline void sq_rhs_qs_body(const Ctx& c, const CmpcConsts& prm, int l, int k, bool havep, double* qsn, const float* Qc, const double* qsc)
+{
+    double* hs = c.pn;
+    sq_hb_rows(c, prm, l, k, havep, NS, Qc, qsc, hs);
+    const int j = l < NS ? l : NS - 1;
+    const int ja = j < 3 ? j : (j >= 9 ? (j - 9) % 3 : 0), ja1 = (ja + 1) % 3, ja2 = (ja + 2) % 3;
+    const int jct = j >= 12 ? 1 : 0;
+    const int roff = j < 3 ? c.L.pComref() + j : (j < 6 ? c.L.pComref() : (j < 9 ? c.L.pHref() + j - 6 : c.L.pNom(jct) + ja));
+    const double wj = (double)qdiag(prm, k, j);
+    const float* geo = c.geoA + GEO * k;
+    const float* F = geo + (j < 3 ? 30 : 24 + 3 * jct);    // Fsum or Fc of the foot
+    const int je = (j >= 3 && j < 6) ? j - 3 : 0;
+    const double gam = gam_of(c, jct, k);
+    const double dt = prm.dt;
+    const double sj = j >= 9 ? gam : 1.0;
+    const double ce = (j >= 3 && j < 6) ? dt : 0.0;
+    const double cg = j < 3 ? dt : (j >= 9 ? -dt * gam : 0.0);
+    const double sv = (double)c.S[NS * k + j], rv = (double)c.sp[roff + 3 * k];
+    const double F1 = (double)F[ja1], F2 = (double)F[ja2];
+    const double vj = hs[j], ve = hs[je], v1 = hs[6 + ja1], v2 = hs[6 + ja2];
+    const double out = wj * (sv - rv) + sj * vj + ce * ve + cg * (v1 * F2 - v2 * F1);
+    if (l < NS) qsn[j] = out;
+}
+// The float32 entries: 360 triples of consecutive entries -- 135 of Quu (row i, block column bj < bi), 150 of Qus^T (row jr, the xyz of one corner / one foot's
+// offset), 75 of Qss (row i, columns 3 jb .. 3 jb + 2: both triangles) -- by one branch-free formula on the descriptor table [B columns | A columns]:
+//   out_c = row^T Qc col_c + ew E[3 c] - [c == symc] symw + [c == qc] qd
+// Which entries a thread owns, where they go and which of the extra terms they carry does not depend on the stage: decoded once per backward pass
+// (triple_decode, two packed words held across the stage loop) -- the decode was 60 of the ~110 instructions of a triple, every stage.
+struct Triple { unsigned w0, w1; };
+//   w0: destination offset [0:11] | kind [12:13] (0 Quu, 1 Qus^T, 2 Qss, 3 none) | descriptor of the row [14:19] | of the first column [20:25]
+//   w1: symc [0:1] (3 none) | sy [2] | foot of the row [3] | sign of the exact-Hessian term [4:5] (0 none, 1 +, 2 -) | its foot [6] | its E column [7:8] | qc [9:10] (3 none) | row of Qss [11:14]
+__device__ inline Triple triple_decode(int id)
+{
+    Triple tr;
+    if (id >= 360) { tr.w0 = 3u << 12; tr.w1 = 3u | (3u << 9); return tr; }
+    const bool isuu = id < 135, isss = id >= 285;
+    // (block row, block column) of the p-th strictly-lower block pair, p = 0..44, in closed form
+    const int p = isuu ? id / 3 : 0;
+    const int bi = 1 + (p >= 1) + (p >= 3) + (p >= 6) + (p >= 10) + (p >= 15) + (p >= 21) + (p >= 28) + (p >= 36);
+    const int bj = p - bi * (bi - 1) / 2;
+    const int idp = isuu ? 0 : (isss ? id - 285 : id - 135);
+    const int pr = isss ? idp / 5 : idp / 10, pc = isss ? idp % 5 : idp % 10;      // Qus^T: row jr = pr, triple pc; Qss: row pr, triple pc
+    const int i = isuu ? 3 * bi + id % 3 : pr;
+    const int col0 = isuu ? 3 * bj : 3 * pc;
+    const int drow = isuu ? i : NU + pr;                    // descriptor of the row: column i of B, or column pr of A
+    const int dcol = isss ? NU + col0 : col0;               // descriptors of the three columns
+    const int doff = isuu ? i * RLD + col0 : (isss ? 16 * pr + col0 : pr * RLD + col0);
+    // Quu: another corner of the same foot, same axis: symmetry-cost coupling
+    const bool sy = isuu && i < NF && (i / 12) == (col0 / 12);
+    const int symc = isuu ? i % 3 : 3;
+    // Qus^T: exact-Hessian cross term -/+ gam Sx between a force and com / its foot's position
+    const int ct = col0 / 12;
+    const int bb = pr < 3 ? pr : pr - 9 - 3 * ct;
+    const bool bin = bb >= 0 && bb < 3;
+    const int sgn = (!isuu && !isss && col0 < NF) ? (pr < 3 ? 2 : (bin ? 1 : 0)) : 0;
+    // Qss: the stage cost on the diagonal
+    const int qc = (isss && pr >= col0 && pr < col0 + 3) ? pr - col0 : 3;
+    tr.w0 = (unsigned)doff | ((isuu ? 0u : (isss ? 2u : 1u)) << 12) | ((unsigned)drow << 14) | ((unsigned)dcol << 20);
+    tr.w1 = (unsigned)symc | ((sy ? 1u : 0u) << 2) | (((isuu && i >= 12) ? 1u : 0u) << 3) | ((unsigned)sgn << 4) | (((ct < 2 ? ct : 0) & 1u) << 6)
+            | ((unsigned)(bin ? bb : 0) << 7) | ((unsigned)qc << 9) | ((unsigned)(isss ? pr : 0) << 11);
+    return tr;
+}
+__device__ inline void sq_triple_body(const Ctx& c, const CmpcConsts& prm, const Triple& tr, int k, float* QuuFn, float* Pann, float* Qbn, const float* YT)
+{
+    const unsigned kind = (tr.w0 >> 12) & 3u;
+    if (kind == 3u) return;
+    const int doff = tr.w0 & 0xfff, drow = (tr.w0 >> 14) & 63, dcol = (tr.w0 >> 20) & 63;
+    float* dst = (kind == 0u ? QuuFn : (kind == 2u ? Qbn : Pann)) + doff;
+    const int symc = tr.w1 & 3u, qc = (tr.w1 >> 9) & 3u, sgn = (tr.w1 >> 4) & 3u, pr = (tr.w1 >> 11) & 15u;
+    const float gam0 = gam_of(c, 0, k), gam1 = gam_of(c, 1, k);
+    const float gq = ((tr.w1 >> 3) & 1u) ? gam1 : gam0;
+    const float symw = ((tr.w1 >> 2) & 1u) ? 2.f * prm.w_sym * 0.25f * gq * (2.f - gq) : 0.f;
+    const float ge = ((tr.w1 >> 6) & 1u) ? gam1 : gam0;
+    const float ew = sgn == 0 ? 0.f : (sgn == 1 ? ge : -ge);
+    const float* E = c.arow + 96 + ((tr.w1 >> 7) & 3u);
+    const float qd = kind == 2u ? qdiag(prm, k, pr) : 0.f;
+    const Desc3 dr = desc_of(c.Brow, c.Bval, drow);
+    const float e0 = E[0], e1 = E[3], e2 = E[6];
+    float o0 = sandwich_y(YT, dr, dcol) + ew * e0, o1 = sandwich_y(YT, dr, dcol + 1) + ew * e1, o2 = sandwich_y(YT, dr, dcol + 2) + ew * e2;
+    o0 += (qc == 0 ? qd : 0.f) - (symc == 0 ? symw : 0.f);
+    o1 += (qc == 1 ? qd : 0.f) - (symc == 1 ? symw : 0.f);
+    o2 += (qc == 2 ? qd : 0.f) - (symc == 2 ? symw : 0.f);
+    dst[0] = o0; dst[1] = o1; dst[2] = o2;
 }
 
-// ---- Z^T = T^T W^T: row i < 30 = sum_a Bval[i][a] W^T[Brow[i][a]] (+ W^T[NS + i], the previous-force column, for a force), row 30 + s likewise
-// through column s of A, row 45 = lq + sum_a d_a W^T[a]; rows of 32 floats (columns 30, 31 are zeros in W^T).  One float4 per thread.
-// c: descriptor set and defects of the stage being ASSEMBLED (k - 1); WT: Pan of the stage just factorised. ----
-__device__ inline void sq_z_body(const Ctx& c, int tid, int kasm, const float* WT)
-{
-    const int row = tid >> 3, q4 = tid & 7;
-    if (row >= 48) return;
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    auto fma4 = [&](float w, int r) {
-        const float4 x = *reinterpret_cast<const float4*>(WT + r * RLD + 4 * q4);
-        acc.x += w * x.x; acc.y += w * x.y; acc.z += w * x.z; acc.w += w * x.w;
-    };
-    if (row < NU + NS) {
-        const Desc3 d = row < NU ? desc_of(c.Brow, c.Bval, row) : desc_of(c.Arow, c.Aval, row - NU);
-        const bool pf = row < NF;
-        const float4 e = *reinterpret_cast<const float4*>(WT + (NS + (pf ? row : 0)) * RLD + 4 * q4);
-        fma4(d.w0, d.r0); fma4(d.w1, d.r1); fma4(d.w2, d.r2);
-        if (pf) { acc.x += e.x; acc.y += e.y; acc.z += e.z; acc.w += e.w; }
-    } else if (row == NU + NS) {
-        acc = *reinterpret_cast<const float4*>(WT + (NPAN - 1) * RLD + 4 * q4);
-#pragma unroll
-        for (int a = 0; a < NS; ++a) fma4(c.d[NS * kasm + a], a);
-    }
-    *reinterpret_cast<float4*>(c.ZT + row * ZLD + 4 * q4) = acc;
-}
-
-// ---- M -= Z^T Z on the matrix cores: the six lower 16 x 16 tiles of the 48 x 48 cover, one per wave (v_mfma_f32_16x16x4_f32: lane (m, kq) feeds
-// component t of TWO float4 of a Z^T row to MFMA t, so the K index it supplies is 4 kq + t (+ 16), the same map for both operands; result register i of
-// lane (m, kq) is entry (16 I + 4 kq + i, 16 J + m)).  Every value the products are subtracted from is fetched before the first MFMA. ----
-__device__ inline void sq_mm_body(const Ctx& c, int tid, float* QuuFn, float* Pann, float* Qbn, double* qsn)
-{
-    typedef float v4f __attribute__((ext_vector_type(4)));
-    const int t = tid >> 6, ln = tid & 63, m4 = ln & 15, kq = ln >> 4;
-    if (t >= 6) return;
-    const int I = t >= 3 ? 2 : (t >= 1 ? 1 : 0), J = t - I * (I + 1) / 2;
-    const float* ra = c.ZT + (16 * I + m4) * ZLD + 4 * kq;
-    const float* rb = c.ZT + (16 * J + m4) * ZLD + 4 * kq;
-    const float4 a0 = *reinterpret_cast<const float4*>(ra), a1 = *reinterpret_cast<const float4*>(ra + 16);
-    const float4 b0 = *reinterpret_cast<const float4*>(rb), b1 = *reinterpret_cast<const float4*>(rb + 16);
-    const int jj = 16 * J + m4;
-    float* dst[4];
-    float* dst2[4];
-    float bs[4];
-    bool ok[4];
-    double gb = 0.0;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int ii = 16 * I + 4 * kq + i;
-        ok[i] = jj <= ii && ii < NU + NS;
-        float* p = QuuFn + ii * RLD + jj;                                   // uu
-        float* p2 = p;
-        if (ii >= NU) {
-            if (jj < NU) { p = Pann + (ii - NU) * RLD + jj; p2 = p; }       // su
-            else { p = Qbn + 16 * (ii - NU) + (jj - NU); p2 = Qbn + 16 * (jj - NU) + (ii - NU); }   // ss, both triangles
-        }
-        if (!ok[i]) { p = QuuFn; p2 = QuuFn; }
-        dst[i] = p; dst2[i] = p2;
-        bs[i] = *p;
-        if (ii == NU + NS && jj < NU + NS) gb = jj < NU ? c.pv[jj] : qsn[jj - NU];   // gradient row: float64
-    }
-    v4f c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
-    c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, b0.x, c0, 0, 0, 0);
-    c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, b1.x, c1, 0, 0, 0);
-    c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, b0.y, c0, 0, 0, 0);
-    c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, b1.y, c1, 0, 0, 0);
-    c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, b0.z, c0, 0, 0, 0);
-    c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, b1.z, c1, 0, 0, 0);
-    c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, b0.w, c0, 0, 0, 0);
-    c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, b1.w, c1, 0, 0, 0);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int ii = 16 * I + 4 * kq + i;
-        const float v = c0[i] + c1[i];
-        if (ok[i]) {
-            const float r = bs[i] - v;
-            *dst[i] = r;
-            *dst2[i] = r;
-        } else if (ii == NU + NS && jj < NU + NS) {
-            const double r = gb - (double)v;
-            if (jj < NU) Pann[(NPAN - 1) * RLD + jj] = (float)r;
-            else qsn[jj - NU] = r;
-        }
-    }
-}
-
-// A square-root backward stage is two calls.  sq_mid: the factorisation of stage k on waves 0-1, meanwhile the Z-independent part of stage k-1 on
-// waves 2, 3, 6, 7 (waves 4, 5 share their SIMDs with the factorising waves and stay idle), and the barrier behind them.  sq_post: Z, barrier, -Z^T Z
-// into stage k-1 on waves 0-5 and the descriptors of stage k-2 on waves 6-7, barrier.
-template <int NT, int NC, bool FG>
-__device__ __attribute__((noinline)) void sq_mid(lds_t lds, int Nrt, float* fg_base, int k_in, int kbase_in, bool havep_in, float reg)
-{
-    CMPC_PHASE_PROLOGUE;
-    const int k = __builtin_amdgcn_readfirstlane(k_in);           // stage to factorise (N: none, only the terminal stage's successor is assembled)
-    const int kb = __builtin_amdgcn_readfirstlane(kbase_in);      // stage to assemble (-1: none)
-    const bool havep = __builtin_amdgcn_readfirstlane((int)havep_in) != 0;
-    PROF_DECL;
-    if (tid < 128) {
-        if (k < N) {
-            const int s = k & 1;
-            const int fixedmask = (~c.qmask[k]) & 63;
-            stage_factor<false, FG>(c.QuuF + s * MSET, s ? c.QuuD1 : c.QuuD, c.Pan + s * MSET, RecRef<FG>(c.Lf, N, k), prm.D[0], prm.D[1], prm.D[2], c.flag, tid, fixedmask);
-        }
-    } else if (kb >= 0 && (tid < 256 || tid >= 384)) {
-        const int t = tid < 256 ? tid - 128 : tid - 256;   // waves 2, 3 -> 0..127, waves 6, 7 -> 128..255
-        const int s = kb & 1, sc = s ^ 1;
-        use_desc_set(c, s);
-        sq_base_body(c, prm, t, kb, havep, reg, c.QuuF + s * MSET, s ? c.QuuD1 : c.QuuD, c.Pan + s * MSET, c.Qb + s * NS * 16, s ? c.qs1 : c.qs,
-                     c.Qb + sc * NS * 16, sc ? c.qs1 : c.qs);
-#ifdef CMPC_PROFILE
-        if (tid == 128 && blockIdx.x == 0) g_prof[5] += __builtin_amdgcn_s_memtime() - pt_;   // the assembly on its waves
-#endif
-    }
-    PROF(9);           // (wave 0: the factorisation alone)
-    __syncthreads();
-    PROF(3);
-}
-template <int NT, int NC, bool FG>
-__device__ __attribute__((noinline)) void sq_post(lds_t lds, int Nrt, float* fg_base, int k_in, int kdesc_in, bool exact_in, float cmu)
-{
-    CMPC_PHASE_PROLOGUE;
-    const int k = __builtin_amdgcn_readfirstlane(k_in);           // stage just factorised; stage k-1 is completed
-    const int kd = __builtin_amdgcn_readfirstlane(kdesc_in);      // stage whose descriptors are built meanwhile (-1: none)
-    const bool use_exact = __builtin_amdgcn_readfirstlane((int)exact_in) != 0;
-    PROF_DECL;
-    {
-        Ctx ca = c;
-        use_desc_set(ca, (k - 1) & 1);
-        sq_z_body(ca, tid, k - 1, c.Pan + (k & 1) * MSET);
-    }
-    __syncthreads();
-    PROF(1);
-    if (tid < 384) {
-        const int s = (k - 1) & 1;
-        sq_mm_body(c, tid, c.QuuF + s * MSET, c.Pan + s * MSET, c.Qb + s * NS * 16, s ? c.qs1 : c.qs);
-    } else if (kd >= 0) {
-        Ctx cd = c;
-        use_desc_set(cd, kd & 1);
-        stage_desc_body(cd, prm, tid - 384, kd, use_exact, cmu);
-    }
-    PROF(2);           // (wave 0: its tile alone)
-    __syncthreads();
-    PROF(4);
-}
-// ---- The streaming form of the square-root stage (CMPC_SQ_STREAM): ONE barrier per stage, one call per backward pass and role.  The factorisation runs on wave 0
-// (the one-wave scheme: 76 rows in 64 lanes) and publishes the three finished columns of W^T after every pivot block (chol_solve_fused<.., PUB>).  Waves 1, 2, 3, 5, 6, 7
-// first assemble the Z-independent part of the next stage (Y = Qss [B A], then 360 float32 triples, the float64 diagonal blocks, q_u and q_s), then follow the
-// factorisation two blocks at a time: each owns one 16 x 16 tile of Z^T Z and, per block, forms the two operand entries its lanes feed to the matrix core -- sparse
-// combinations of the published rows -- and issues one v_mfma_f32_16x16x4_f32 (K = the block's three columns and a zero); the wave of tile (2, 2) also carries the
-// gradient column.  When the last block is out, what remains is one tile update and the read-modify-write of the tile's entries.  Wave 4 shares its SIMD with the
-// factorising wave and only builds the descriptors of the stage after next.
+// ---- The streaming square-root stage: ONE barrier per stage, one call per backward pass and role.  The factorisation runs on wave 0 (the one-wave scheme: 76 rows
+// in 64 lanes, trailing updates on the matrix pipe) and publishes the three finished columns of W^T after every pivot block (chol_block<.., PUB>).  Waves 1, 2, 3, 5, 6, 7
+// first assemble the Z-independent part of the next stage -- Y = Qss [B A] on waves 5-7; the float64 right-hand sides q_u (wave 2) and q_s (wave 3), which need no Y
+// and start at once; the float64 diagonal blocks (wave 1) and 360 float32 triples (all six) behind Y -- then follow the factorisation two blocks at a time: each owns
+// one 16 x 16 tile of Z^T Z and, per block, forms the two operand entries its lanes feed to the matrix core -- sparse combinations of the published rows -- and issues
+// one v_mfma_f32_16x16x4_f32 (K = the block's three columns and a zero).  When the last block is out, what remains is one tile update and the read-modify-write of the
+// tile's entries.  Wave 4 shares its SIMD with the factorising wave: it builds the descriptors of the stage after next and then carries the gradient column in three
+// batches of pivot blocks (sq_gradient_role) -- few instructions, mostly waiting, and its last batch runs while wave 0 stores its record rows.
 // Synchronisation inside the stage is by LDS words: the progress of wave 0 (monotonic over the backward pass: 16 ord + block + 1; one copy per lane, so that the store
-// needs no lane predicate), a count of consumer waves done with Y, and a count of those whose part of the assembly is complete (6 per stage each).  Every wait is
-// bounded: a wave that gives up raises the failure flag. ----
-#ifndef CMPC_SQ_STREAM
-#define CMPC_SQ_STREAM 1
-#endif
-__device__ inline int lds_peek(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-// the operand row of Z^T a lane feeds: up to four published rows with weights (the row's column of B or A, and the previous-force column for a force)
+// needs no lane predicate), a count of the waves done with Y (3 per stage), and a count of those whose part of the assembly is complete (6 per stage).  Every wait is
+// bounded: a wave that gives up raises the failure flag AND the give-up word c.flag[1], which the driver reports in its own digit of info[3] (include/cmpc.h) -- a
+// stalled hand-off must never read as a bad pivot.
+// BARRIER INVARIANT: sq_factor_loop and sq_consume_loop each execute exactly 1 + (N - k0) workgroup barriers per backward pass (sq_pass_barriers), one per stage plus
+// the one behind the terminal assembly, with no early exit on either side; tests/test_host_logic.py holds the two counts together. ----
+#define SQ_Y_WAVES 3           // consumer waves that write Y (waves 5, 6, 7): the Y count advances by this per stage
+// the stage loop of a backward pass: BOTH roles iterate with this header and hold exactly one barrier per trip (plus SQ_PRE_BARRIERS before the loop)
+#define SQ_STAGE_LOOP(k, N, k0) for (int k = (N) - 1; k >= (k0); --k)
+#define SQ_PRE_BARRIERS 1
+__host__ __device__ constexpr int sq_pass_barriers(int N, int k0) { return SQ_PRE_BARRIERS + (N - k0); }
+// Hand-off words: release on the publishing side, acquire on the reading side, workgroup scope (relaxed accesses leaned on in-order LDS issue of one wave,
+// which is how the hardware behaves and not what the memory model promises; on LDS-only traffic the stronger orders cost an s_waitcnt lgkmcnt(0) the code had anyway).
+__device__ inline int lds_peek(const int* p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ inline void lds_count(int* p) { __hip_atomic_fetch_add(p, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+// bounded wait until *p >= want; false: gave up (the caller raises the flags)
+__device__ inline bool lds_wait_ge(const int* p, int want)
+{
+    int spins = 0;
+    // (the word is one address for the whole wave: made provably uniform, so that the loop is scalar control flow and not an exec-mask waterfall)
+    while (__builtin_amdgcn_readfirstlane(lds_peek(p)) < want) {
+        if (++spins > SQ_SPIN_MAX) return false;
+        __builtin_amdgcn_s_sleep(1);
+    }
+    return true;
+}
+__device__ inline void sq_give_up(const Ctx& c) { c.flag[0] = 1; c.flag[1] = 1; }
+// the operand row of Z^T a lane feeds: up to four published rows with weights (the row's column of B or A, and the previous-force column for a force).  The ROWS do not
+// depend on the stage (the sparsity pattern of A and B is fixed): packed once per backward pass, 8 bits each; the weights are loaded per stage.
 struct ZRow { int r0, r1, r2, r3; float w0, w1, w2, w3; };
-__device__ inline ZRow zrow_of(const Ctx& c, const CmpcConsts& prm, int row)
+__device__ inline unsigned zrow_rows(const Ctx& c, int row)
+{
+    if (row >= NU + NS) return 0u;
+    const int* rows = row < NU ? c.Brow + 3 * row : c.Arow + 3 * (row - NU);
+    return (unsigned)rows[0] | ((unsigned)rows[1] << 8) | ((unsigned)rows[2] << 16) | ((unsigned)(row < NF ? NS + row : 0) << 24);
+}
+__device__ inline ZRow zrow_load(const Ctx& c, const CmpcConsts& prm, int row, unsigned rows)
 {
     ZRow z;
-    z.r0 = z.r1 = z.r2 = z.r3 = 0; z.w0 = z.w1 = z.w2 = z.w3 = 0.f;
-    if (row < NU + NS) {
-        const Desc3 d = row < NU ? desc_of(c.Brow, c.Bval, row) : desc_of(c.Arow, c.Aval, row - NU);
-        z.r0 = d.r0; z.r1 = d.r1; z.r2 = d.r2; z.w0 = d.w0; z.w1 = d.w1; z.w2 = d.w2;
-        if (row < NF) { z.r3 = NS + row; z.w3 = -prm.D[row % 3]; }   // W_p = -L^{-1}[:, :24] D: the identity rows are published unscaled
-    }
-    return z;   // (the gradient column, row 45, is not part of the tiles: see the gradient role of sq_consume)
+    z.r0 = rows & 255u; z.r1 = (rows >> 8) & 255u; z.r2 = (rows >> 16) & 255u; z.r3 = rows >> 24;
+    const int rc = row < NU + NS ? row : 0;
+    const float* vals = rc < NU ? c.Bval + 3 * rc : c.Aval + 3 * (rc - NU);
+    const bool ok = row < NU + NS;
+    z.w0 = ok ? vals[0] : 0.f; z.w1 = ok ? vals[1] : 0.f; z.w2 = ok ? vals[2] : 0.f;
+    z.w3 = row < NF ? -prm.D[row % 3] : 0.f;   // W_p = -L^{-1}[:, :24] D: the identity rows are published unscaled
+    return z;   // (the gradient column, row 45, is not part of the tiles: see sq_gradient_role)
 }
+__device__ inline ZRow zrow_of(const Ctx& c, const CmpcConsts& prm, int row) { return zrow_load(c, prm, row, zrow_rows(c, row)); }
 // The factorising wave's side of a backward pass: ONE call for all stages (the stage loop and its barriers inside: a call per stage cost the critical wave the
 // rebuilding of the LDS map every stage).
 template <int NT, int NC, bool FG>
@@ -1791,12 +1769,9 @@ __device__ __attribute__((noinline)) void sq_factor_loop(lds_t lds, int Nrt, flo
     const int k0 = __builtin_amdgcn_readfirstlane(k0_in);
     __syncthreads();                                   // (the consumers assemble stage N-1 from the terminal cost meanwhile)
     int ord = 0;                                       // ordinal of the stage within the backward pass
-#ifndef CMPC_FACT_PRIO
-#define CMPC_FACT_PRIO 3
-#endif
-    __builtin_amdgcn_s_setprio(CMPC_FACT_PRIO);
+    __builtin_amdgcn_s_setprio(3);
 #pragma unroll 1
-    for (int k = N - 1; k >= k0; --k) {
+    SQ_STAGE_LOOP(k, N, k0) {                          // (sq_pass_barriers: one barrier per trip, no early exit)
         ++ord;
         lds_t lk = lds;                                // (an opaque copy of the LDS base per stage: see sq_consume_loop)
         asm volatile("" : "+v"(lk));
@@ -1817,20 +1792,27 @@ __device__ __attribute__((noinline)) void sq_factor_loop(lds_t lds, int Nrt, flo
     __builtin_amdgcn_s_setprio(0);
 }
 // k: stage being factorised meanwhile (N: none, only the terminal stage's successor is assembled); kb: stage to assemble; kd: stage whose descriptors are built
-// meanwhile (-1: none); ord: ordinal of the stage within the backward pass.  All uniform.  (c by value: the descriptor set is selected in the copy)
-#ifndef CMPC_SQ_DEV
-#define CMPC_SQ_DEV 0    // timing probes of the streaming stage (wrong numerics; read 'cycles per stage of a pass' of a -DCMPC_PROFILE -DCMPC_PROFILE_LIGHT build):
-#endif                   //  1 no assembly, 2 no tiles, 4 no descriptors, 8 no gradient role
-__device__ inline void sq_consume_body(Ctx c, const CmpcConsts& prm, int tid, int N, int k, int kb, int kd, int ord, bool havep, bool use_exact, float reg, float cmu)
+// meanwhile (-1: none); ord: ordinal of the stage within the backward pass.  All uniform.  (c by value: the descriptor set is selected in the copy.)
+// tr: the thread's float32 triple; rowsA, rowsB: the packed published rows of its two tile operands -- all three fixed over the backward pass.
+__device__ inline void sq_consume_body(Ctx c, const CmpcConsts& prm, int tid, int N, int k, int kb, int kd, int ord, bool havep, bool use_exact, float reg, float cmu,
+                                       const Triple& tr, unsigned rowsA, unsigned rowsB, unsigned rowsG)
 {
     const float* Wb = c.ZT;                                       // published W^T, [block][panel row][4]
-    const int* prog = c.prog;                                     // progress of the factorising wave (lane 0's copy); c.flag[2]: consumer waves done with Y, c.flag[3]: with the assembly
-    // waves 1, 2, 3, 5, 6, 7 own a tile each (wv = 0..5) and share the assembly; wave 4 -- on the factorising wave's SIMD, a fraction of the issue slots -- only builds
-    // the descriptors of stage kd, which nobody reads before the next stage
+    const int* prog = c.prog;                                     // progress of the factorising wave (lane 0's copy); c.flag[2]: waves done with Y, c.flag[3]: with the assembly
+    // waves 1, 2, 3, 5, 6, 7 own a tile each (wv = 0..5) and share the assembly; wave 4 -- on the factorising wave's SIMD -- builds the descriptors of stage kd, which
+    // nobody reads before the next stage, and then carries the gradient column
     const int w7 = tid >> 6, ln = tid & 63, m4 = ln & 15, kq = ln >> 4;
     const int wv = w7 < 4 ? w7 - 1 : w7 - 2, t = 64 * wv + ln;
+    const int s = kb & 1, sc = s ^ 1;
+    float* QuuFn = c.QuuF + s * MSET;
+    float* Pann = c.Pan + s * MSET;
+    float* Qbn = c.Qb + s * NS * 16;
+    double* qsn = s ? c.qs1 : c.qs;
+#ifdef CMPC_PROFILE
+    const long long pc0_ = __builtin_amdgcn_s_memtime();
+#endif
     if (w7 == 4) {
-        if (!(CMPC_SQ_DEV & 4) && kd >= 0) {
+        if (kd >= 0) {
             use_desc_set(c, kd & 1);
             // (one role per trip -- B columns, A columns, barrier rows, exact-Hessian block -- each on lanes 0..n-1)
 #pragma unroll 1
@@ -1838,42 +1820,33 @@ __device__ inline void sq_consume_body(Ctx c, const CmpcConsts& prm, int tid, in
         }
         return;
     }
-#ifdef CMPC_PROFILE
-    const long long pc0_ = __builtin_amdgcn_s_memtime();
-#endif
-    const int s = kb & 1, sc = s ^ 1;
-    float* QuuFn = c.QuuF + s * MSET;
-    float* Pann = c.Pan + s * MSET;
-    float* Qbn = c.Qb + s * NS * 16;
-    double* qsn = s ? c.qs1 : c.qs;
     CPROF(0);
     use_desc_set(c, s);
-    // Y = Qss T_s first (180 threads), then -- behind a count of the consumer waves -- everything that reads it.  Y^T lives in the panel rows of the set being
-    // assembled that hold nothing in the streaming stage (the identity rows exist in registers only and W^T is published, not stored there)
+    const float* Qc = c.Qb + sc * NS * 16;
+    const double* qsc = sc ? c.qs1 : c.qs;
+    // the tile's operand weights: descriptor values of stage kb, there since the stage before -- fetched now, used after the assembly
+    const int I = wv >= 3 ? 2 : (wv >= 1 ? 1 : 0), J = wv - I * (I + 1) / 2;
+    const ZRow za = zrow_load(c, prm, 16 * I + m4, rowsA), zb = zrow_load(c, prm, 16 * J + m4, rowsB);
+    // Y = Qss T_s (180 threads on waves 5, 6, 7), then -- behind a count of those waves -- everything that reads it.  Y^T lives in the panel rows of the set being
+    // assembled that hold nothing in the streaming stage (the identity rows exist in registers only and W^T is published, not stored there).  The float64
+    // right-hand sides read no Y: waves 2 and 3 take them first (they were 3.4 k cycles behind Y on one wave: the longest pole of the stage, round 4 profile).
     float* YT = Pann + NS * RLD;
-    sq_y_body(c, t - 192, c.Qb + sc * NS * 16, YT);   // (waves 5, 6, 7: the float64 parts of the assembly sit on waves 1 and 2)
-    asm volatile("" ::: "memory");
-    if (ln == 0) __hip_atomic_fetch_add(c.flag + 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    {
-        const int want = SQ_TILE_WAVES * (ord + 1);
-        int spins = 0;
-        while (lds_peek(c.flag + 2) < want) {
-            if (++spins > SQ_SPIN_MAX) { if (ln == 0) *c.flag = 1; break; }
-            __builtin_amdgcn_s_sleep(1);
-        }
-        asm volatile("" ::: "memory");
-    }
-    if (!(CMPC_SQ_DEV & 1)) sq_base_body<384, true>(c, prm, t, kb, havep, reg, QuuFn, s ? c.QuuD1 : c.QuuD, Pann, Qbn, qsn, c.Qb + sc * NS * 16, sc ? c.qs1 : c.qs, YT);
-    asm volatile("" ::: "memory");
-    if (ln == 0) __hip_atomic_fetch_add(c.flag + 3, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (wv >= 3) {
+        sq_y_body(c, t - 192, Qc, YT);
+        CPROF2(0);
+        if (ln == 0) lds_count(c.flag + 2);
+    } else if (wv == 1) sq_rhs_qu_body(c, prm, ln, kb, havep, Pann, Qc, qsc);
+    else if (wv == 2) sq_rhs_qs_body(c, prm, ln, kb, havep, qsn, Qc, qsc);
+    CPROF2(1);
+    bool gaveup = !lds_wait_ge(c.flag + 2, SQ_Y_WAVES * (ord + 1));
+    CPROF2(2);
+    if (wv == 0) sq_diag_body(c, prm, ln, kb, havep, reg, QuuFn, s ? c.QuuD1 : c.QuuD, YT);
+    sq_triple_body(c, prm, tr, kb, QuuFn, Pann, Qbn, YT);
+    if (ln == 0) lds_count(c.flag + 3);
     CPROF(1);
-    if (!(CMPC_SQ_DEV & 2) && k < N) {
-        typedef float v4f __attribute__((ext_vector_type(4)));
-        const int I = wv >= 3 ? 2 : (wv >= 1 ? 1 : 0), J = wv - I * (I + 1) / 2;
-        const ZRow za = zrow_of(c, prm, 16 * I + m4), zb = zrow_of(c, prm, 16 * J + m4);
+    if (k < N) {
         const int fixedmask = (~c.qmask[k]) & 63;
         v4f acc = {0.f, 0.f, 0.f, 0.f};
-        bool gaveup = false;
         const int seq0 = 16 * ord;
         int avail = 0;                       // pivot blocks known to be published
         // blocks 0 .. nblk-1 published?  One look at the progress word; nothing at all while the last look already covers the request
@@ -1881,12 +1854,11 @@ __device__ inline void sq_consume_body(Ctx c, const CmpcConsts& prm, int tid, in
             if (avail >= nblk) return;
             int spins = 0;
             for (;;) {
-                avail = lds_peek(prog) - seq0;
+                avail = __builtin_amdgcn_readfirstlane(lds_peek(prog)) - seq0;
                 if (avail >= nblk) break;
                 if (++spins > SQ_SPIN_MAX) { gaveup = true; avail = 16; break; }
                 __builtin_amdgcn_s_sleep(1);
             }
-            asm volatile("" ::: "memory");
         };
         // the two operand entries of pivot block b
         // (the eight addresses of block 0 in registers: with the block number a constant, every load below is base + immediate offset)
@@ -1899,46 +1871,7 @@ __device__ inline void sq_consume_body(Ctx c, const CmpcConsts& prm, int tid, in
             a = za.w0 * x0 + za.w1 * x1 + za.w2 * x2 + za.w3 * x3;
             bv = zb.w0 * y0 + zb.w1 * y1 + zb.w2 * y2 + zb.w3 * y3;
         };
-        // The gradient column (row 45 of M) is not a tile row: z_g = lq + Ws d would need a 16-term combination per block in three tiles.  The wave of tile (2, 2)
-        // carries it instead as v = W^T z_g: lane <-> published row (0..14 Ws, 15 lq, 16..45 the identity rows), z_g of the block
-        // by a 16-lane DPP sum, v += x . z_g; at the end M[45][j] -= sum_a w_a(j) v[r_a(j)], the same sparse combination as a row of Z^T.
-        const bool grole = wv == 5 && !(CMPC_SQ_DEV & 8);
-        const int grow = ln < NS ? ln : (ln == NS ? NPAN - 1 : (ln < NPAN ? ln - 1 : 0));
-        const float gw = grole ? (ln < NS ? c.d[NS * kb + ln] : (ln == NS ? 1.f : 0.f)) : 0.f;
-        float vacc = 0.f;
-        auto gradient = [&](int b) {
-            const float4 x = *reinterpret_cast<const float4*>(Wb + (NPAN * b + grow) * 4);
-            float t0 = gw * x.x, t1 = gw * x.y, t2 = gw * x.z;
-            t0 += dpp_f<0x111>(t0); t1 += dpp_f<0x111>(t1); t2 += dpp_f<0x111>(t2);   // row_shr:1, 2, 4, 8: lane 15 ends with the sum of lanes 0..15
-            t0 += dpp_f<0x112>(t0); t1 += dpp_f<0x112>(t1); t2 += dpp_f<0x112>(t2);
-            t0 += dpp_f<0x114>(t0); t1 += dpp_f<0x114>(t1); t2 += dpp_f<0x114>(t2);
-            t0 += dpp_f<0x118>(t0); t1 += dpp_f<0x118>(t1); t2 += dpp_f<0x118>(t2);
-            vacc += x.x * readlane_f(t0, 15) + x.y * readlane_f(t1, 15) + x.z * readlane_f(t2, 15);
-        };
-        CPROF(2);
-        // blocks 0..7 (the forces: never skipped) in pairs: the loads of both in flight, two chained MFMAs
-#pragma unroll
-        for (int b = 0; b < 8; b += 2) {
-            need(b + 2);
-            float a0, b0, a1, b1;
-            operands(b, a0, b0);
-            operands(b + 1, a1, b1);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc, 0, 0, 0);
-            if (grole) { gradient(b); gradient(b + 1); }
-        }
-        CPROF(3);
-        // every consumer wave's part of the assembly must be in LDS before the tiles are subtracted from it; then what the tile is subtracted from
-        // is fetched -- ahead of the last blocks, off the tail of the stage
-        {
-            const int want = SQ_TILE_WAVES * (ord + 1);
-            int spins = 0;
-            while (lds_peek(c.flag + 3) < want) {
-                if (++spins > SQ_SPIN_MAX) { gaveup = true; break; }
-                __builtin_amdgcn_s_sleep(1);
-            }
-            asm volatile("" ::: "memory");
-        }
+        // where the tile goes (fixed per lane but for the set base): computed here, in the slack under the factorisation, not behind the last block
         const int jj = 16 * J + m4;
         float* dst[4];
         float* dst2[4];
@@ -1956,29 +1889,84 @@ __device__ inline void sq_consume_body(Ctx c, const CmpcConsts& prm, int tid, in
             }
             if (!ok[i]) { p = QuuFn; p2 = QuuFn; }
             dst[i] = p; dst2[i] = p2;
-            bs[i] = *p;
         }
-        // blocks 8, 9: the landing offsets of the two feet (a stance foot's block is skipped by the factorisation: nothing is published)
-        {
-            const bool sk8 = ((fixedmask >> 0) & 7) == 7, sk9 = ((fixedmask >> 3) & 7) == 7;
-            if (!sk8 && !sk9) {
-                need(10);
-                float a0, b0, a1, b1;
-                operands(8, a0, b0);
-                operands(9, a1, b1);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc, 0, 0, 0);
-                if (grole) { gradient(8); gradient(9); }
-            } else if (!sk8 || !sk9) {
-                const int b = sk8 ? 9 : 8;
-                need(b + 1);
-                float a0, b0;
-                operands(b, a0, b0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc, 0, 0, 0);
-                if (grole) gradient(b);
+        const bool sk8 = ((fixedmask >> 0) & 7) == 7, sk9 = ((fixedmask >> 3) & 7) == 7;   // (a stance foot's block is skipped by the factorisation: nothing is published)
+        // The gradient column (row 45 of M) is not a tile row: z_g = lq + Ws d would need a 16-term combination per block in three tiles.  The wave of tile (2, 2)
+        // carries it as v = W^T z_g, a pair of pivot blocks at a time: the six entries of z_g of the pair by eight lanes each (two of the sixteen terms per lane,
+        // summed by DPP), handed to all lanes through LDS; then lane <-> published row (0..14 Ws, 15 lq, 16..45 the identity rows) takes v += x . z_g.  At the end
+        // M[45][j] -= sum_a w_a(j) v[r_a(j)], the same sparse combination as a row of Z^T.  (Rounds 1-3: a 16-lane DPP sum of three components per BLOCK, 22
+        // instructions each: that wave finished 2 k cycles after the other five.  A batch form on wave 4 was measured too -- the factorising wave's SIMD mate is
+        // starved of issue slots: its descriptors alone take 6 k cycles of a 7 k stage.)
+        const bool grole = wv == 5;
+        const int ge = ln >> 3, gt = ln & 7;                       // entry of the pair (0..5 used), term
+        const int gcomp = ge % 3, gblk = ge < 3 ? 0 : 1;           // its component and block within the pair
+        const float* gsrc = Wb + (NPAN * gblk + gt) * 4 + gcomp;   // terms gt (Ws row gt) and gt + 8 (Ws row gt + 8; the lq row for gt = 7)
+        const int grow2 = gt == 7 ? NPAN - 1 : gt + 8;
+        const float gw0 = grole ? c.d[NS * kb + gt] : 0.f, gw1 = grole ? (gt == 7 ? 1.f : c.d[NS * kb + (gt == 7 ? 0 : gt + 8)]) : 0.f;
+        const int grow = ln < NS ? ln : (ln == NS ? NPAN - 1 : (ln < NPAN ? ln - 1 : 0));
+        float* zbuf = c.ybuf;                 // (the sweeps' 16-byte aligned staging buffer, 96 floats, idle during the backward pass): z_g of the pair, [block][4]
+        float vacc = 0.f;
+        struct GradLoads { float4 xa, xb; float g0, g1; };
+        auto gradient_loads = [&](int b) {
+            const int o = NPAN * 4 * b;
+            GradLoads gl;
+            gl.xa = *reinterpret_cast<const float4*>(Wb + o + grow * 4);
+            gl.xb = *reinterpret_cast<const float4*>(Wb + o + (NPAN + grow) * 4);
+            gl.g0 = gsrc[o]; gl.g1 = gsrc[o + 4 * (grow2 - gt)];
+            return gl;
+        };
+        auto gradient_pair = [&](const GradLoads& gl, bool skip0, bool skip1) {
+            float z = oct_sum(gw0 * gl.g0 + gw1 * gl.g1);
+            if ((gblk == 0 && skip0) || (gblk == 1 && skip1)) z = 0.f;
+            if (gt == 0 && ge < 6) zbuf[4 * gblk + gcomp] = z;
+            wave_lds_sync();
+            const float4 z0 = *reinterpret_cast<const float4*>(zbuf), z1 = *reinterpret_cast<const float4*>(zbuf + 4);
+            if (!skip0) vacc += gl.xa.x * z0.x + gl.xa.y * z0.y + gl.xa.z * z0.z;
+            if (!skip1) vacc += gl.xb.x * z1.x + gl.xb.y * z1.y + gl.xb.z * z1.z;
+            wave_lds_sync();
+        };
+        // the last step of the gradient role -- M[45][j] -= sum_a w_a(j) v[r_a(j)] -- has its operands fetched here, not behind the last block
+        ZRow zj = ZRow{0, 0, 0, 0, 0.f, 0.f, 0.f, 0.f};
+        if (grole) zj = zrow_load(c, prm, ln < NU + NS ? ln : NU + NS, rowsG);
+        double gbase = 0.0;
+        CPROF(2);
+        // blocks 0..7 (the forces: never skipped) in pairs: the loads of both in flight, two chained MFMAs
+#pragma unroll
+        for (int b = 0; b < 8; b += 2) {
+            need(b + 2);
+            float a0, b0, a1, b1;
+            operands(b, a0, b0);
+            operands(b + 1, a1, b1);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc, 0, 0, 0);
+            if (grole) gradient_pair(gradient_loads(b), false, false);   // (its loads behind the tile's: fetched together with the operand rows they cost 1.5 %)
+            if (b == 0) {
+                // every consumer wave's part of the assembly must be in LDS before the tiles are subtracted from it (long there by now); then what the tile is
+                // subtracted from is fetched -- far ahead of the last blocks, off the tail of the stage
+                gaveup = !lds_wait_ge(c.flag + 3, SQ_TILE_WAVES * (ord + 1)) || gaveup;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) bs[i] = *dst[i];
+                if (grole && ln < NU + NS) gbase = ln < NU ? c.pv[ln] : qsn[ln - NU];
             }
         }
-        if (gaveup && ln == 0) *c.flag = 1;
+        CPROF(3);
+        // blocks 8, 9: the landing offsets of the two feet
+        if (!sk8 && !sk9) {
+            need(10);
+            float a0, b0, a1, b1;
+            operands(8, a0, b0);
+            operands(9, a1, b1);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc, 0, 0, 0);
+        } else if (!sk8 || !sk9) {
+            const int b = sk8 ? 9 : 8;
+            need(b + 1);
+            float a0, b0;
+            operands(b, a0, b0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc, 0, 0, 0);
+        }
+        if (grole && !(sk8 && sk9)) gradient_pair(gradient_loads(8), sk8, sk9);
+        CPROF2(4);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             if (ok[i]) {
@@ -1988,18 +1976,18 @@ __device__ inline void sq_consume_body(Ctx c, const CmpcConsts& prm, int tid, in
             }
         }
         if (grole) {
-            float* vb = c.fpv;                     // (80 floats with fpn behind it; the sweeps' buffer, idle during the backward pass)
+            float* vb = c.ybuf + 16;               // (46 floats of the same buffer)
             if (ln < NPAN) vb[grow] = vacc;
             wave_lds_sync();
             if (ln < NU + NS) {
-                const ZRow zj = zrow_of(c, prm, ln);
                 const float val = zj.w0 * vb[zj.r0] + zj.w1 * vb[zj.r1] + zj.w2 * vb[zj.r2] + zj.w3 * vb[zj.r3];
-                if (ln < NU) Pann[(NPAN - 1) * RLD + ln] = (float)(c.pv[ln] - (double)val);
-                else qsn[ln - NU] -= (double)val;
+                if (ln < NU) Pann[(NPAN - 1) * RLD + ln] = (float)(gbase - (double)val);
+                else qsn[ln - NU] = gbase - (double)val;
             }
         }
         CPROF(4);
     }
+    if (gaveup && ln == 0) sq_give_up(c);
 }
 // The consumers' side of a backward pass (waves 1..7), one call: the assembly of stage N-1 from the terminal cost, then a stage per barrier.
 template <int NT, int NC, bool FG>
@@ -2008,11 +1996,22 @@ __device__ __attribute__((noinline)) void sq_consume_loop(lds_t lds, int Nrt, fl
     CMPC_PHASE_PROLOGUE;
     const int k0 = __builtin_amdgcn_readfirstlane(k0_in);
     const bool use_exact = __builtin_amdgcn_readfirstlane((int)exact_in) != 0;
-    sq_consume_body(c, prm, tid, N, N, N - 1, -1, 0, false, use_exact, reg, cmu);
+    // what does not change from stage to stage: the thread's triple and the published rows of its tile operands (descriptor ROWS are the same in both sets)
+    Triple tr;
+    unsigned rowsA, rowsB, rowsG;
+    {
+        const int w7 = tid >> 6, ln = tid & 63, m4 = ln & 15;
+        const int wv = w7 < 4 ? w7 - 1 : w7 - 2;
+        tr = triple_decode(w7 == 4 ? 360 : 64 * wv + ln);
+        const int I = wv >= 3 ? 2 : (wv >= 1 ? 1 : 0), J = wv - I * (I + 1) / 2;
+        rowsA = zrow_rows(c, 16 * I + m4); rowsB = zrow_rows(c, 16 * J + m4);
+        rowsG = zrow_rows(c, ln);            // (gradient role: the wave of tile (2, 2))
+    }
+    sq_consume_body(c, prm, tid, N, N, N - 1, -1, 0, false, use_exact, reg, cmu, tr, rowsA, rowsB, rowsG);
     __syncthreads();
     int ord = 0;
 #pragma unroll 1
-    for (int k = N - 1; k >= k0; --k) {
+    SQ_STAGE_LOOP(k, N, k0) {                          // (sq_pass_barriers: one barrier per trip, no early exit)
         ++ord;
         if (k > k0) {
             // (the LDS map is rebuilt from an opaque copy of the base every stage -- constant offsets, a handful of adds -- instead of living in ~60 registers across the loop:
@@ -2022,7 +2021,7 @@ __device__ __attribute__((noinline)) void sq_consume_loop(lds_t lds, int Nrt, fl
             char* smk = (char*)lk;
             Ctx ck;
             make_ctx<FG>(ck, smk, N, fg_base);
-            sq_consume_body(ck, *reinterpret_cast<const CmpcConsts*>(smk), tid, N, k, k - 1, k - 2 >= k0 ? k - 2 : -1, ord, true, use_exact, reg, cmu);
+            sq_consume_body(ck, *reinterpret_cast<const CmpcConsts*>(smk), tid, N, k, k - 1, k - 2 >= k0 ? k - 2 : -1, ord, true, use_exact, reg, cmu, tr, rowsA, rowsB, rowsG);
         }
         __syncthreads();
     }
@@ -2039,7 +2038,7 @@ __device__ __attribute__((noinline)) void sq_init(lds_t lds, int Nrt, float* fg_
         double* qN = (N & 1) ? c.qs1 : c.qs;
         if (tid < NS * 16) QN[tid] = (tid >> 4) == (tid & 15) ? qdiag(prm, N, tid & 15) : 0.f;
         else if (tid >= 256 && tid < 256 + NS) qN[tid - 256] = grad_track(c, prm, N, tid - 256);
-        if (tid < 4) c.flag[tid] = 0;   // failure flag | - | - | assembly count (streaming stage)
+        if (tid < 4) c.flag[tid] = 0;   // failure flag | sync give-up | Y count | assembly count (streaming stage)
         if (tid >= 128 && tid < 256) c.prog[tid - 128] = 0;   // progress of the factorising wave
         // the identity rows 18..29 take over lanes of finished L rows at block LATE_B: their entries of the blocks before it are zeros nobody ever writes
         if (tid >= 256 && tid < 256 + LATE_B * NLATE) {
@@ -2061,18 +2060,11 @@ __device__ inline int riccati_backward_sq(lds_t lds, const Ctx& c, float* fg_bas
 {
     const int N = c.N;
     sq_init<NT, NC, FG>(lds, N, fg_base, k0, use_exact, cmu);
-    if (CMPC_SQ_STREAM) {
-        if (threadIdx.x < 64) sq_factor_loop<NT, NC, FG>(lds, N, fg_base, k0);
-        else sq_consume_loop<NT, NC, FG>(lds, N, fg_base, k0, use_exact, reg, cmu);
-        return *c.flag ? 1 : 0;
-    }
-    sq_mid<NT, NC, FG>(lds, N, fg_base, N, N - 1, false, reg);                       // assemble stage N-1 (no Z: the terminal cost has no factors)
-    for (int k = N - 1; k >= k0; --k) {
-        sq_mid<NT, NC, FG>(lds, N, fg_base, k, k > k0 ? k - 1 : -1, true, reg);
-        if (k > k0) sq_post<NT, NC, FG>(lds, N, fg_base, k, k - 2 >= k0 ? k - 2 : -1, use_exact, cmu);
-    }
-    // (a non-positive pivot raises the flag and the stages after it run on garbage, harmlessly -- every array they write is rebuilt by the retry)
-    return *c.flag ? 1 : 0;
+    if (threadIdx.x < 64) sq_factor_loop<NT, NC, FG>(lds, N, fg_base, k0);
+    else sq_consume_loop<NT, NC, FG>(lds, N, fg_base, k0, use_exact, reg, cmu);
+    // (a non-positive pivot raises the flag and the stages after it run on garbage, harmlessly -- every array they write is rebuilt by the retry.
+    //  Bit 1: a wave gave up waiting at a hand-off word -- reported apart from a bad pivot, see the driver)
+    return (c.flag[0] ? 1 : 0) | (c.flag[1] ? 2 : 0);
 }
 
 // ---- Riccati backward sweep (matrices + right-hand side of the affine step, or of a centring step with target
@@ -2993,10 +2985,17 @@ __global__ __launch_bounds__(NT, FG ? 3 : 1) void cmpc_solve_kernel(CmpcParams k
             bool exact = prm.exact_hessian != 0;
             float reg = prm.reg;
             int fail = 1;
+            bool resync = false;
             for (int attempt = 0; attempt < 4; ++attempt) {
                 fail = phase_backward<NT, NC, FG>(lds, N, fg_base, exact, reg, centring ? prm.mu_min : 0.f);
                 if (!fail) break;
                 __syncthreads();
+                if (fail & 2) {
+                    // a wave of the streaming stage gave up at a hand-off word (never seen; a protocol bug would look like this): counted in its own digit of
+                    // info[3], and the same pass is tried once more as it was -- it is not a bad pivot and must not change the algorithm
+                    sg += 1000000;
+                    if (!resync) { resync = true; --attempt; continue; }
+                }
                 ++sg; exact = false;
                 if (attempt > 0) reg *= 1e3f;
             }
@@ -3060,6 +3059,16 @@ __global__ __launch_bounds__(NT, FG ? 3 : 1) void cmpc_solve_kernel(CmpcParams k
 
 }  // namespace
 
+// Workgroup barriers one role of the streaming stage executes in a backward pass over stages N-1 .. k0 (role 0: the factorising wave, sq_factor_loop; 1: the
+// consumers, sq_consume_loop), counted on the loop skeleton both device loops are written with.  A mismatch would be a hang of the whole workgroup on the GPU:
+// tests/test_host_logic.py holds the two together.
+extern "C" int cmpc_sq_pass_barriers(int N, int k0, int role)
+{
+    int n = SQ_PRE_BARRIERS;
+    SQ_STAGE_LOOP(k, N, k0) { (void)role; ++n; }
+    return n == sq_pass_barriers(N, k0) ? n : -1;
+}
+
 // LDS bytes the kernel needs for horizon N
 extern "C" size_t cmpc_solver_lds_bytes(int N, int factors_global)
 {
@@ -3077,8 +3086,8 @@ extern "C" size_t cmpc_solver_lds_bytes(int N, int factors_global)
 #ifdef CMPC_PROFILE
 extern "C" int cmpc_profile_read(long long* out, int reset)
 {
-    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof), sizeof(long long) * 64);
-    if (reset) { long long z[64] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof(z)); }
+    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof), sizeof(long long) * 128);
+    if (reset) { long long z[128] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof(z)); }
     return (int)e;
 }
 extern "C" int cmpc_trace_read(float* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_trace), sizeof(float) * 64 * 8); }

@@ -17,7 +17,7 @@ else:
     cfg, P, X0 = cm.synthetic.config2_perturbed_com(256)
 s = cm.BatchSolver(cfg, P.shape[0])
 X, info, rc = s.solve_host(P, X0)
-out = (C.c_longlong * 64)()
+out = (C.c_longlong * 128)()
 cm._capi.lib().cmpc_profile_read(out, 1)
 v = np.array(out[:18], float)
 tot = v[10:18].sum()
@@ -40,6 +40,14 @@ if any(out[32:62]):
     print("  consumer waves 1, 2, 3, 5, 6, 7, cycles from entry (per stage of a pass): entry | assembly | operand rows | blocks 0-7 | exit")
     for w in range(6):
         print("    wave %d: " % (w + 1 if w < 3 else w + 2) + " ".join("%6d" % (out[32 + 5 * w + i] / den) for i in range(5)))
+if any(out[64:112]):
+    den = out[31] * cfg.N
+    print("  finer: Y written | Y wait over | float64 part | [assembly] | assembly-count wait over | blocks 8, 9 | [exit]")
+    for w in range(6):
+        print("    wave %d: " % (w + 1 if w < 3 else w + 2) + " ".join("%6d" % (out[64 + 8 * w + i] / den) for i in range(5)))
+if any(out[112:120]):
+    den = out[31] * cfg.N
+    print("  wave 4: descriptors done | blocks 0-3 | blocks 4-7 | gradient column applied: " + " ".join("%6d" % (out[112 + i] / den) for i in range(4)))
 tr = (C.c_float * 512)()
 cm._capi.lib().cmpc_trace_read(tr)
 tr = np.array(tr[:]).reshape(64, 8)
