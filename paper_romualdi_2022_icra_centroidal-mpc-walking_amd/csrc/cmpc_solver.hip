@@ -69,7 +69,7 @@
 #define SQ_SPIN_MAX (1 << 20)  // looks at a progress word or a count before a waiting wave gives up (raises the failure flag: the pass ends as a failed factorisation)
 #define SQ_PUB_FLOATS (10 * NPAN * 4 + 128 * 4)   // published W^T: ten pivot blocks x 46 panel rows x float4, and a slot per lane of two waves for lanes without a panel row
 #define ZLD 36     // leading dim of Z^T (48 rows: 30 u-columns, 15 s-columns, the gradient column, 2 zero rows)
-#define MSET (NU * RLD + NPAN * RLD)   // floats of one set QuuF | Pan (the resident variants hold two: stage k is factorised from set k & 1)
+#define MSET (NU * RLD + NPAN * RLD + NS * 16)   // floats of one set QuuF | Pan | Qb (the resident variants hold two: stage k is factorised from set k & 1)
 #define NTRI 256   // entries of the lower-triangle index table (the users need 210: 2x2 tiles of a 39x39)
 // Per-stage factor record (floats), in LDS or -- FG kernels -- in HBM scratch.  Phase 3 leaves column m of
 // L^{-1} and column j of Ws = L^{-1} Qus in the registers of one lane, so both are stored transposed, one
@@ -160,7 +160,7 @@ struct Ctx {
     float *Lf;             // per-stage factor records (REC_N floats each)
     float *geoA;           // N x GEO
     float *P0, *Qb, *G, *QuuF, *Pan, *Bval, *Aval, *arow, *ybuf, *fpv, *fpn;
-    float *ZT;             // (resident variants) Z^T of the square-root backward stage; there Qb and QuuF | Pan exist twice (stride NS * 16, MSET)
+    float *ZT;             // (resident variants) the published W^T of the streaming stage; there QuuF | Pan | Qb exist twice (stride MSET)
     double *QuuD1, *qs1;   // (resident variants) second set of the float64 diagonal blocks and of qs
     int *Brow, *Arow, *qmask;
     unsigned short* tri;
@@ -251,11 +251,12 @@ __device__ inline void make_ctx(Ctx& c, char* smem, int N, float* fg_base)
     c.Pan = fp; fp += NPAN * RLD;
     c.ZT = nullptr;
     if (!FG) {
-        // resident variants: QuuF0 | Pan0 | QuuF1 | Pan1 | Z^T | Qb0 | Qb1 -- G and P0 (only the four-wave developer variant still forms them) lie over set 1 and Z^T
-        c.G = fp; c.P0 = fp + ((NXA * GLD + 3) & ~3);
+        // resident variants: QuuF0 | Pan0 | Qb0 | QuuF1 | Pan1 | Qb1 | published W^T -- one stride (MSET) for everything a stage is assembled in, so that the set is an
+        // immediate offset in the consumers' LDS instructions
+        c.G = nullptr; c.P0 = nullptr;
+        c.Qb = fp; fp += NS * 16;
         fp += MSET;
-        c.ZT = fp; fp += SQ_PUB_FLOATS;   // Z^T (48 x ZLD) or -- streaming stage -- the published W^T, [block][panel row][4]
-        c.Qb = fp; fp += 2 * NS * 16;
+        c.ZT = fp; fp += SQ_PUB_FLOATS;   // the published W^T of the streaming stage, [block][panel row][4]
     } else {
     c.G = fp; fp += (NXA * GLD + 3) & ~3;                   // (sizes rounded to 16 bytes: ybuf and the LDS factor records
     c.P0 = fp; fp += (NXA * PLD + 3) & ~3; c.Qb = fp; fp += NS * 16;   //  behind them are read with ds_read_b128)
@@ -1491,218 +1492,10 @@ __device__ __attribute__((noinline)) void stage_post_pre(lds_t lds, int Nrt, flo
 //   uu  lower triangle, float, in QuuF (the slots inside the 3x3 diagonal blocks hold only the -Z^T Z part; their cost / barrier part is float64 in QuuD)
 //   su  Pan rows 0..14 (row s, 30 columns),  gu  Pan row NPAN-1 (qu),  ss  Qb (both triangles),  gs  qs (float64)
 // =====================================================================================================================
-struct Desc3 { int r0, r1, r2; float w0, w1, w2; };
-__device__ inline Desc3 desc_of(const int* rows, const float* vals, int col)
-{
-    Desc3 d;
-    d.r0 = rows[3 * col]; d.r1 = rows[3 * col + 1]; d.r2 = rows[3 * col + 2];
-    d.w0 = vals[3 * col]; d.w1 = vals[3 * col + 1]; d.w2 = vals[3 * col + 2];
-    return d;
-}
-// a^T Q b for two sparse columns (Q: 15 x 15 in rows of 16 floats, both triangles)
-__device__ inline float sandwich(const float* Q, const Desc3& a, const Desc3& b)
-{
-    const float* q0 = Q + 16 * a.r0;
-    const float* q1 = Q + 16 * a.r1;
-    const float* q2 = Q + 16 * a.r2;
-    return a.w0 * (b.w0 * q0[b.r0] + b.w1 * q0[b.r1] + b.w2 * q0[b.r2]) + a.w1 * (b.w0 * q1[b.r0] + b.w1 * q1[b.r1] + b.w2 * q1[b.r2])
-           + a.w2 * (b.w0 * q2[b.r0] + b.w1 * q2[b.r1] + b.w2 * q2[b.r2]);
-}
-
-// ---- the part of stage k's matrix that does not depend on the factorisation of stage k+1:  cost, barrier, Levenberg terms
-// + T^T [Qss 0; 0 D] T (Qss, qs of stage k+1 in Qc, qsc; havep: stage k+1 has a previous-force block, i.e. it is not the terminal stage).
-// 256 threads (t): 0..59 the float64 diagonal blocks of Quu; 64..127 hb = [Qss d + qs; -D (u_k+1 - u_k)] and behind it, on the same wave, qu and qs;
-// then all of them the 405 float tasks: 135 triples of Quu, 150 triples of Qus^T, 120 entries of Qss.  c: descriptor set of stage k selected. ----
-// Y^T = (Qc T_s)^T, T_s = [B A] (15 x 45): row col of Y^T = sum_b w_b(col) Qc[r_b(col)][:] (Qc is symmetric), 16 floats; one float4 per thread, 180 threads.
-// With it a sandwich entry T_i^T Qc T_col is three loads instead of nine (and the column's descriptor is not needed).
-__device__ inline void sq_y_body(const Ctx& c, int t, const float* Qc, float* YT)
-{
-    if (t < 0 || t >= 4 * (NU + NS)) return;
-    const int col = t >> 2, q = t & 3;
-    const Desc3 d = desc_of(c.Brow, c.Bval, col);
-    const float4 x0 = *reinterpret_cast<const float4*>(Qc + 16 * d.r0 + 4 * q);
-    const float4 x1 = *reinterpret_cast<const float4*>(Qc + 16 * d.r1 + 4 * q);
-    const float4 x2 = *reinterpret_cast<const float4*>(Qc + 16 * d.r2 + 4 * q);
-    *reinterpret_cast<float4*>(YT + 16 * col + 4 * q) = make_float4(d.w0 * x0.x + d.w1 * x1.x + d.w2 * x2.x, d.w0 * x0.y + d.w1 * x1.y + d.w2 * x2.y,
-                                                                     d.w0 * x0.z + d.w1 * x1.z + d.w2 * x2.z, d.w0 * x0.w + d.w1 * x1.w + d.w2 * x2.w);
-}
-__device__ inline float sandwich_y(const float* YT, const Desc3& a, int col) { const float* y = YT + 16 * col; return a.w0 * y[a.r0] + a.w1 * y[a.r1] + a.w2 * y[a.r2]; }
-// ---- the assembly roles of the consumer waves.  c: descriptor set of stage k selected; Qc, qsc: Qss and qs of stage k+1; havep: stage k+1 has a
-// previous-force block (it is not the terminal stage). ----
-// The ten 3x3 diagonal blocks of Quu in float64 (60 lower entries, lane l), branch-free on clamped indices.
-__device__ inline void sq_diag_body(const Ctx& c, const CmpcConsts& prm, int l, int k, bool havep, float reg, float* QuuFn, double* QuuDn, const float* YT)
-{
-    const bool pk = k > 0;
-    const int tc = l < 60 ? l : 59;
-    const int b = tc / 6, w = tc - 6 * b;
-    const int rr = w >= 3 ? 2 : (w >= 1 ? 1 : 0), cc = w - rr * (rr + 1) / 2;
-    const int i = 3 * b + rr, j = 3 * b + cc;
-    const bool isF = i < NF, dg = i == j;
-    const Desc3 di = desc_of(c.Brow, c.Bval, i);
-    const int r0 = isF ? 4 * b : 0;             // friction rows of the corner
-    const int iq = isF ? 0 : i - 24;            // landing-offset component
-    double sg[4], ar[4], ac[4];
-#pragma unroll
-    for (int f = 0; f < 4; ++f) { sg[f] = c.sig[r0 + f]; ar[f] = (double)c.arow[3 * (r0 + f) + rr]; ac[f] = (double)c.arow[3 * (r0 + f) + cc]; }
-    const double slo = c.sig[32 + iq], shi = c.sig[38 + iq];
-    const bool fr = qfree(c, k, iq);
-    const double gam = gam_of(c, isF ? i / 12 : 0, k);
-    const double v = (double)sandwich_y(YT, di, j);
-    double vF = v;
-    if (dg) {
-        vF += 2.0 * prm.w_sym * (1.0 - 0.25 * gam * (2.0 - gam));
-        if (pk) vF += (double)prm.D[i % 3];       // own force-rate cost
-        if (havep) vF += (double)prm.D[i % 3];    // E^T D E: the next stage's force-rate cost
-        vF += (double)reg;
-    }
-#pragma unroll
-    for (int f = 0; f < 4; ++f) vF += sg[f] * ar[f] * ac[f];
-    const double vQ = dg ? (fr ? v + slo + shi + (double)reg : 1.0) : v;   // fixed q: exact identity row
-    if (l < 60) {
-        QuuDn[9 * b + 3 * rr + cc] = isF ? vF : vQ;
-        QuuFn[i * RLD + j] = 0.f;   // the float copy of a diagonal block collects -Z^T Z and the updates by earlier blocks
-    }
-}
-// hb = [Qss d + qs; -D (u_k+1 - u_k)] (float64), rows 0 .. nrow-1, into hb[] (lane l <-> row l); needs nothing but Qss, qs of stage k+1
-__device__ inline void sq_hb_rows(const Ctx& c, const CmpcConsts& prm, int l, int k, bool havep, int nrow, const float* Qc, const double* qsc, double* hb)
-{
-    const int r = l < nrow ? l : nrow - 1;
-    double hv;
-    if (r < NS) {
-        double acc = 0.0;
-#pragma unroll
-        for (int a = 0; a < NS; ++a) acc += (double)Qc[16 * a + r] * (double)c.d[NS * k + a];
-        hv = qsc[r] + acc;
-    } else {
-        const int m = r - NS;
-        hv = havep ? -(double)prm.D[m % 3] * ((double)c.U[NU * (k + 1) + m] - (double)c.U[NU * k + m]) : 0.0;
-    }
-    if (l < nrow) hb[r] = hv;
-    wave_lds_sync();
-}
-// qu (float64, one wave): gradient of the symmetry cost, barrier terms, force-rate term, B~^T hb.  Left in c.pv (float64) until -Z^T z_g has been
-// subtracted (the gradient role); the terminal stage has no Z and writes the panel row itself.
-__device__ inline void sq_rhs_qu_body(const Ctx& c, const CmpcConsts& prm, int l, int k, bool havep, float* Pann, const float* Qc, const double* qsc)
-{
-    const bool pk = k > 0;
-    const float* u = c.U + NU * k;
-    double* hb = c.Pd;
-    sq_hb_rows(c, prm, l, k, havep, NXA, Qc, qsc, hb);
-    const int iq = l < NU ? l : NU - 1;
-    const bool isF = iq < NF;
-    const int m = isF ? iq : 0, ct = m / 12, ax = m % 3;
-    const int q = isF ? 0 : iq - 24;
-    const float* uf = u + 12 * ct + ax;
-    const float u0 = uf[0], u1 = uf[3], u2 = uf[6], u3 = uf[9], um = u[m];
-    const float up = c.U[NU * (pk ? k - 1 : 0) + m];
-    const double gam = gam_of(c, ct, k);
-    const int r0 = 4 * (m / 3);
-    double gc[4], ar[4];
-#pragma unroll
-    for (int f = 0; f < 4; ++f) { gc[f] = c.gco[r0 + f]; ar[f] = (double)c.arow[3 * (r0 + f) + ax]; }
-    const double glo = c.gco[32 + q], ghi = c.gco[38 + q];
-    const bool fr = qfree(c, k, q);
-    const Desc3 dq = desc_of(c.Brow, c.Bval, iq);
-    const double mean = 0.25 * ((double)u0 + (double)u1 + (double)u2 + (double)u3);
-    const double esum = 4.0 * mean * (1.0 - gam);
-    double gF = 2.0 * prm.w_sym * (((double)um - gam * mean) - 0.25 * gam * esum);
-#pragma unroll
-    for (int f = 0; f < 4; ++f) gF += gc[f] * ar[f];
-    if (pk) gF += (double)prm.D[ax] * ((double)um - (double)up);
-    const double gQ = fr ? glo - ghi : 0.0;
-    double g = isF ? (havep ? gF + hb[NS + m] : gF) : gQ;
-    g += (double)dq.w0 * hb[dq.r0] + (double)dq.w1 * hb[dq.r1] + (double)dq.w2 * hb[dq.r2];
-    if (l < NU) {
-        c.pv[iq] = g;
-        if (!havep) Pann[(NPAN - 1) * RLD + iq] = (float)g;
-    }
-}
-// qs = gradient of the tracking cost + A^T hb[0..14] (float64, another wave than qu: its own copy of the 15 rows of hb it needs, in c.pn), one formula
-// with per-lane coefficients:  qs_j = w_j (s_j - ref_j) + sj v_j + ce v_je + cg (v_{6+a1} F_a2 - v_{6+a2} F_a1)
-__device__ inline void sq_rhs_qs_body(const Ctx& c, const CmpcConsts& prm, int l, int k, bool havep, double* qsn, const float* Qc, const double* qsc)
-{
-    double* hs = c.pn;
-    sq_hb_rows(c, prm, l, k, havep, NS, Qc, qsc, hs);
-    const int j = l < NS ? l : NS - 1;
-    const int ja = j < 3 ? j : (j >= 9 ? (j - 9) % 3 : 0), ja1 = (ja + 1) % 3, ja2 = (ja + 2) % 3;
-    const int jct = j >= 12 ? 1 : 0;
-    const int roff = j < 3 ? c.L.pComref() + j : (j < 6 ? c.L.pComref() : (j < 9 ? c.L.pHref() + j - 6 : c.L.pNom(jct) + ja));
-    const double wj = (double)qdiag(prm, k, j);
-    const float* geo = c.geoA + GEO * k;
-    const float* F = geo + (j < 3 ? 30 : 24 + 3 * jct);    // Fsum or Fc of the foot
-    const int je = (j >= 3 && j < 6) ? j - 3 : 0;
-    const double gam = gam_of(c, jct, k);
-    const double dt = prm.dt;
-    const double sj = j >= 9 ? gam : 1.0;
-    const double ce = (j >= 3 && j < 6) ? dt : 0.0;
-    const double cg = j < 3 ? dt : (j >= 9 ? -dt * gam : 0.0);
-    const double sv = (double)c.S[NS * k + j], rv = (double)c.sp[roff + 3 * k];
-    const double F1 = (double)F[ja1], F2 = (double)F[ja2];
-    const double vj = hs[j], ve = hs[je], v1 = hs[6 + ja1], v2 = hs[6 + ja2];
-    const double out = wj * (sv - rv) + sj * vj + ce * ve + cg * (v1 * F2 - v2 * F1);
-    if (l < NS) qsn[j] = out;
-}
-// The float32 entries: 360 triples of consecutive entries -- 135 of Quu (row i, block column bj < bi), 150 of Qus^T (row jr, the xyz of one corner / one foot's
-// offset), 75 of Qss (row i, columns 3 jb .. 3 jb + 2: both triangles) -- by one branch-free formula on the descriptor table [B columns | A columns]:
-//   out_c = row^T Qc col_c + ew E[3 c] - [c == symc] symw + [c == qc] qd
-// Which entries a thread owns, where they go and which of the extra terms they carry does not depend on the stage: decoded once per backward pass
-// (triple_decode, two packed words held across the stage loop) -- the decode was 60 of the ~110 instructions of a triple, every stage.
-struct Triple { unsigned w0, w1; };
-//   w0: destination offset [0:11] | kind [12:13] (0 Quu, 1 Qus^T, 2 Qss, 3 none) | descriptor of the row [14:19] | of the first column [20:25]
-//   w1: symc [0:1] (3 none) | sy [2] | foot of the row [3] | sign of the exact-Hessian term [4:5] (0 none, 1 +, 2 -) | its foot [6] | its E column [7:8] | qc [9:10] (3 none) | row of Qss [11:14]
-__device__ inline Triple triple_decode(int id)
-{
-    Triple tr;
-    if (id >= 360) { tr.w0 = 3u << 12; tr.w1 = 3u | (3u << 9); return tr; }
-    const bool isuu = id < 135, isss = id >= 285;
-    // (block row, block column) of the p-th strictly-lower block pair, p = 0..44, in closed form
-    const int p = isuu ? id / 3 : 0;
-    const int bi = 1 + (p >= 1) + (p >= 3) + (p >= 6) + (p >= 10) + (p >= 15) + (p >= 21) + (p >= 28) + (p >= 36);
-    const int bj = p - bi * (bi - 1) / 2;
-    const int idp = isuu ? 0 : (isss ? id - 285 : id - 135);
-    const int pr = isss ? idp / 5 : idp / 10, pc = isss ? idp % 5 : idp % 10;      // Qus^T: row jr = pr, triple pc; Qss: row pr, triple pc
-    const int i = isuu ? 3 * bi + id % 3 : pr;
-    const int col0 = isuu ? 3 * bj : 3 * pc;
-    const int drow = isuu ? i : NU + pr;                    // descriptor of the row: column i of B, or column pr of A
-    const int dcol = isss ? NU + col0 : col0;               // descriptors of the three columns
-    const int doff = isuu ? i * RLD + col0 : (isss ? 16 * pr + col0 : pr * RLD + col0);
-    // Quu: another corner of the same foot, same axis: symmetry-cost coupling
-    const bool sy = isuu && i < NF && (i / 12) == (col0 / 12);
-    const int symc = isuu ? i % 3 : 3;
-    // Qus^T: exact-Hessian cross term -/+ gam Sx between a force and com / its foot's position
-    const int ct = col0 / 12;
-    const int bb = pr < 3 ? pr : pr - 9 - 3 * ct;
-    const bool bin = bb >= 0 && bb < 3;
-    const int sgn = (!isuu && !isss && col0 < NF) ? (pr < 3 ? 2 : (bin ? 1 : 0)) : 0;
-    // Qss: the stage cost on the diagonal
-    const int qc = (isss && pr >= col0 && pr < col0 + 3) ? pr - col0 : 3;
-    tr.w0 = (unsigned)doff | ((isuu ? 0u : (isss ? 2u : 1u)) << 12) | ((unsigned)drow << 14) | ((unsigned)dcol << 20);
-    tr.w1 = (unsigned)symc | ((sy ? 1u : 0u) << 2) | (((isuu && i >= 12) ? 1u : 0u) << 3) | ((unsigned)sgn << 4) | (((ct < 2 ? ct : 0) & 1u) << 6)
-            | ((unsigned)(bin ? bb : 0) << 7) | ((unsigned)qc << 9) | ((unsigned)(isss ? pr : 0) << 11);
-    return tr;
-}
-__device__ inline void sq_triple_body(const Ctx& c, const CmpcConsts& prm, const Triple& tr, int k, float* QuuFn, float* Pann, float* Qbn, const float* YT)
-{
-    const unsigned kind = (tr.w0 >> 12) & 3u;
-    if (kind == 3u) return;
-    const int doff = tr.w0 & 0xfff, drow = (tr.w0 >> 14) & 63, dcol = (tr.w0 >> 20) & 63;
-    float* dst = (kind == 0u ? QuuFn : (kind == 2u ? Qbn : Pann)) + doff;
-    const int symc = tr.w1 & 3u, qc = (tr.w1 >> 9) & 3u, sgn = (tr.w1 >> 4) & 3u, pr = (tr.w1 >> 11) & 15u;
-    const float gam0 = gam_of(c, 0, k), gam1 = gam_of(c, 1, k);
-    const float gq = ((tr.w1 >> 3) & 1u) ? gam1 : gam0;
-    const float symw = ((tr.w1 >> 2) & 1u) ? 2.f * prm.w_sym * 0.25f * gq * (2.f - gq) : 0.f;
-    const float ge = ((tr.w1 >> 6) & 1u) ? gam1 : gam0;
-    const float ew = sgn == 0 ? 0.f : (sgn == 1 ? ge : -ge);
-    const float* E = c.arow + 96 + ((tr.w1 >> 7) & 3u);
-    const float qd = kind == 2u ? qdiag(prm, k, pr) : 0.f;
-    const Desc3 dr = desc_of(c.Brow, c.Bval, drow);
-    const float e0 = E[0], e1 = E[3], e2 = E[6];
-    float o0 = sandwich_y(YT, dr, dcol) + ew * e0, o1 = sandwich_y(YT, dr, dcol + 1) + ew * e1, o2 = sandwich_y(YT, dr, dcol + 2) + ew * e2;
-    o0 += (qc == 0 ? qd : 0.f) - (symc == 0 ? symw : 0.f);
-    o1 += (qc == 1 ? qd : 0.f) - (symc == 1 ? symw : 0.f);
-    o2 += (qc == 2 ? qd : 0.f) - (symc == 2 ? symw : 0.f);
-    dst[0] = o0; dst[1] = o1; dst[2] = o2;
-}
+// With T = [B~ A~] (39 x 45, <= 4 non-zeros per column), W = L^{-1}[Qus | -D] of stage k+1 and Z = W T, stage k's matrix is
+//   (cost, barrier, Levenberg terms + T^T [Qss 0; 0 D] T)  -  Z^T Z:
+// the bracket needs nothing of stage k+1's factorisation and is assembled while that runs, through Y = Qss [B A] (15 x 45): a sandwich entry T_i^T Qss T_col is then
+// three loads, sum_a w_a(i) Y[r_a(i)][col], instead of nine.
 
 // ---- The streaming square-root stage: ONE barrier per stage, one call per backward pass and role.  The factorisation runs on wave 0 (the one-wave scheme: 76 rows
 // in 64 lanes, trailing updates on the matrix pipe) and publishes the three finished columns of W^T after every pivot block (chol_block<.., PUB>).  Waves 1, 2, 3, 5, 6, 7
@@ -1739,27 +1532,6 @@ __device__ inline bool lds_wait_ge(const int* p, int want)
     return true;
 }
 __device__ inline void sq_give_up(const Ctx& c) { c.flag[0] = 1; c.flag[1] = 1; }
-// the operand row of Z^T a lane feeds: up to four published rows with weights (the row's column of B or A, and the previous-force column for a force).  The ROWS do not
-// depend on the stage (the sparsity pattern of A and B is fixed): packed once per backward pass, 8 bits each; the weights are loaded per stage.
-struct ZRow { int r0, r1, r2, r3; float w0, w1, w2, w3; };
-__device__ inline unsigned zrow_rows(const Ctx& c, int row)
-{
-    if (row >= NU + NS) return 0u;
-    const int* rows = row < NU ? c.Brow + 3 * row : c.Arow + 3 * (row - NU);
-    return (unsigned)rows[0] | ((unsigned)rows[1] << 8) | ((unsigned)rows[2] << 16) | ((unsigned)(row < NF ? NS + row : 0) << 24);
-}
-__device__ inline ZRow zrow_load(const Ctx& c, const CmpcConsts& prm, int row, unsigned rows)
-{
-    ZRow z;
-    z.r0 = rows & 255u; z.r1 = (rows >> 8) & 255u; z.r2 = (rows >> 16) & 255u; z.r3 = rows >> 24;
-    const int rc = row < NU + NS ? row : 0;
-    const float* vals = rc < NU ? c.Bval + 3 * rc : c.Aval + 3 * (rc - NU);
-    const bool ok = row < NU + NS;
-    z.w0 = ok ? vals[0] : 0.f; z.w1 = ok ? vals[1] : 0.f; z.w2 = ok ? vals[2] : 0.f;
-    z.w3 = row < NF ? -prm.D[row % 3] : 0.f;   // W_p = -L^{-1}[:, :24] D: the identity rows are published unscaled
-    return z;   // (the gradient column, row 45, is not part of the tiles: see sq_gradient_role)
-}
-__device__ inline ZRow zrow_of(const Ctx& c, const CmpcConsts& prm, int row) { return zrow_load(c, prm, row, zrow_rows(c, row)); }
 // The factorising wave's side of a backward pass: ONE call for all stages (the stage loop and its barriers inside: a call per stage cost the critical wave the
 // rebuilding of the LDS map every stage).
 template <int NT, int NC, bool FG>
@@ -1791,144 +1563,387 @@ __device__ __attribute__((noinline)) void sq_factor_loop(lds_t lds, int Nrt, flo
     }
     __builtin_amdgcn_s_setprio(0);
 }
-// k: stage being factorised meanwhile (N: none, only the terminal stage's successor is assembled); kb: stage to assemble; kd: stage whose descriptors are built
-// meanwhile (-1: none); ord: ordinal of the stage within the backward pass.  All uniform.  (c by value: the descriptor set is selected in the copy.)
-// tr: the thread's float32 triple; rowsA, rowsB: the packed published rows of its two tile operands -- all three fixed over the backward pass.
-__device__ inline void sq_consume_body(Ctx c, const CmpcConsts& prm, int tid, int N, int k, int kb, int kd, int ord, bool havep, bool use_exact, float reg, float cmu,
-                                       const Triple& tr, unsigned rowsA, unsigned rowsB, unsigned rowsG)
+// =====================================================================================================================
+// The consumers of the streaming stage, lean form (round 4).  One wave executes at most one instruction of ANY kind per four cycles, so what a
+// consumer wave costs is its instruction count, scalar bookkeeping and exec-mask juggling included: the first streaming version spent ~1 800
+// instructions per wave and stage, two thirds of them index decoding, clamping and divergent control flow that does not depend on the stage.
+// Here everything that is fixed over a backward pass -- which entries a lane owns, the rows its sparse columns point at, where results go -- is
+// decoded ONCE per pass into a per-lane plan of indices and 0/1 float masks (ConsPlan), the stage body is straight-line code on clamped indices
+// (results of lanes without a task go to words nobody reads), and the set a stage is assembled in is a template parameter, so that every set offset
+// folds into the immediate field of the LDS instruction (that is why Qss lives inside the set: QuuF | Pan | Qb, one stride).
+// =====================================================================================================================
+struct ConsPlan {
+    // the thread's float32 triple: out_c = w . Y[:, col + c] + ew E[3 c] + m_c (qd - symw)
+    int t_dst, t_w, t_y0, t_y1, t_y2, t_e;
+    float t_symk, t_fsel, t_esgn, t_efsel, t_qdc, t_zsel, t_m0, t_m1, t_m2;
+    // the lane's two tile operands: published rows (float index kq + 4 r into the publication buffer) and where their weights are
+    int pa0, pa1, pa2, pa3, pb0, pb1, pb2, pb3, wa, wb;
+    float wa3, wb3;
+    // where the four results of the lane go (float index from QuuF of the set) and their mirror images (Qss is kept with both triangles)
+    int d0, d1, d2, d3, e0, e1, e2, e3;
+    // role of the wave: waves 1, 2, 3 the float64 parts (diagonal blocks, q_u, q_s), waves 5, 6, 7 Y, wave 7 also the gradient column
+    int ri[14];
+    float rf[6];
+};
+#define SQ_TRASH (32)   // float index, from QuuF of a set, of four words nobody reads (columns 32..35 of row 0: the rows are read as 32 floats)
+// rows of column `col` of [B | A] (fixed sparsity pattern; read from a descriptor set that has been built)
+__device__ inline void plan_rows(const int* rows, int col, int& r0, int& r1, int& r2) { r0 = rows[3 * col]; r1 = rows[3 * col + 1]; r2 = rows[3 * col + 2]; }
+__device__ inline void cons_plan_build(ConsPlan& pl, const Ctx& c, const CmpcConsts& prm, int w7, int ln, const int* rows)
 {
-    const float* Wb = c.ZT;                                       // published W^T, [block][panel row][4]
-    const int* prog = c.prog;                                     // progress of the factorising wave (lane 0's copy); c.flag[2]: waves done with Y, c.flag[3]: with the assembly
-    // waves 1, 2, 3, 5, 6, 7 own a tile each (wv = 0..5) and share the assembly; wave 4 -- on the factorising wave's SIMD -- builds the descriptors of stage kd, which
-    // nobody reads before the next stage, and then carries the gradient column
-    const int w7 = tid >> 6, ln = tid & 63, m4 = ln & 15, kq = ln >> 4;
-    const int wv = w7 < 4 ? w7 - 1 : w7 - 2, t = 64 * wv + ln;
-    const int s = kb & 1, sc = s ^ 1;
-    float* QuuFn = c.QuuF + s * MSET;
-    float* Pann = c.Pan + s * MSET;
-    float* Qbn = c.Qb + s * NS * 16;
-    double* qsn = s ? c.qs1 : c.qs;
-#ifdef CMPC_PROFILE
-    const long long pc0_ = __builtin_amdgcn_s_memtime();
-#endif
+    const int wv = w7 < 4 ? w7 - 1 : w7 - 2;       // 0..5 (wave 4 has no plan: -1 here)
+    const int m4 = ln & 15, kq = ln >> 4;
+    // ---- triple ----
+    {
+        const int id = (wv >= 0 && w7 != 4) ? 64 * wv + ln : 360;
+        const bool val = id < 360;
+        const int idc = val ? id : 0;
+        const bool isuu = idc < 135, isss = idc >= 285;
+        const int p = isuu ? idc / 3 : 0;
+        const int bi = 1 + (p >= 1) + (p >= 3) + (p >= 6) + (p >= 10) + (p >= 15) + (p >= 21) + (p >= 28) + (p >= 36);
+        const int bj = p - bi * (bi - 1) / 2;
+        const int idp = isuu ? 0 : (isss ? idc - 285 : idc - 135);
+        const int pr = isss ? idp / 5 : idp / 10, pc = isss ? idp % 5 : idp % 10;
+        const int i = isuu ? 3 * bi + idc % 3 : pr;
+        const int col0 = isuu ? 3 * bj : 3 * pc;
+        const int drow = isuu ? i : NU + pr;
+        const int dcol = isss ? NU + col0 : col0;
+        int r0, r1, r2;
+        plan_rows(rows, drow, r0, r1, r2);
+        pl.t_w = 3 * drow;
+        pl.t_y0 = 16 * dcol + r0; pl.t_y1 = 16 * dcol + r1; pl.t_y2 = 16 * dcol + r2;
+        pl.t_dst = !val ? SQ_TRASH : (isuu ? i * RLD + col0 : (isss ? NU * RLD + NPAN * RLD + 16 * pr + col0 : NU * RLD + pr * RLD + col0));
+        const bool sy = isuu && i < NF && (i / 12) == (col0 / 12);
+        pl.t_symk = sy ? 0.5f * prm.w_sym : 0.f;
+        pl.t_fsel = (isuu && i >= 12) ? 1.f : 0.f;
+        const int ct = col0 / 12;
+        const int bb = pr < 3 ? pr : pr - 9 - 3 * ct;
+        const bool bin = bb >= 0 && bb < 3;
+        const bool su = !isuu && !isss;
+        pl.t_esgn = (su && col0 < NF) ? (pr < 3 ? -1.f : (bin ? 1.f : 0.f)) : 0.f;
+        pl.t_efsel = (ct == 1) ? 1.f : 0.f;
+        pl.t_e = 96 + (bin ? bb : 0);
+        const int symc = isuu ? i % 3 : -1, qc = isss ? pr - col0 : -1;
+        const int mc = isuu ? symc : qc;             // component that carries the extra term (-symw for Quu, +qd for Qss)
+        pl.t_m0 = mc == 0 ? 1.f : 0.f; pl.t_m1 = mc == 1 ? 1.f : 0.f; pl.t_m2 = mc == 2 ? 1.f : 0.f;
+        pl.t_qdc = (isss && pr != 2) ? qdiag(prm, 0, pr) : 0.f;
+        pl.t_zsel = (isss && pr == 2) ? 1.f : 0.f;
+    }
+    // ---- tile ----
+    {
+        const int wvc = wv < 0 ? 0 : wv;
+        const int I = wvc >= 3 ? 2 : (wvc >= 1 ? 1 : 0), J = wvc - I * (I + 1) / 2;
+        auto operand = [&](int row, int& p0, int& p1, int& p2, int& p3, int& w, float& w3) {
+            const bool ok = row < NU + NS;
+            int r0 = 0, r1 = 0, r2 = 0;
+            if (ok) plan_rows(rows, row, r0, r1, r2);
+            p0 = kq + 4 * r0; p1 = kq + 4 * r1; p2 = kq + 4 * r2; p3 = kq + 4 * (row < NF ? NS + row : 0);
+            w = ok ? 3 * row : 3 * NU + 3 * NS + 3 + 105;      // (arow[105..107]: never written, zero since the kernel started)
+            w3 = row < NF ? -prm.D[row % 3] : 0.f;             // W_p = -L^{-1}[:, :24] D: the identity rows are published unscaled
+        };
+        operand(16 * I + m4, pl.pa0, pl.pa1, pl.pa2, pl.pa3, pl.wa, pl.wa3);
+        operand(16 * J + m4, pl.pb0, pl.pb1, pl.pb2, pl.pb3, pl.wb, pl.wb3);
+        const int jj = 16 * J + m4;
+        int d[4], e[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int ii = 16 * I + 4 * kq + i;
+            const bool ok = jj <= ii && ii < NU + NS;
+            int p = ii * RLD + jj, p2 = p;
+            if (ii >= NU) {
+                if (jj < NU) { p = NU * RLD + (ii - NU) * RLD + jj; p2 = p; }
+                else { p = NU * RLD + NPAN * RLD + 16 * (ii - NU) + (jj - NU); p2 = NU * RLD + NPAN * RLD + 16 * (jj - NU) + (ii - NU); }
+            }
+            d[i] = ok ? p : SQ_TRASH + i; e[i] = ok ? p2 : SQ_TRASH + i;
+        }
+        pl.d0 = d[0]; pl.d1 = d[1]; pl.d2 = d[2]; pl.d3 = d[3];
+        pl.e0 = e[0]; pl.e1 = e[1]; pl.e2 = e[2]; pl.e3 = e[3];
+    }
+    // ---- role ----
+#pragma unroll
+    for (int q = 0; q < 14; ++q) pl.ri[q] = 0;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) pl.rf[q] = 0.f;
+    if (wv == 0) {
+        // the ten 3x3 diagonal blocks of Quu in float64: lane <-> lower entry w of block b: (row, col) = (0,0) (1,0) (1,1) (2,0) (2,1) (2,2)
+        const int tc = ln < 60 ? ln : 59;
+        const int b = tc / 6, w = tc - 6 * b;
+        const int rr = w >= 3 ? 2 : (w >= 1 ? 1 : 0), cc = w - rr * (rr + 1) / 2;
+        const int i = 3 * b + rr, j = 3 * b + cc;
+        const bool isF = i < NF;
+        int r0, r1, r2;
+        plan_rows(rows, i, r0, r1, r2);
+        const int f0 = isF ? 4 * b : 0;
+        pl.ri[0] = 3 * i; pl.ri[1] = 16 * j + r0; pl.ri[2] = 16 * j + r1; pl.ri[3] = 16 * j + r2;
+        pl.ri[4] = f0; pl.ri[5] = 3 * f0 + rr; pl.ri[6] = 3 * f0 + cc; pl.ri[7] = isF ? 0 : i - 24;
+        pl.ri[8] = 9 * b + 3 * rr + cc;                           // (lanes 60..63 repeat lane 59: the same value to the same word)
+        pl.ri[9] = i * RLD + j;
+        pl.rf[0] = isF ? 1.f : 0.f; pl.rf[1] = rr == cc ? 1.f : 0.f; pl.rf[2] = (isF && i >= 12) ? 1.f : 0.f; pl.rf[3] = prm.D[i % 3];
+    } else if (wv == 1) {
+        // q_u: lane l <-> row l of hb (39) and entry l of q_u (30)
+        const int r = ln < NXA ? ln : NXA - 1, iq = ln < NU ? ln : NU - 1;
+        const bool isF = iq < NF;
+        const int m = isF ? iq : 0, ct = m / 12, ax = m % 3, q = isF ? 0 : iq - 24;
+        const int mr = r >= NS ? r - NS : 0;
+        int r0, r1, r2;
+        plan_rows(rows, iq, r0, r1, r2);
+        pl.ri[0] = r < NS ? r : NS - 1; pl.ri[1] = mr; pl.ri[2] = 12 * ct + ax; pl.ri[3] = m; pl.ri[4] = 4 * (m / 3); pl.ri[5] = 12 * (m / 3) + ax;
+        pl.ri[6] = q; pl.ri[7] = 3 * iq; pl.ri[8] = r0; pl.ri[9] = r1; pl.ri[10] = r2; pl.ri[11] = iq;
+        pl.rf[0] = isF ? 1.f : 0.f; pl.rf[1] = ct ? 1.f : 0.f; pl.rf[2] = prm.D[mr % 3]; pl.rf[3] = prm.D[ax]; pl.rf[4] = r < NS ? 1.f : 0.f;
+    } else if (wv == 2) {
+        // q_s: lane l <-> state component l
+        const int j = ln < NS ? ln : NS - 1;
+        const int ja = j < 3 ? j : (j >= 9 ? (j - 9) % 3 : 0), ja1 = (ja + 1) % 3, ja2 = (ja + 2) % 3;
+        const int jct = j >= 12 ? 1 : 0;
+        const int gfo = j < 3 ? 30 : 24 + 3 * jct;
+        pl.ri[0] = j;
+        pl.ri[1] = j < 3 ? c.L.pComref() + j : (j < 6 ? c.L.pComref() : (j < 9 ? c.L.pHref() + j - 6 : c.L.pNom(jct) + ja));
+        pl.ri[2] = gfo + ja1; pl.ri[3] = gfo + ja2; pl.ri[4] = (j >= 3 && j < 6) ? j - 3 : 0; pl.ri[5] = 6 + ja1; pl.ri[6] = 6 + ja2;
+        pl.rf[0] = j != 2 ? qdiag(prm, 0, j) : 0.f; pl.rf[1] = j == 2 ? 1.f : 0.f; pl.rf[2] = jct ? 1.f : 0.f;
+        pl.rf[3] = j < 3 ? 1.f : 0.f; pl.rf[4] = (j >= 3 && j < 6) ? 1.f : 0.f; pl.rf[5] = j >= 9 ? 1.f : 0.f;
+    } else if (wv >= 3) {
+        // Y^T = (Qss [B A])^T: one float4 per lane (180 of the 192)
+        const int t = 64 * (wv - 3) + ln, col = t >> 2, q = t & 3;
+        const int cl = col < NU + NS ? col : NU + NS - 1;
+        int r0, r1, r2;
+        plan_rows(rows, cl, r0, r1, r2);
+        pl.ri[0] = 3 * cl; pl.ri[1] = 16 * r0 + 4 * q; pl.ri[2] = 16 * r1 + 4 * q; pl.ri[3] = 16 * r2 + 4 * q;
+        pl.ri[4] = col < NU + NS ? NS * RLD + 16 * col + 4 * q : -1;     // float index from Pan of the set, or none
+        if (wv == 5) {
+            // gradient column: z_g of a pair of pivot blocks by eight lanes per entry (term gt and gt + 8 of the sixteen), then lane <-> published row
+            const int ge = ln >> 3, gt = ln & 7;
+            const int gcomp = ge % 3, gblk = ge < 3 ? 0 : 1;
+            const int grow2 = gt == 7 ? NPAN - 1 : gt + 8;
+            pl.ri[5] = (NPAN * gblk + gt) * 4 + gcomp; pl.ri[6] = (NPAN * gblk + grow2) * 4 + gcomp;
+            pl.ri[7] = gt; pl.ri[8] = gt == 7 ? 0 : gt + 8;
+            pl.ri[9] = (gt == 0 && ge < 6) ? 4 * gblk + gcomp : 8 + (ln & 7);          // z_g slot, or a word of the staging buffer nobody reads
+            pl.ri[10] = 4 * (ln < NS ? ln : (ln == NS ? NPAN - 1 : (ln < NPAN ? ln - 1 : 0)));   // the lane's published row
+            // last step: M[45][j] -= sum_a w_a(j) v[r_a(j)], lane j < 45
+            const int jr = ln < NU + NS ? ln : NU + NS - 1;
+            plan_rows(rows, jr, r0, r1, r2);
+            pl.ri[11] = r0 | (r1 << 8) | (r2 << 16) | ((jr < NF ? NS + jr : 0) << 24);
+            pl.ri[12] = 3 * jr;
+            pl.ri[13] = ln < NPAN ? 16 + (ln < NS ? ln : (ln == NS ? NPAN - 1 : ln - 1)) : 64 + (ln & 15);   // where the lane's v goes in the staging buffer
+            pl.rf[0] = gt == 7 ? 1.f : 0.f; pl.rf[1] = gblk ? 1.f : 0.f; pl.rf[2] = jr < NF ? -prm.D[jr % 3] : 0.f;
+            pl.rf[3] = ln < NU ? 1.f : 0.f; pl.rf[4] = ln < NU + NS ? 1.f : 0.f;
+        }
+    }
+}
+// One stage of the consumers.  S: the set stage kb is assembled in (kb & 1); k: stage being factorised meanwhile (N: none -- the terminal call: only stage N-1 is
+// assembled, no previous-force block: havep false); kd: stage whose descriptors wave 4 builds (-1: none); ord: ordinal of the stage within the pass.  All uniform.
+template <int S>
+__device__ __forceinline__ void sq_consume_stage(const Ctx& c, const CmpcConsts& prm, const ConsPlan& pl, int tid, int N, int k, int kb, int kd, int ord, bool havep,
+                                                 bool use_exact, float reg, float cmu)
+{
+    const int w7 = tid >> 6, ln = tid & 63;
+    const int wv = w7 < 4 ? w7 - 1 : w7 - 2;
     if (w7 == 4) {
+        // the factorising wave's SIMD mate: descriptors of stage kd, which nobody reads before the next stage (it is starved of issue slots: nothing else lives here)
         if (kd >= 0) {
-            use_desc_set(c, kd & 1);
-            // (one role per trip -- B columns, A columns, barrier rows, exact-Hessian block -- each on lanes 0..n-1)
+            Ctx cd = c;
+            use_desc_set(cd, kd & 1);
 #pragma unroll 1
-            for (int r = 0; r < 4; ++r) stage_desc_body(c, prm, desc_role_t(r, ln), kd, use_exact, cmu);
+            for (int r = 0; r < 4; ++r) stage_desc_body(cd, prm, desc_role_t(r, ln), kd, use_exact, cmu);
         }
         return;
     }
+#ifdef CMPC_PROFILE
+    const long long pc0_ = __builtin_amdgcn_s_memtime();
+#endif
     CPROF(0);
-    use_desc_set(c, s);
-    const float* Qc = c.Qb + sc * NS * 16;
-    const double* qsc = sc ? c.qs1 : c.qs;
-    // the tile's operand weights: descriptor values of stage kb, there since the stage before -- fetched now, used after the assembly
-    const int I = wv >= 3 ? 2 : (wv >= 1 ? 1 : 0), J = wv - I * (I + 1) / 2;
-    const ZRow za = zrow_load(c, prm, 16 * I + m4, rowsA), zb = zrow_load(c, prm, 16 * J + m4, rowsB);
-    // Y = Qss T_s (180 threads on waves 5, 6, 7), then -- behind a count of those waves -- everything that reads it.  Y^T lives in the panel rows of the set being
-    // assembled that hold nothing in the streaming stage (the identity rows exist in registers only and W^T is published, not stored there).  The float64
-    // right-hand sides read no Y: waves 2 and 3 take them first (they were 3.4 k cycles behind Y on one wave: the longest pole of the stage, round 4 profile).
+    // the sets: stage kb is assembled in set S (QuuF | Pan | Qb, float64 diagonal blocks, qs) from Qss, qs of stage kb + 1 in set S ^ 1 and the descriptors of stage kb (set S)
+    float* Mn = c.QuuF + S * MSET;
+    float* Pann = Mn + NU * RLD;
+    const float* Qc = c.Qb + (S ^ 1) * MSET;
+    double* qsn = S ? c.qs1 : c.qs;
+    const double* qsc = S ? c.qs : c.qs1;
+    double* QuuDn = S ? c.QuuD1 : c.QuuD;
+    const float* Bval = c.Bval + S * DSET_F;       // Bval | Aval | arow contiguous: index 3 col for a column of [B | A], 3 NU + 3 NS + 3 + e for arow[e]
+    const float* arow = c.arow + S * DSET_F;
+    const double* sig = c.sig + S * 2 * NI;
+    const double* gco = c.gco + S * 2 * NI;
     float* YT = Pann + NS * RLD;
+    const float gam0 = c.sp[c.L.pGam(0) + kb], gam1 = c.sp[c.L.pGam(1) + kb];
+    const float dgam = gam1 - gam0;
+    const float* Wb = c.ZT;                        // published W^T, [block][panel row][4]
+    // the tile's operand weights: descriptor values of stage kb, there since the stage before -- fetched now, used after the assembly
+    const float wa0 = Bval[pl.wa], wa1 = Bval[pl.wa + 1], wa2 = Bval[pl.wa + 2];
+    const float wb0 = Bval[pl.wb], wb1 = Bval[pl.wb + 1], wb2 = Bval[pl.wb + 2];
+    bool gaveup = false;
+    // ---- what needs no Y ----
     if (wv >= 3) {
-        sq_y_body(c, t - 192, Qc, YT);
+        // Y^T = (Qss [B A])^T in the panel rows of the set that hold nothing in the streaming stage
+        const float w0 = Bval[pl.ri[0]], w1 = Bval[pl.ri[0] + 1], w2 = Bval[pl.ri[0] + 2];
+        const float4 x0 = *reinterpret_cast<const float4*>(Qc + pl.ri[1]);
+        const float4 x1 = *reinterpret_cast<const float4*>(Qc + pl.ri[2]);
+        const float4 x2 = *reinterpret_cast<const float4*>(Qc + pl.ri[3]);
+        if (pl.ri[4] >= 0)
+            *reinterpret_cast<float4*>(Pann + pl.ri[4]) = make_float4(w0 * x0.x + w1 * x1.x + w2 * x2.x, w0 * x0.y + w1 * x1.y + w2 * x2.y,
+                                                                      w0 * x0.z + w1 * x1.z + w2 * x2.z, w0 * x0.w + w1 * x1.w + w2 * x2.w);
         CPROF2(0);
         if (ln == 0) lds_count(c.flag + 2);
-    } else if (wv == 1) sq_rhs_qu_body(c, prm, ln, kb, havep, Pann, Qc, qsc);
-    else if (wv == 2) sq_rhs_qs_body(c, prm, ln, kb, havep, qsn, Qc, qsc);
+    } else if (wv == 1) {
+        // hb = [Qss d + qs; -D (u_kb+1 - u_kb)] (float64), then q_u = gradient of the symmetry cost + barrier terms + force-rate term + B~^T hb
+        const bool pk = kb > 0;
+        double* hb = c.Pd;
+        const float* u = c.U + NU * kb;
+        {
+            const float* qcol = Qc + pl.ri[0];
+            const float* dk = c.d + NS * kb;
+            double acc = 0.0;
+#pragma unroll
+            for (int a = 0; a < NS; ++a) acc += (double)qcol[16 * a] * (double)dk[a];
+            const double hs = qsc[pl.ri[0]] + acc;
+            const float du = c.U[NU * (havep ? kb + 1 : kb) + pl.ri[1]] - u[pl.ri[1]];
+            const double hr = -(double)pl.rf[2] * (double)du;
+            if (ln < NXA) hb[ln] = pl.rf[4] != 0.f ? hs : hr;
+        }
+        wave_lds_sync();
+        const int m = pl.ri[3], q = pl.ri[6];
+        const float* uf = u + pl.ri[2];
+        const float u0 = uf[0], u1 = uf[3], u2 = uf[6], u3 = uf[9], um = u[m];
+        const float up = c.U[NU * (pk ? kb - 1 : 0) + m];
+        const double gam = (double)fmaf(pl.rf[1], dgam, gam0);
+        const double* gcp = gco + pl.ri[4];
+        const float* arp = arow + pl.ri[5];
+        double gF;
+        {
+            const double mean = 0.25 * ((double)u0 + (double)u1 + (double)u2 + (double)u3);
+            const double esum = 4.0 * mean * (1.0 - gam);
+            gF = 2.0 * prm.w_sym * (((double)um - gam * mean) - 0.25 * gam * esum);
+#pragma unroll
+            for (int f = 0; f < 4; ++f) gF += gcp[f] * (double)arp[3 * f];
+            if (pk) gF += (double)pl.rf[3] * ((double)um - (double)up);
+            if (havep) gF += hb[NS + m];
+        }
+        const bool fr = (c.qmask[kb] >> q) & 1;
+        const double gQ = fr ? gco[32 + q] - gco[38 + q] : 0.0;
+        double g = pl.rf[0] != 0.f ? gF : gQ;
+        g += (double)Bval[pl.ri[7]] * hb[pl.ri[8]] + (double)Bval[pl.ri[7] + 1] * hb[pl.ri[9]] + (double)Bval[pl.ri[7] + 2] * hb[pl.ri[10]];
+        if (ln < NU) {
+            c.pv[ln] = g;                                          // float64 until -Z^T z_g has been subtracted (the gradient role)
+            if (!havep) Pann[(NPAN - 1) * RLD + ln] = (float)g;   // (the terminal stage has no Z)
+        }
+    } else if (wv == 2) {
+        // q_s = gradient of the tracking cost + A^T hb[0..14], its own copy of those rows of hb in c.pn
+        double* hs = c.pn;
+        {
+            const float* qcol = Qc + pl.ri[0];
+            const float* dk = c.d + NS * kb;
+            double acc = 0.0;
+#pragma unroll
+            for (int a = 0; a < NS; ++a) acc += (double)qcol[16 * a] * (double)dk[a];
+            if (ln < NS) hs[ln] = qsc[pl.ri[0]] + acc;
+        }
+        wave_lds_sync();
+        const int j = pl.ri[0];
+        const double wj = (double)fmaf(pl.rf[1], prm.wz2[kb], pl.rf[0]);
+        const float* geo = c.geoA + GEO * kb;
+        const double gam = (double)fmaf(pl.rf[2], dgam, gam0);
+        const double dt = prm.dt;
+        const double sj = pl.rf[5] != 0.f ? gam : 1.0;
+        const double ce = (double)pl.rf[4] * dt;
+        const double cg = (double)pl.rf[3] * dt - (double)pl.rf[5] * dt * gam;
+        const double sv = (double)c.S[NS * kb + j], rv = (double)c.sp[pl.ri[1] + 3 * kb];
+        const double F1 = (double)geo[pl.ri[2]], F2 = (double)geo[pl.ri[3]];
+        const double out = wj * (sv - rv) + sj * hs[j] + ce * hs[pl.ri[4]] + cg * (hs[pl.ri[5]] * F2 - hs[pl.ri[6]] * F1);
+        if (ln < NS) qsn[j] = out;
+    }
     CPROF2(1);
-    bool gaveup = !lds_wait_ge(c.flag + 2, SQ_Y_WAVES * (ord + 1));
+    gaveup = !lds_wait_ge(c.flag + 2, SQ_Y_WAVES * (ord + 1));
     CPROF2(2);
-    if (wv == 0) sq_diag_body(c, prm, ln, kb, havep, reg, QuuFn, s ? c.QuuD1 : c.QuuD, YT);
-    sq_triple_body(c, prm, tr, kb, QuuFn, Pann, Qbn, YT);
+    // ---- behind Y ----
+    if (wv == 0) {
+        // the ten 3x3 diagonal blocks of Quu in float64 (cost, barrier and Levenberg terms + the sandwich entry)
+        const bool pk = kb > 0;
+        const float w0 = Bval[pl.ri[0]], w1 = Bval[pl.ri[0] + 1], w2 = Bval[pl.ri[0] + 2];
+        const double v = (double)(w0 * YT[pl.ri[1]] + w1 * YT[pl.ri[2]] + w2 * YT[pl.ri[3]]);
+        const double* sg = sig + pl.ri[4];
+        const float* ar = arow + pl.ri[5];
+        const float* ac = arow + pl.ri[6];
+        const double gam = (double)fmaf(pl.rf[2], dgam, gam0);
+        double vF = v;
+        if (pl.rf[1] != 0.f) {
+            vF += 2.0 * prm.w_sym * (1.0 - 0.25 * gam * (2.0 - gam));
+            if (pk) vF += (double)pl.rf[3];       // own force-rate cost
+            if (havep) vF += (double)pl.rf[3];    // E^T D E: the next stage's force-rate cost
+            vF += (double)reg;
+        }
+#pragma unroll
+        for (int f = 0; f < 4; ++f) vF += sg[f] * (double)ar[3 * f] * (double)ac[3 * f];
+        const int iq = pl.ri[7];
+        const bool fr = (c.qmask[kb] >> iq) & 1;
+        const double vQ = pl.rf[1] != 0.f ? (fr ? v + sig[32 + iq] + sig[38 + iq] + (double)reg : 1.0) : v;   // fixed q: exact identity row
+        QuuDn[pl.ri[8]] = pl.rf[0] != 0.f ? vF : vQ;
+        Mn[pl.ri[9]] = 0.f;   // the float copy of a diagonal block collects -Z^T Z and the updates by earlier blocks
+    }
+    {
+        // the thread's triple
+        const float w0 = Bval[pl.t_w], w1 = Bval[pl.t_w + 1], w2 = Bval[pl.t_w + 2];
+        const float* y0 = YT + pl.t_y0;
+        const float* y1 = YT + pl.t_y1;
+        const float* y2 = YT + pl.t_y2;
+        const float* E = arow + pl.t_e;
+        const float gq = fmaf(pl.t_fsel, dgam, gam0);
+        const float ex = fmaf(pl.t_zsel, prm.wz2[kb], pl.t_qdc) - pl.t_symk * gq * (2.f - gq);
+        const float ew = pl.t_esgn * fmaf(pl.t_efsel, dgam, gam0);
+        float* dst = Mn + pl.t_dst;
+        dst[0] = w0 * y0[0] + w1 * y1[0] + w2 * y2[0] + ew * E[0] + pl.t_m0 * ex;
+        dst[1] = w0 * y0[16] + w1 * y1[16] + w2 * y2[16] + ew * E[3] + pl.t_m1 * ex;
+        dst[2] = w0 * y0[32] + w1 * y1[32] + w2 * y2[32] + ew * E[6] + pl.t_m2 * ex;
+    }
     if (ln == 0) lds_count(c.flag + 3);
     CPROF(1);
     if (k < N) {
         const int fixedmask = (~c.qmask[k]) & 63;
+        const bool sk8 = ((fixedmask >> 0) & 7) == 7, sk9 = ((fixedmask >> 3) & 7) == 7;   // (a stance foot's block is skipped by the factorisation: nothing is published)
         v4f acc = {0.f, 0.f, 0.f, 0.f};
         const int seq0 = 16 * ord;
-        int avail = 0;                       // pivot blocks known to be published
-        // blocks 0 .. nblk-1 published?  One look at the progress word; nothing at all while the last look already covers the request
+        int avail = 0;                       // pivot blocks known to be published (uniform)
         auto need = [&](int nblk) {
             if (avail >= nblk) return;
             int spins = 0;
             for (;;) {
-                avail = __builtin_amdgcn_readfirstlane(lds_peek(prog)) - seq0;
+                avail = __builtin_amdgcn_readfirstlane(lds_peek(c.prog)) - seq0;
                 if (avail >= nblk) break;
                 if (++spins > SQ_SPIN_MAX) { gaveup = true; avail = 16; break; }
                 __builtin_amdgcn_s_sleep(1);
             }
         };
-        // the two operand entries of pivot block b
-        // (the eight addresses of block 0 in registers: with the block number a constant, every load below is base + immediate offset)
-        const float* pa0 = Wb + kq + 4 * za.r0; const float* pa1 = Wb + kq + 4 * za.r1; const float* pa2 = Wb + kq + 4 * za.r2; const float* pa3 = Wb + kq + 4 * za.r3;
-        const float* pb0 = Wb + kq + 4 * zb.r0; const float* pb1 = Wb + kq + 4 * zb.r1; const float* pb2 = Wb + kq + 4 * zb.r2; const float* pb3 = Wb + kq + 4 * zb.r3;
+        const float* pa0 = Wb + pl.pa0; const float* pa1 = Wb + pl.pa1; const float* pa2 = Wb + pl.pa2; const float* pa3 = Wb + pl.pa3;
+        const float* pb0 = Wb + pl.pb0; const float* pb1 = Wb + pl.pb1; const float* pb2 = Wb + pl.pb2; const float* pb3 = Wb + pl.pb3;
         auto operands = [&](int b, float& a, float& bv) {
             const int o = NPAN * 4 * b;
             const float x0 = pa0[o], x1 = pa1[o], x2 = pa2[o], x3 = pa3[o];
             const float y0 = pb0[o], y1 = pb1[o], y2 = pb2[o], y3 = pb3[o];   // (a diagonal tile loads the same four again: no branch in the load stream)
-            a = za.w0 * x0 + za.w1 * x1 + za.w2 * x2 + za.w3 * x3;
-            bv = zb.w0 * y0 + zb.w1 * y1 + zb.w2 * y2 + zb.w3 * y3;
+            a = wa0 * x0 + wa1 * x1 + wa2 * x2 + pl.wa3 * x3;
+            bv = wb0 * y0 + wb1 * y1 + wb2 * y2 + pl.wb3 * y3;
         };
-        // where the tile goes (fixed per lane but for the set base): computed here, in the slack under the factorisation, not behind the last block
-        const int jj = 16 * J + m4;
-        float* dst[4];
-        float* dst2[4];
-        float bs[4];
-        bool ok[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int ii = 16 * I + 4 * kq + i;
-            ok[i] = jj <= ii && ii < NU + NS;
-            float* p = QuuFn + ii * RLD + jj;                                   // uu
-            float* p2 = p;
-            if (ii >= NU) {
-                if (jj < NU) { p = Pann + (ii - NU) * RLD + jj; p2 = p; }       // su
-                else { p = Qbn + 16 * (ii - NU) + (jj - NU); p2 = Qbn + 16 * (jj - NU) + (ii - NU); }   // ss, both triangles
-            }
-            if (!ok[i]) { p = QuuFn; p2 = QuuFn; }
-            dst[i] = p; dst2[i] = p2;
-        }
-        const bool sk8 = ((fixedmask >> 0) & 7) == 7, sk9 = ((fixedmask >> 3) & 7) == 7;   // (a stance foot's block is skipped by the factorisation: nothing is published)
-        // The gradient column (row 45 of M) is not a tile row: z_g = lq + Ws d would need a 16-term combination per block in three tiles.  The wave of tile (2, 2)
-        // carries it as v = W^T z_g, a pair of pivot blocks at a time: the six entries of z_g of the pair by eight lanes each (two of the sixteen terms per lane,
-        // summed by DPP), handed to all lanes through LDS; then lane <-> published row (0..14 Ws, 15 lq, 16..45 the identity rows) takes v += x . z_g.  At the end
-        // M[45][j] -= sum_a w_a(j) v[r_a(j)], the same sparse combination as a row of Z^T.  (Rounds 1-3: a 16-lane DPP sum of three components per BLOCK, 22
-        // instructions each: that wave finished 2 k cycles after the other five.  A batch form on wave 4 was measured too -- the factorising wave's SIMD mate is
-        // starved of issue slots: its descriptors alone take 6 k cycles of a 7 k stage.)
+        // The gradient column (row 45 of M) on the wave of tile (2, 2): v = W^T z_g a pair of pivot blocks at a time -- see the plan (ri[5..13]) --, and at the end
+        // M[45][j] -= sum_a w_a(j) v[r_a(j)], the same sparse combination as a row of Z^T.
         const bool grole = wv == 5;
-        const int ge = ln >> 3, gt = ln & 7;                       // entry of the pair (0..5 used), term
-        const int gcomp = ge % 3, gblk = ge < 3 ? 0 : 1;           // its component and block within the pair
-        const float* gsrc = Wb + (NPAN * gblk + gt) * 4 + gcomp;   // terms gt (Ws row gt) and gt + 8 (Ws row gt + 8; the lq row for gt = 7)
-        const int grow2 = gt == 7 ? NPAN - 1 : gt + 8;
-        const float gw0 = grole ? c.d[NS * kb + gt] : 0.f, gw1 = grole ? (gt == 7 ? 1.f : c.d[NS * kb + (gt == 7 ? 0 : gt + 8)]) : 0.f;
-        const int grow = ln < NS ? ln : (ln == NS ? NPAN - 1 : (ln < NPAN ? ln - 1 : 0));
-        float* zbuf = c.ybuf;                 // (the sweeps' 16-byte aligned staging buffer, 96 floats, idle during the backward pass): z_g of the pair, [block][4]
+        float* zbuf = c.ybuf;                 // (the sweeps' 16-byte aligned staging buffer, idle during the backward pass): z_g of the pair [block][4], then v from float 16 on
         float vacc = 0.f;
-        struct GradLoads { float4 xa, xb; float g0, g1; };
-        auto gradient_loads = [&](int b) {
+        float gw0 = 0.f, gw1 = 0.f, gz0 = 0.f, gz1 = 0.f, gz2 = 0.f;
+        double gbase = 0.0;
+        if (grole) {
+            gw0 = c.d[NS * kb + pl.ri[7]];
+            gw1 = pl.rf[0] != 0.f ? 1.f : c.d[NS * kb + pl.ri[8]];
+            gz0 = Bval[pl.ri[12]]; gz1 = Bval[pl.ri[12] + 1]; gz2 = Bval[pl.ri[12] + 2];
+        }
+        auto gradient_pair = [&](int b, bool skip0, bool skip1) {
             const int o = NPAN * 4 * b;
-            GradLoads gl;
-            gl.xa = *reinterpret_cast<const float4*>(Wb + o + grow * 4);
-            gl.xb = *reinterpret_cast<const float4*>(Wb + o + (NPAN + grow) * 4);
-            gl.g0 = gsrc[o]; gl.g1 = gsrc[o + 4 * (grow2 - gt)];
-            return gl;
-        };
-        auto gradient_pair = [&](const GradLoads& gl, bool skip0, bool skip1) {
-            float z = oct_sum(gw0 * gl.g0 + gw1 * gl.g1);
-            if ((gblk == 0 && skip0) || (gblk == 1 && skip1)) z = 0.f;
-            if (gt == 0 && ge < 6) zbuf[4 * gblk + gcomp] = z;
+            const float4 xa = *reinterpret_cast<const float4*>(Wb + o + pl.ri[10]);
+            const float4 xb = *reinterpret_cast<const float4*>(Wb + o + NPAN * 4 + pl.ri[10]);
+            float z = oct_sum(gw0 * Wb[o + pl.ri[5]] + gw1 * Wb[o + pl.ri[6]]);
+            if ((skip0 && pl.rf[1] == 0.f) || (skip1 && pl.rf[1] != 0.f)) z = 0.f;
+            zbuf[pl.ri[9]] = z;
             wave_lds_sync();
             const float4 z0 = *reinterpret_cast<const float4*>(zbuf), z1 = *reinterpret_cast<const float4*>(zbuf + 4);
-            if (!skip0) vacc += gl.xa.x * z0.x + gl.xa.y * z0.y + gl.xa.z * z0.z;
-            if (!skip1) vacc += gl.xb.x * z1.x + gl.xb.y * z1.y + gl.xb.z * z1.z;
+            if (!skip0) vacc += xa.x * z0.x + xa.y * z0.y + xa.z * z0.z;
+            if (!skip1) vacc += xb.x * z1.x + xb.y * z1.y + xb.z * z1.z;
             wave_lds_sync();
         };
-        // the last step of the gradient role -- M[45][j] -= sum_a w_a(j) v[r_a(j)] -- has its operands fetched here, not behind the last block
-        ZRow zj = ZRow{0, 0, 0, 0, 0.f, 0.f, 0.f, 0.f};
-        if (grole) zj = zrow_load(c, prm, ln < NU + NS ? ln : NU + NS, rowsG);
-        double gbase = 0.0;
+        float bs0 = 0.f, bs1 = 0.f, bs2 = 0.f, bs3 = 0.f;
         CPROF(2);
         // blocks 0..7 (the forces: never skipped) in pairs: the loads of both in flight, two chained MFMAs
 #pragma unroll
@@ -1939,14 +1954,13 @@ __device__ inline void sq_consume_body(Ctx c, const CmpcConsts& prm, int tid, in
             operands(b + 1, a1, b1);
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc, 0, 0, 0);
-            if (grole) gradient_pair(gradient_loads(b), false, false);   // (its loads behind the tile's: fetched together with the operand rows they cost 1.5 %)
+            if (grole) gradient_pair(b, false, false);   // (its loads behind the tile's: fetched together with the operand rows they cost 1.5 %)
             if (b == 0) {
                 // every consumer wave's part of the assembly must be in LDS before the tiles are subtracted from it (long there by now); then what the tile is
                 // subtracted from is fetched -- far ahead of the last blocks, off the tail of the stage
                 gaveup = !lds_wait_ge(c.flag + 3, SQ_TILE_WAVES * (ord + 1)) || gaveup;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) bs[i] = *dst[i];
-                if (grole && ln < NU + NS) gbase = ln < NU ? c.pv[ln] : qsn[ln - NU];
+                bs0 = Mn[pl.d0]; bs1 = Mn[pl.d1]; bs2 = Mn[pl.d2]; bs3 = Mn[pl.d3];
+                if (grole) gbase = pl.rf[3] != 0.f ? c.pv[ln < NU ? ln : 0] : qsn[ln >= NU && ln < NU + NS ? ln - NU : 0];
             }
         }
         CPROF(3);
@@ -1965,63 +1979,46 @@ __device__ inline void sq_consume_body(Ctx c, const CmpcConsts& prm, int tid, in
             operands(b, a0, b0);
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc, 0, 0, 0);
         }
-        if (grole && !(sk8 && sk9)) gradient_pair(gradient_loads(8), sk8, sk9);
+        if (grole && !(sk8 && sk9)) gradient_pair(8, sk8, sk9);
         CPROF2(4);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            if (ok[i]) {
-                const float r = bs[i] - acc[i];
-                *dst[i] = r;
-                *dst2[i] = r;
-            }
+        {
+            const float r0 = bs0 - acc[0], r1 = bs1 - acc[1], r2 = bs2 - acc[2], r3 = bs3 - acc[3];
+            Mn[pl.d0] = r0; Mn[pl.d1] = r1; Mn[pl.d2] = r2; Mn[pl.d3] = r3;
+            if (wv == 2 || wv >= 4) { Mn[pl.e0] = r0; Mn[pl.e1] = r1; Mn[pl.e2] = r2; Mn[pl.e3] = r3; }   // (tiles with entries of Qss: both triangles)
         }
         if (grole) {
-            float* vb = c.ybuf + 16;               // (46 floats of the same buffer)
-            if (ln < NPAN) vb[grow] = vacc;
+            zbuf[pl.ri[13]] = vacc;
             wave_lds_sync();
-            if (ln < NU + NS) {
-                const float val = zj.w0 * vb[zj.r0] + zj.w1 * vb[zj.r1] + zj.w2 * vb[zj.r2] + zj.w3 * vb[zj.r3];
-                if (ln < NU) Pann[(NPAN - 1) * RLD + ln] = (float)(gbase - (double)val);
-                else qsn[ln - NU] = gbase - (double)val;
-            }
+            const float* vb = zbuf + 16;
+            const unsigned rw = (unsigned)pl.ri[11];
+            const float val = gz0 * vb[rw & 255u] + gz1 * vb[(rw >> 8) & 255u] + gz2 * vb[(rw >> 16) & 255u] + pl.rf[2] * vb[rw >> 24];
+            const double res = gbase - (double)val;
+            if (ln < NU) Pann[(NPAN - 1) * RLD + ln] = (float)res;
+            else if (ln < NU + NS) qsn[ln - NU] = res;
         }
         CPROF(4);
     }
     if (gaveup && ln == 0) sq_give_up(c);
 }
-// The consumers' side of a backward pass (waves 1..7), one call: the assembly of stage N-1 from the terminal cost, then a stage per barrier.
+// The consumers' side of a backward pass (waves 1..7), one call: the plan, the assembly of stage N-1 from the terminal cost, then a stage per barrier.
 template <int NT, int NC, bool FG>
 __device__ __attribute__((noinline)) void sq_consume_loop(lds_t lds, int Nrt, float* fg_base, int k0_in, bool exact_in, float reg, float cmu)
 {
     CMPC_PHASE_PROLOGUE;
     const int k0 = __builtin_amdgcn_readfirstlane(k0_in);
     const bool use_exact = __builtin_amdgcn_readfirstlane((int)exact_in) != 0;
-    // what does not change from stage to stage: the thread's triple and the published rows of its tile operands (descriptor ROWS are the same in both sets)
-    Triple tr;
-    unsigned rowsA, rowsB, rowsG;
-    {
-        const int w7 = tid >> 6, ln = tid & 63, m4 = ln & 15;
-        const int wv = w7 < 4 ? w7 - 1 : w7 - 2;
-        tr = triple_decode(w7 == 4 ? 360 : 64 * wv + ln);
-        const int I = wv >= 3 ? 2 : (wv >= 1 ? 1 : 0), J = wv - I * (I + 1) / 2;
-        rowsA = zrow_rows(c, 16 * I + m4); rowsB = zrow_rows(c, 16 * J + m4);
-        rowsG = zrow_rows(c, ln);            // (gradient role: the wave of tile (2, 2))
-    }
-    sq_consume_body(c, prm, tid, N, N, N - 1, -1, 0, false, use_exact, reg, cmu, tr, rowsA, rowsB, rowsG);
+    ConsPlan pl;
+    cons_plan_build(pl, c, prm, tid >> 6, tid & 63, c.Brow + ((N - 1) & 1) * DSET_I);   // (the rows of set (N-1) & 1: built by sq_init whatever k0 is)
+    if ((N - 1) & 1) sq_consume_stage<1>(c, prm, pl, tid, N, N, N - 1, -1, 0, false, use_exact, reg, cmu);
+    else sq_consume_stage<0>(c, prm, pl, tid, N, N, N - 1, -1, 0, false, use_exact, reg, cmu);
     __syncthreads();
     int ord = 0;
 #pragma unroll 1
     SQ_STAGE_LOOP(k, N, k0) {                          // (sq_pass_barriers: one barrier per trip, no early exit)
         ++ord;
         if (k > k0) {
-            // (the LDS map is rebuilt from an opaque copy of the base every stage -- constant offsets, a handful of adds -- instead of living in ~60 registers across the loop:
-            //  held live it pushed the function into the callee-saved registers, 33 of them saved to scratch per lane and pass: 56 MB of scratch writes per B = 256 launch)
-            lds_t lk = lds;
-            asm volatile("" : "+v"(lk));
-            char* smk = (char*)lk;
-            Ctx ck;
-            make_ctx<FG>(ck, smk, N, fg_base);
-            sq_consume_body(ck, *reinterpret_cast<const CmpcConsts*>(smk), tid, N, k, k - 1, k - 2 >= k0 ? k - 2 : -1, ord, true, use_exact, reg, cmu, tr, rowsA, rowsB, rowsG);
+            if ((k - 1) & 1) sq_consume_stage<1>(c, prm, pl, tid, N, k, k - 1, k - 2 >= k0 ? k - 2 : -1, ord, true, use_exact, reg, cmu);
+            else sq_consume_stage<0>(c, prm, pl, tid, N, k, k - 1, k - 2 >= k0 ? k - 2 : -1, ord, true, use_exact, reg, cmu);
         }
         __syncthreads();
     }
@@ -2034,7 +2031,7 @@ __device__ __attribute__((noinline)) void sq_init(lds_t lds, int Nrt, float* fg_
     const int k0 = __builtin_amdgcn_readfirstlane(k0_in);
     const bool use_exact = __builtin_amdgcn_readfirstlane((int)exact_in) != 0;
     {
-        float* QN = c.Qb + (N & 1) * NS * 16;
+        float* QN = c.Qb + (N & 1) * MSET;
         double* qN = (N & 1) ? c.qs1 : c.qs;
         if (tid < NS * 16) QN[tid] = (tid >> 4) == (tid & 15) ? qdiag(prm, N, tid & 15) : 0.f;
         else if (tid >= 256 && tid < 256 + NS) qN[tid - 256] = grad_track(c, prm, N, tid - 256);
@@ -3075,7 +3072,7 @@ extern "C" size_t cmpc_solver_lds_bytes(int N, int factors_global)
     CmpcLayout L;
     cmpc_layout_init(L, N);
     const size_t dbl = 90 + 40 + 40 + 16 + 40 + 4 * NI + 8 + (factors_global ? 0 : 90 + 16);
-    const size_t work = factors_global ? ((NXA * PLD + 3) & ~3) + NS * 16 + ((NXA * GLD + 3) & ~3) : (size_t)MSET + SQ_PUB_FLOATS + 2 * NS * 16 + 128;   // (see make_ctx)
+    const size_t work = factors_global ? ((NXA * PLD + 3) & ~3) + NS * 16 + ((NXA * GLD + 3) & ~3) : (size_t)MSET + NS * 16 + SQ_PUB_FLOATS + 128;   // (see make_ctx)
     const size_t flt = (size_t)NU * RLD + (size_t)NPAN * RLD + 96 + ((L.np + 3) & ~3)
                        + ((size_t)NS * (N + 1) + (size_t)NU * N + ((factors_global && N > CMPC_TZ_LDS_NMAX) ? 0 : 2 * (size_t)NI * N)) + (size_t)NS * N + (size_t)NS * (N + 1)
                        + (size_t)GEO * N + work + 2 * DSET_F + 40 + 40 + 24
