@@ -71,6 +71,11 @@
 #define ZLD 36     // leading dim of Z^T (48 rows: 30 u-columns, 15 s-columns, the gradient column, 2 zero rows)
 #define MSET (NU * RLD + NPAN * RLD + NS * 16)   // floats of one set QuuF | Pan | Qb (the resident variants hold two: stage k is factorised from set k & 1)
 #define NTRI 256   // entries of the lower-triangle index table (the users need 210: 2x2 tiles of a 39x39)
+// Rows of the 30 x 30 identity as 16-byte aligned 32-float windows of four constant strips: strip s = 68 floats with a 1 at position 32 + s; row m of the identity
+// (32 floats) is strip m % 4 from float 32 + m % 4 - m on.  The factorisation's identity panel rows are LOADED like every other row (8 x ds_read_b128) instead of
+// being built entry by entry: 120 instructions of the critical wave per stage.
+#define ID_STRIP_LEN 68
+#define ID_STRIPS (4 * ID_STRIP_LEN)
 // Per-stage factor record (floats), in LDS or -- FG kernels -- in HBM scratch.  Phase 3 leaves column m of
 // L^{-1} and column j of Ws = L^{-1} Qus in the registers of one lane, so both are stored transposed, one
 // 16-byte-aligned row per lane:
@@ -160,6 +165,7 @@ struct Ctx {
     float *Lf;             // per-stage factor records (REC_N floats each)
     float *geoA;           // N x GEO
     float *P0, *Qb, *G, *QuuF, *Pan, *Bval, *Aval, *arow, *ybuf, *fpv, *fpn;
+    float *idstrip;        // four strips of 68 floats, a single 1 in each: rows of the identity for the fused factorisation's panel (id_row)
     float *ZT;             // (resident variants) the published W^T of the streaming stage; there QuuF | Pan | Qb exist twice (stride MSET)
     double *QuuD1, *qs1;   // (resident variants) second set of the float64 diagonal blocks and of qs
     int *Brow, *Arow, *qmask;
@@ -266,6 +272,7 @@ __device__ inline void make_ctx(Ctx& c, char* smem, int N, float* fg_base)
         c.dS = vp; vp += NS * (N + 1); c.dU = vp; vp += NU * N; c.dT = vp; vp += NI * N; c.dZ = vp;
     }
     c.ybuf = fp; fp += 96;          // 16-byte aligned vector staging of the sweeps
+    c.idstrip = fp; fp += ID_STRIPS;
     if (!FG) { c.Lf = fp; fp += (size_t)REC_N * N; } else c.Lf = fg_base;
     c.sp = fp; fp += (c.L.np() + 3) & ~3;
     c.S = fp; fp += NS * (N + 1); c.U = fp; fp += NU * N;
@@ -697,6 +704,8 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 #define LATE_B 6
 #define LATE_M0 18
 #define NLATE (NU - LATE_M0)
+// where row m of the identity starts in the strips (float offset, a multiple of 4)
+__device__ inline int id_row(int m) { return ID_STRIP_LEN * (m & 3) + 32 + (m & 3) - m; }
 // rank-1 update of the column groups G0 .. 7 (av: -x of the L rows below the pivot block, 0 elsewhere; bv: the lane's own x)
 template <int G0>
 __device__ __forceinline__ void trail_rank1(v4f (&acc)[8], float av, float bv)
@@ -707,7 +716,7 @@ __device__ __forceinline__ void trail_rank1(v4f (&acc)[8], float av, float bv)
 }
 // PUB (streaming square-root stage): after every pivot block the finished entries x0..x2 of this lane's panel row go to pub[(46 b + prow) * 4 ..]
 // and the wave's progress word *pflag is set to seq0 + b + 1.  LDS operations of one wave execute in issue order: whoever sees the flag sees the data.
-struct CholPub { float* pub; int stride; int* pflag; int seq0; float* publate; };
+struct CholPub { float* pub; int stride; int* pflag; int seq0; float* publate; const float* idstrip; };
 // Where a lane's finished row goes: one row per lane, 16-byte stores -- the record row for the sweeps and (HBM-factor variants) the panel row for phase 4.
 // The four columns of chunk Q are final as soon as the pivot block holding the last of them is done, so the stores are issued from inside the block loop and
 // drain under the remaining blocks (round 4: behind the last block they were 1.3 k cycles of the critical wave's stage); chunks 6, 7 follow the loop.
@@ -721,16 +730,16 @@ struct RowStore {
     unsigned rrow;
     int I, sw;
     bool on;
-    float D0, D1, D2;
+    const float* Dp;    // the force-rate weights D[3] (in LDS: an indexed load -- three members and a select chain were turned into an indexed private array, i.e. scratch memory)
     float* Pan;
-    __device__ __forceinline__ RowStore(const RecRef<G>& r, float* Pan_, float d0, float d1, float d2) : rec(r), prow_p(Pan_), sc(1.f), rrow(0), I(0), sw(0), on(false), D0(d0), D1(d1), D2(d2), Pan(Pan_) {}
+    __device__ __forceinline__ RowStore(const RecRef<G>& r, float* Pan_, const float* Dp_) : rec(r), prow_p(Pan_), sc(1.f), rrow(0), I(0), sw(0), on(false), Dp(Dp_), Pan(Pan_) {}
     // this lane stores panel row srow (Qus^T rows 0..14, identity rows NS..NS+29 = columns of L^{-1}, the lq row NPAN-1)
     __device__ __forceinline__ void set_row(int srow)
     {
         const int m = srow - NS;                       // identity rows: column m of L^{-1}
         const bool isId = srow >= NS && srow < NS + NU;
         sc = 1.f;
-        if (isId) sc = m < NF ? -((m % 3 == 0) ? D0 : ((m % 3 == 1) ? D1 : D2)) : 0.f;
+        if (!PUB && isId) sc = m < NF ? -Dp[m % 3] : 0.f;
         const int jw = srow < NS ? srow : 15;          // Ws column j, or the lq row
         I = isId ? (m >> 2) : 0;
         prow_p = Pan + srow * RLD;
@@ -757,9 +766,12 @@ __device__ __forceinline__ bool chol_block(v4f (&acc)[8], double (&dd)[3], int l
     constexpr int j0 = 3 * B;
     if (ONE && B == LATE_B) {
         if (lane < NLATE) {
-            const unsigned hot = 1u << (LATE_M0 + lane);   // (bit-field extract + convert: two instructions per entry, no
-#pragma unroll                                              //  compare -> mask hazard slots)
-            for (int cc = 0; cc < NU; ++cc) VE(cc) = (float)((hot >> cc) & 1u);
+            const float* idr = pb.idstrip + id_row(LATE_M0 + lane);
+#pragma unroll
+            for (int q4 = 0; q4 < 8; ++q4) {
+                const float4 t4 = *reinterpret_cast<const float4*>(idr + 4 * q4);
+                acc[q4] = v4f{t4.x, t4.y, t4.z, t4.w};
+            }
             if (PUB) { pb.pub = pb.publate; pb.stride = NPAN * 4; }   // (the identity row this lane now holds: its entries of the earlier blocks are zeros, kept zero in the buffer)
             if constexpr (ST::EARLY) st.set_row(NS + LATE_M0 + lane);   // (its chunks 0..3, left of the diagonal block, were never stored: they belong to the discarded row anyway)
         }
@@ -791,7 +803,9 @@ __device__ __forceinline__ bool chol_block(v4f (&acc)[8], double (&dd)[3], int l
     const float r00 = __builtin_amdgcn_rsqf(p0f), r11 = __builtin_amdgcn_rsqf(p1f), r22 = __builtin_amdgcn_rsqf(p2f);
     const float l10 = (float)d10 * r00, l20 = (float)d20 * r00, l21 = (float)t21 * r11;
     // a non-positive pivot: v_rsq_f32 of a negative number is NaN, of zero inf; p1 and p2 inherit a bad d00 through i00
-    const bool bad = !(p0f > 0.f) || !(p1f > 0.f) || !(p2f > 0.f);
+    // -- which then is NaN in every x of the block, in every trailing column and in every later pivot: tested where the factorisation ends (blocks 7..9; a stance
+    // foot's blocks 8, 9 are skipped), not ten times
+    const bool bad = B >= 7 && (!(p0f > 0.f) || !(p1f > 0.f) || !(p2f > 0.f));
     // rows below the block and panel rows: x = v[j0..j0+2] L_bb^{-T}
     const float x0 = VE(j0) * r00;
     const float x1 = (VE(j0 + 1) - x0 * l10) * r11;
@@ -808,6 +822,7 @@ __device__ __forceinline__ bool chol_block(v4f (&acc)[8], double (&dd)[3], int l
         // word cannot become visible before the data written just before it; the readers load it with acquire order (lds_peek).
         asm volatile("" ::: "memory");
         __hip_atomic_store(pb.pflag, pb.seq0 + B + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __builtin_amdgcn_sched_barrier(0);   // (left alone the scheduler sinks the two stores behind two thirds of the block's matrix-pipe instructions: 100+ cycles later for every reader)
     }
     // rank-3 update of the trailing columns j0 + 3 .. 29 on the matrix pipe (see above): multipliers from the lanes of the L rows below the block.
     // Pivot-column-major over the groups: the three updates of one group are a dependent chain (20 cycles apart alone, 8 when interleaved).
@@ -834,10 +849,10 @@ __device__ __forceinline__ bool chol_block(v4f (&acc)[8], double (&dd)[3], int l
 }
 // ---- fused Cholesky + panel solve, one wave, rows in registers, 3x3 pivot blocks (see the comment block above rcp_d) ----
 template <bool ONE, bool PUB, typename ST>
-__device__ __forceinline__ bool chol_solve_fused(v4f (&acc)[8], double (&dd)[3], int lane, int fixedmask, ST& st, float* pub = nullptr,
+__device__ __forceinline__ bool chol_solve_fused(v4f (&acc)[8], double (&dd)[3], int lane, int fixedmask, ST& st, const float* idstrip, float* pub = nullptr,
                                                  int pubstride = 0, int* pflag = nullptr, int seq0 = 0, float* publate = nullptr)
 {
-    CholPub pb{pub, pubstride, pflag, seq0, publate};
+    CholPub pb{pub, pubstride, pflag, seq0, publate, idstrip};
     bool bad = false;
     bad |= chol_block<0, ONE, PUB>(acc, dd, lane, fixedmask, pb, st);
     bad |= chol_block<1, ONE, PUB>(acc, dd, lane, fixedmask, pb, st);
@@ -859,8 +874,8 @@ __device__ __forceinline__ bool chol_solve_fused(v4f (&acc)[8], double (&dd)[3],
 // phase 3 of a backward stage, kept out of line so that its ~40 VGPRs of matrix rows and its
 // stream of v_readlane broadcasts get a register allocation of their own
 template <bool ONE, bool G, bool PUB = false>
-__device__ __forceinline__ void stage_factor(const float* QuuF, const double* QuuD, float* Pan, const RecRef<G>& rec,
-                                          float D0, float D1, float D2, int* flag, int tid, int fixedmask, float* pub = nullptr, int* pflag = nullptr, int seq0 = 0)
+__device__ __forceinline__ void stage_factor(const float* QuuF, const double* QuuD, float* Pan, const RecRef<G>& rec, const float* idstrip,
+                                          const float* Dp, int* flag, int tid, int fixedmask, float* pub = nullptr, int* pflag = nullptr, int seq0 = 0)
 {
     const int lane = tid & 63, wv = tid >> 6;
     // panel row of lanes >= 30.  Two waves: rows 0..33 on wave 0, 34..45 on wave 1 (both repeat the L rows).  One wave: Qus rows
@@ -874,16 +889,11 @@ __device__ __forceinline__ void stage_factor(const float* QuuF, const double* Qu
     PROF2_DECL;
     const bool idrow = !isL && prow >= NS && prow < NS + NU;
     {
-        const float* src = isL ? QuuF + lane * RLD : Pan + ((active && !idrow) ? prow : 0) * RLD;
+        const float* src = isL ? QuuF + lane * RLD : (idrow ? idstrip + id_row(prow - NS) : Pan + (active ? prow : 0) * RLD);
 #pragma unroll
         for (int q4 = 0; q4 < 8; ++q4) {
             const float4 t4 = *reinterpret_cast<const float4*>(src + 4 * q4);
             acc[q4] = v4f{t4.x, t4.y, t4.z, t4.w};
-        }
-        if (idrow) {
-            const unsigned hot = 1u << (prow - NS);
-#pragma unroll
-            for (int cc = 0; cc < NU; ++cc) VE(cc) = (float)((hot >> cc) & 1u);
         }
         if (isL) {
             dd[0] = QuuD[9 * (lane / 3) + 3 * (lane % 3) + 0];
@@ -896,10 +906,10 @@ __device__ __forceinline__ void stage_factor(const float* QuuF, const double* Qu
     // their own behind the ten blocks (block stride 0)
     float* pubp = pub;
     if (PUB) pubp = (!isL && active) ? pub + prow * 4 : pub + (10 * NPAN + 64 * wv + lane) * 4;
-    RowStore<G, PUB> st(rec, Pan, D0, D1, D2);
+    RowStore<G, PUB> st(rec, Pan, Dp);
     typedef RowStore<G, PUB> ST;
     if (ST::EARLY && !isL && active) st.set_row(prow);
-    const bool bad = chol_solve_fused<ONE, PUB>(acc, dd, lane, fixedmask, st, pubp, (!isL && active) ? NPAN * 4 : 0, pflag, seq0,
+    const bool bad = chol_solve_fused<ONE, PUB>(acc, dd, lane, fixedmask, st, idstrip, pubp, (!isL && active) ? NPAN * 4 : 0, pflag, seq0,
                                                 PUB ? pub + (NS + LATE_M0 + (lane < NLATE ? lane : 0)) * 4 : nullptr);
     PROF2(29);
     if (bad && tid == 0) *flag = 1;
@@ -1461,7 +1471,7 @@ __device__ __attribute__((noinline)) void stage_mid(lds_t lds, int Nrt, float* f
     PROF_DECL;
     if (tid < (CMPC_ONE_WAVE_FACTOR(FG) ? 64 : 128)) {
         const int fixedmask = (~c.qmask[k]) & 63;
-        stage_factor<CMPC_ONE_WAVE_FACTOR(FG), FG>(c.QuuF, c.QuuD, c.Pan, RecRef<FG>(c.Lf, N, k), prm.D[0], prm.D[1], prm.D[2], c.flag, tid, fixedmask);
+        stage_factor<CMPC_ONE_WAVE_FACTOR(FG), FG>(c.QuuF, c.QuuD, c.Pan, RecRef<FG>(c.Lf, N, k), c.idstrip, prm.D, c.flag, tid, fixedmask);
     } else if (tid >= 128) {
         use_desc_set(c, k & 1);
         stage_qss_body<NT>(c, prm, tid, k, c.P0, c.Qb, tqp);
@@ -1555,7 +1565,7 @@ __device__ __attribute__((noinline)) void sq_factor_loop(lds_t lds, int Nrt, flo
         const int fixedmask = (~c.qmask[k]) & 63;
         SQPROF_DECL;
         // (one wave: its second SIMD's worth of issue slots goes to the consumers -- the eight-wave shape is bound by what waves 1-7 can issue under the factorisation)
-        stage_factor<true, FG, true>(c.QuuF + s * MSET, s ? c.QuuD1 : c.QuuD, c.Pan + s * MSET, RecRef<FG>(c.Lf, N, k), prm.D[0], prm.D[1], prm.D[2], c.flag, tid,
+        stage_factor<true, FG, true>(c.QuuF + s * MSET, s ? c.QuuD1 : c.QuuD, c.Pan + s * MSET, RecRef<FG>(c.Lf, N, k), c.idstrip, prm.D, c.flag, tid,
                                      fixedmask, c.ZT, c.prog + tid, 16 * ord);
         SQPROF(9);         // (wave 0: the factorisation alone)
         __syncthreads();
@@ -2691,6 +2701,7 @@ __device__ __attribute__((noinline)) void phase_setup(lds_t lds, int Nrt, float*
         while (i * (i + 1) / 2 > e) --i;
         c.tri[e] = (unsigned short)((i << 8) | (e - i * (i + 1) / 2));
     }
+    for (int e = tid; e < ID_STRIPS; e += NT) c.idstrip[e] = (e % ID_STRIP_LEN) == 32 + e / ID_STRIP_LEN ? 1.f : 0.f;
     // (zero blocks of the factor records: LDS was zeroed by the kernel; HBM scratch is zeroed once, at cmpc_create)
     for (int e = tid; e < c.L.np(); e += NT) spw[e] = gp[e];
     __syncthreads();
@@ -3073,7 +3084,7 @@ extern "C" size_t cmpc_solver_lds_bytes(int N, int factors_global)
     cmpc_layout_init(L, N);
     const size_t dbl = 90 + 40 + 40 + 16 + 40 + 4 * NI + 8 + (factors_global ? 0 : 90 + 16);
     const size_t work = factors_global ? ((NXA * PLD + 3) & ~3) + NS * 16 + ((NXA * GLD + 3) & ~3) : (size_t)MSET + NS * 16 + SQ_PUB_FLOATS + 128;   // (see make_ctx)
-    const size_t flt = (size_t)NU * RLD + (size_t)NPAN * RLD + 96 + ((L.np + 3) & ~3)
+    const size_t flt = (size_t)NU * RLD + (size_t)NPAN * RLD + 96 + ID_STRIPS + ((L.np + 3) & ~3)
                        + ((size_t)NS * (N + 1) + (size_t)NU * N + ((factors_global && N > CMPC_TZ_LDS_NMAX) ? 0 : 2 * (size_t)NI * N)) + (size_t)NS * N + (size_t)NS * (N + 1)
                        + (size_t)GEO * N + work + 2 * DSET_F + 40 + 40 + 24
                        + 2 * DSET_I + 4 + CMPC_NMAX + NTRI / 2 + (factors_global ? 0 : (size_t)REC_N * N);
