@@ -35,7 +35,7 @@ sys.path.insert(0, ROOT)
 
 # canonical algorithmic work: F_iter(N) = 4.25e5 * N flop per interior-point iteration
 F_ITER_PER_STAGE = 4.25e5
-PEAK_F32_TFLOPS = 157.3  # MI355X_MICROARCH.md: f32 vector peak = f32-input MFMA peak (phase 4 of the resident variants runs on v_mfma_f32_16x16x4_f32, the rest on the VALU)
+PEAK_F32_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense f32-input MFMA peak = f32 vector peak
 CONFIG4_TOTAL = 65536
 
 
@@ -211,7 +211,8 @@ class Runner:
             self.barrier()
             ag_ms = self.max_over_ranks((time.perf_counter() - t1) / 10 * 1e3)
         iters = info[:, 0]
-        per_rank = self.gather_floats([float(kern_ms.mean()), float(iters.sum()), float(iters.max()), float((info[:, 5] == 0).sum()), float(B)])
+        giveups = float(np.floor(info[:, 3] / 1e6).sum())    # info[3] carries 1e6 per give-up at a hand-off word of the streaming stage (include/cmpc.h)
+        per_rank = self.gather_floats([float(kern_ms.mean()), float(iters.sum()), float(iters.max()), float((info[:, 5] == 0).sum()), float(B), giveups])
         pr = np.array(per_rank)
         total_B = int(pr[:, 4].sum())
         flop_per_launch = float(iters.sum()) * F_ITER_PER_STAGE * cfg.N     # this rank's launch
@@ -223,8 +224,9 @@ class Runner:
             "batch_per_gpu": B, "batch_total": total_B, "horizon": cfg.N,
             "iterations_mean": round(float(pr[:, 1].sum() / total_B), 2), "iterations_max": int(pr[:, 2].max()),
             "converged_fraction": round(float(pr[:, 3].sum() / total_B), 6),
+            "sync_giveups": int(pr[:, 5].sum()),
             "kernel_ms_per_rank": [round(v, 4) for v in pr[:, 0].tolist()],
-            "roofline": {"bound": "valu_f32", "achieved": round(achieved, 4), "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
+            "roofline": {"bound": "mfma", "achieved": round(achieved, 4), "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_F32_TFLOPS, 5), "traffic": None,
                          "kernel": "cmpc_solve_kernel", "kernel_ms_avg": round(float(kern_ms.mean()), 4),
                          "algorithmic_flop_per_launch": flop_per_launch,
@@ -283,6 +285,11 @@ class Runner:
         rec = ro.run(ticks, com0, dcom0, h0, push=push, push_ticks=3, record="light")
         self.barrier()
         elapsed = self.max_over_ranks(time.perf_counter() - t0)
+        if "aborted_tick" in rec:
+            ro.solver.close()
+            return {"workload": f"warm-started receding-horizon walking roll-out: batch={B}/GPU x {ticks} ticks", "failed": True,
+                    "aborted_tick": int(rec["aborted_tick"]), "why": "the merge of the planner's and the MPC's contact lists failed (updateContactPhaseList returned false): "
+                                                                      "the reference aborts the tick there, CentroidalMPCBlock.cpp:603-607"}
         ms = np.array(rec["tick_ms"])
         pr = np.array(self.gather_floats([float(np.sum(rec["unconverged"])), float(np.max(rec["iterations_max"])), float(np.mean(rec["iterations_mean"])),
                                           float(ms.max()), float(np.median(ms)), float(np.percentile(ms, 99))]))
@@ -402,14 +409,23 @@ def main():
                 # HBM GB/s (tiny: the state lives in LDS) and VALU busy, from the same committed counter passes
                 m["roofline"]["hbm_GBps"] = round(traffic / (m["roofline"]["kernel_ms_avg"] * 1e-3) / 1e9, 2)
                 m["roofline"]["valu_active_over_wave_cycles"] = round(pmj["derived"]["valu_active_over_wave_cycles"], 3)
+            # north_star's "MFMA%" and the share of wave-cycles spent parked, from the committed wait-attribution passes of the same command
+            pw = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_wait_config2.json")))
+            if pw and args.workload == "config2" and m["batch_per_gpu"] == 256:
+                pwj = json.load(open(pw[-1]))["derived"]
+                m["roofline"]["mfma_busy_frac"] = round(pwj["mfma_pipe_quadcycles_over_wave_cycles"], 4)
+                m["roofline"]["mfma_share_of_valu_instructions"] = round(pwj["mfma_share_of_valu_instructions"], 4)
+                m["roofline"]["wait_any_frac"] = round(pwj["wait_any_share"], 3)
+                m["roofline"]["counters_source"] = f"{os.path.relpath(pw[-1], ROOT)} (committed rocprofv3 --pmc passes of this command; not measured in this run)"
         except Exception:
             traffic = None
         m["roofline"]["traffic"] = traffic
         m["roofline"]["traffic_source"] = (f"{tsrc} (rocprofv3 --pmc passes of this command, committed; not measured in this run)"
                                            if tsrc else None)
-        m["roofline"]["note"] = ("bound = f32 VALU issue (f32-input MFMA -- used for the stage's Schur-complement product Z^T Z in the resident variants -- peaks at the "
-                                 "vector rate, 157.3 TFLOP/s); flop = executed IP iterations x 4.25e5*N (SURVEY 8d canonical "
-                                 "count); HBM traffic is ~11 KB/solve")
+        m["roofline"]["note"] = ("peak = dense f32-input MFMA = f32 vector rate, 157.3 TFLOP/s (MI355X_MICROARCH.md); the matrix pipe carries the trailing updates of the fused "
+                                 "factorisation (v_mfma_f32_4x4x1, every variant) and the stage's Schur-complement product Z^T Z (v_mfma_f32_16x16x4, resident variants), the "
+                                 "rest is f32/f64 VALU; what binds in practice is instruction issue of single waves (4 cycles per instruction of any kind); flop = executed IP "
+                                 "iterations x 4.25e5*N (SURVEY 8d canonical count); HBM traffic is ~11 KB/solve")
         out = {
             "metric": "centroidal-MPC solves/sec (batch, horizon=20)",
             "value": m["value"], "unit": "solves/s",
@@ -422,6 +438,7 @@ def main():
             "p50_solve_latency_ms": round(float(np.median(data["kern_ms"])), 4),
             "iterations_mean": m["iterations_mean"], "iterations_max": m["iterations_max"],
             "converged_fraction": m["converged_fraction"],
+            "sync_giveups": m["sync_giveups"],
             "kernel_ms_per_rank": m["kernel_ms_per_rank"],
             "roofline": m["roofline"],
         }

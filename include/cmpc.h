@@ -56,11 +56,11 @@ typedef struct {
     double corners[2][4][3];  /* [CONTACT_i] corner_j, contacts in alphabetical name order        */
     /* solver options (ipopt_tolerance / ipopt_max_iteration take the place of IPOPT's) */
     int max_iterations;       /* Newton iteration budget per solve (default 40)                   */
-    double tolerance;         /* on the primal residuals and on max t*z (default 1e-6)                 */
+    double tolerance;         /* on the primal residuals and on max t*z (<= 0: default 1e-6 up to N = 20, 5e-7 beyond) */
     double step_tolerance;    /* on the last Newton step, max-norm over states and forces (default 1e-4) */
     double mu_init;           /* initial barrier parameter; <= 0 (default): per problem, from its
                                * initial infeasibility ep0: clamp(3.5 ep0^2, 0.03, 0.5)           */
-    double mu_min;            /* final barrier parameter (default 0.05 x tolerance = 5e-8)        */
+    double mu_min;            /* final barrier parameter (<= 0: default max(0.05 x tolerance, 5e-8): the float32 factorisations start to fail below) */
     int exact_hessian;        /* 1 (default): Lagrangian Hessian; 0: Gauss-Newton                 */
     int final_extrapolation;  /* 1 (default): a converged solve finishes with one affine-scaling Newton step towards
                                * mu = 0 (one more factorisation): removes the O(mu) bias of the barrier floor and
@@ -74,7 +74,15 @@ typedef struct {
     int tail_stages;
     int tail_iterations;
     double tail_trigger;
+    /* where the per-stage factor records of the Riccati recursion live: CMPC_FACTORS_AUTO (default) = in LDS, one problem per compute unit, eight waves
+     * (the latency variant) when the batch does not exceed the number of compute units and the horizon's image fits 160 KiB, else in HBM scratch with three
+     * problems per compute unit (the throughput variant); CMPC_FACTORS_LDS / _HBM force one (LDS only where it fits).  Both give the same solutions to
+     * the tolerance; tests use the switch to hold them together. */
+    int factor_storage;
 } cmpc_config;
+#define CMPC_FACTORS_AUTO 0
+#define CMPC_FACTORS_LDS 1
+#define CMPC_FACTORS_HBM 2
 
 /* number of floats per solve in the info array */
 #define CMPC_INFO 8
@@ -85,7 +93,9 @@ typedef struct {
  * kkt_error, mu and primal_inf are those of the last iterate whose residuals were evaluated: the iterate the
  * termination test accepted.  With final_extrapolation the returned x is one affine-scaling step beyond it.
  * safeguards = Gauss-Newton fallbacks + 100 x emergency re-centrings (warm starts) + 10000 x (1 if the warm-started pass
- * was abandoned and the problem solved again from the cold start) + 100000 x (1 if the tail was polished).
+ * was abandoned and the problem solved again from the cold start) + 100000 x (1 if the tail was polished)
+ * + 1000000 x (times a wave of the streaming backward stage gave up waiting at a hand-off word: never observed; a protocol bug would show HERE and not
+ * as a failed factorisation -- the pass is repeated once unchanged.  Tests, the soak tool and bench.py assert / report that this digit is zero).
  * iterations counts both passes of a restarted warm start: it can reach 2 x max_iterations. */
 
 void cmpc_default_config(cmpc_config* cfg);                      /* ergoCubGazeboV1 values, N=20 */
@@ -124,6 +134,9 @@ float cmpc_last_solve_ms(cmpc_handle h);
  * test can show that a solve does not depend on what an earlier workgroup or kernel left there.  No reference
  * counterpart. */
 int cmpc_test_poison_lds(cmpc_handle h);
+/* test hook (host only, no GPU): workgroup barriers one role of the streaming backward stage executes in a pass over stages N-1 .. k0 -- role 0 the
+ * factorising wave, 1 the consumers -- counted on the loop skeleton both device loops are written with.  Unequal counts would hang a workgroup. */
+int cmpc_sq_pass_barriers(int horizon, int k0, int role);
 
 /* ---- NLP callbacks (what IPOPT evaluated through the generated code), batched on the device ----
  * any output pointer may be NULL.  dLamG[B][n_g], lam_f scalar (hess of lam_f f + lam_g^T g).
@@ -158,6 +171,11 @@ int cmpc_set_initial_guess(cmpc_handle h, const float* x0, int shift_previous);
 /* solve the handle's own problem set (set_* above); synchronous */
 int cmpc_advance(cmpc_handle h);
 int cmpc_get_solution(cmpc_handle h, float* X, float* info);
+/* read-back of what the setters above have written: the handle's parameter set P[B][n_p] exactly as the next cmpc_advance will solve it
+ * (the reference's setState / setReferenceTrajectory / setContactPhaseList fill CasADi's parameter vector p the same way, CentroidalMPCBlock.cpp:407, :579,
+ * :609) -- host copy, or the handle's device buffer after uploading the staged values (valid until the next setter call / cmpc_advance). */
+int cmpc_get_parameters(cmpc_handle h, float* P);
+int cmpc_get_parameters_device(cmpc_handle h, const float** dP);
 /* compact output of getOutput(): per problem first-knot corner forces [2][4][3], contact
  * positions at knot 0 [2][3], next (adjusted) landing position per contact [2][3] and its knot
  * index [2] (-1 if the contact does not land inside the horizon) */
@@ -181,6 +199,11 @@ int cmpc_plant_step_device(cmpc_handle h, const float* dX, const float* dP, cons
  * dOut[B][3(N+1) + 38] = CoM trajectory 3(N+1) | first-knot corner forces 24 | knot-0 and knot-1 foot positions 12 |
  * iterations | status, from dX[B][n_x] and dInfo[B][8].  Device pointers; asynchronous on `stream` (NULL: the handle's). */
 int cmpc_compact_output_device(cmpc_handle h, const float* dX, const float* dInfo, float* dOut, void* stream);
+/* ... and the gather itself: ncclAllGather (RCCL, over xGMI) of every rank's B compact records, dLocal[B][3(N+1) + 38] -> dAll[world_size][B][...], on
+ * `stream` (NULL: the handle's).  nccl_comm is the caller's ncclComm_t (one rank per GPU and process, ncclCommInitRank; every rank's handle must have the
+ * same batch -- pad ragged shards).  librccl.so is opened on first use.  The Python harness does the same with torch.distributed (distributed.py); this entry
+ * point is what a C++ Monte-Carlo driver shaped after the reference's Main.cpp:98-134 calls (examples/montecarlo_allgather.cpp). */
+int cmpc_allgather_compact_device(cmpc_handle h, void* nccl_comm, int world_size, const float* dLocal, float* dAll, void* stream);
 
 /* ---- 8f-1: contact schedules, batched ----
  * What the reference does with BipedalLocomotion::Contacts::ContactPhaseList objects around the solve, for a batch.

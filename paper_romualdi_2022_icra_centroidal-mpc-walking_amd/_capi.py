@@ -33,7 +33,11 @@ class CmpcConfig(C.Structure):
         ("tail_stages", C.c_int),
         ("tail_iterations", C.c_int),
         ("tail_trigger", C.c_double),
+        ("factor_storage", C.c_int),
     ]
+
+
+FACTORS = {None: 0, "auto": 0, "lds": 1, "hbm": 2}   # cmpc_config.factor_storage
 
 
 EXPORTS = [
@@ -45,6 +49,7 @@ EXPORTS = [
     "cmpc_compact_output_device", "cmpc_contacts_merge", "cmpc_contacts_merge_device", "cmpc_contacts_sample",
     "cmpc_contacts_sample_device", "cmpc_set_contact_lists", "cmpc_contacts_adjust", "cmpc_contacts_adjust_device",
     "cmpc_write_state_device", "cmpc_shift_solution_device", "cmpc_eval_nlp_grad_device", "cmpc_solve_device_warm", "cmpc_set_warm_policy",
+    "cmpc_get_parameters", "cmpc_get_parameters_device", "cmpc_allgather_compact_device", "cmpc_sq_pass_barriers",
 ]
 
 _lib = None
@@ -107,5 +112,10 @@ def lib():
         L.cmpc_write_state_device.argtypes = [vp, fp, fp, fp, vp]
         L.cmpc_shift_solution_device.argtypes = [vp, fp, fp, vp]
         L.cmpc_eval_nlp_grad_device.argtypes = [vp, fp, fp, fp, C.c_float, fp, fp, vp]
+        if hasattr(L, "cmpc_get_parameters"):   # (absent from earlier rounds' builds of the library, which tools/ab_multi.sh may load as a baseline)
+            L.cmpc_get_parameters.argtypes = [vp, fp]
+            L.cmpc_get_parameters_device.argtypes = [vp, C.POINTER(vp)]
+            L.cmpc_allgather_compact_device.argtypes = [vp, vp, C.c_int, fp, fp, vp]
+            L.cmpc_sq_pass_barriers.argtypes = [C.c_int, C.c_int, C.c_int]
         _lib = L
     return _lib

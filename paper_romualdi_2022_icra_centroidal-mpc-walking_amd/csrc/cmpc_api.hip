@@ -8,11 +8,13 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <dlfcn.h>
 #include <string>
 #include <vector>
 
 extern "C" size_t cmpc_solver_lds_bytes(int N, int factors_global);
 extern "C" int cmpc_launch_solver(const CmpcParams* prm, size_t lds_bytes, hipStream_t stream);
+extern "C" int cmpc_prepare_solver(int N, int factors_global, size_t lds_bytes);
 extern "C" int cmpc_launch_nlp_eval(const CmpcParams* prm, const float* dX, const float* dP, const float* dLamG,
                                     float lam_f, float* dF, float* dG, float* dGradF, float* dJac, float* dHess,
                                     hipStream_t stream);
@@ -139,20 +141,26 @@ int cmpc_create(const cmpc_config* cfg, int batch, int device, cmpc_handle* out)
     cmpc_handle h = new cmpc_handle_s();
     h->cfg = *cfg;
     if (h->cfg.max_iterations <= 0) h->cfg.max_iterations = 40;
-    if (!(h->cfg.tolerance > 0)) h->cfg.tolerance = 1e-6;
+    // Default tolerance by horizon: 1e-6 up to N = 20; 5e-7 beyond.  The error of the far-horizon CoM velocity is fed by the complementarity products that still
+    // lag above the barrier floor at termination (max t z <= tolerance), and it grows with the number of stages behind the first knots: measured on config 5
+    // (N = 30, 5 unseen seeds x 512 problems) 1.05e-4 at 1e-6 against 8.4e-5 at 5e-7, for 4 % more iterations (profiles/r03_accuracy_sweep.txt, r04_accuracy_sweep.txt).
+    if (!(h->cfg.tolerance > 0)) h->cfg.tolerance = h->cfg.horizon > 20 ? 5e-7 : 1e-6;
     if (!(h->cfg.step_tolerance > 0)) h->cfg.step_tolerance = 100.0 * h->cfg.tolerance;
     // 0.05 x tolerance: the same iteration counts as tolerance / 10 (the barrier decreases superlinearly at the end)
     // at 0.7 x the sqrt(mu) bias of the nearly degenerate rows; float32 factorisations start to fail at 2e-8 (8 of 512
     // problems of config 5), 1e-8 loses most of config 3
-    if (!(h->cfg.mu_min > 0)) h->cfg.mu_min = 0.05 * h->cfg.tolerance;
+    // ... so the default floor never goes below 5e-8, whatever the tolerance (N > 20: tolerance 5e-7, floor 5e-8)
+    if (!(h->cfg.mu_min > 0)) h->cfg.mu_min = std::max(0.05 * h->cfg.tolerance, 5e-8);
     if (!(h->cfg.gravity > 0)) h->cfg.gravity = 9.80665;
     h->B = batch;
     h->device = device;
-    if (const char* e = std::getenv("CMPC_WARM_DUALS")) h->warm_duals = std::atoi(e);   // developer knob
-    if (const char* e = std::getenv("CMPC_MU_WARM")) { h->mu_warm = std::atof(e); h->floor_warm = std::min(1e-2, h->mu_warm); }   // developer knob
-    // (every developer knob is read here, once: no getenv on the solve path)
+#ifdef CMPC_PROFILE
+    // developer knobs exist in the diagnostic build only (-DCMPC_PROFILE), read once, here: the shipped library reads no environment variable
+    if (const char* e = std::getenv("CMPC_WARM_DUALS")) h->warm_duals = std::atoi(e);
+    if (const char* e = std::getenv("CMPC_MU_WARM")) { h->mu_warm = std::atof(e); h->floor_warm = std::min(1e-2, h->mu_warm); }
     h->force_warm = std::getenv("CMPC_FORCE_WARM") != nullptr;
     if (const char* e = std::getenv("CMPC_MU_ADAPT")) h->mu_adapt = (float)std::atof(e);
+#endif
     if (h->cfg.tail_stages < 0 || h->cfg.tail_stages >= h->cfg.horizon) h->cfg.tail_stages = 0;
     if (h->cfg.tail_iterations < 0) h->cfg.tail_iterations = 0;
     if (!(h->cfg.tail_trigger > 0)) h->cfg.tail_trigger = 2e-5;
@@ -168,10 +176,8 @@ int cmpc_create(const cmpc_config* cfg, int batch, int device, cmpc_handle* out)
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && batch > prop.multiProcessorCount) fg = true;
     }
-    if (const char* e = std::getenv("CMPC_FACTORS")) {
-        if (std::string(e) == "hbm") fg = true;
-        if (std::string(e) == "lds" && h->lds <= 160 * 1024) fg = false;
-    }
+    if (h->cfg.factor_storage == CMPC_FACTORS_HBM) fg = true;
+    if (h->cfg.factor_storage == CMPC_FACTORS_LDS && h->lds <= 160 * 1024) fg = false;
     if (fg) {
         h->lds = cmpc_solver_lds_bytes(cfg->horizon, 1);
         h->scratch_stride = ((long long)CMPC_REC_N + 2 * CMPC_NI) * cfg->horizon;   // factor records | slacks | multipliers
@@ -193,6 +199,7 @@ int cmpc_create(const cmpc_config* cfg, int batch, int device, cmpc_handle* out)
         }                                                                                                     \
     } while (0)
     HIPCHK_CREATE(hipSetDevice(device));
+    HIPCHK_CREATE((hipError_t)cmpc_prepare_solver(cfg->horizon, fg ? 1 : 0, h->lds));   // (the kernel variant's dynamic-LDS limit: once per handle, not per launch)
     if (fg) {
         // the factor records rely on never-written zero blocks (layout: cmpc_solver.hip): zero once
         HIPCHK_CREATE(hipMalloc(&h->dScratch, sizeof(float) * (size_t)h->scratch_stride * (size_t)batch));
@@ -263,19 +270,19 @@ static void fill_consts(cmpc_handle h, CmpcConsts& q)
         double dmin = 2.0 * c.force_rate_of_change_weight[0];
         for (int i = 1; i < 3; ++i) dmin = std::min(dmin, 2.0 * c.force_rate_of_change_weight[i]);
         q.reg = (float)std::max(1e-5, 5e-5 * dmin);
-        if (const char* e = std::getenv("CMPC_REG")) q.reg = (float)std::atof(e);  // developer knob
+#ifdef CMPC_PROFILE
+        if (const char* e = std::getenv("CMPC_REG")) q.reg = (float)std::atof(e);
+#endif
     }
     // Mehrotra's sigma = (mu_aff/mu)^3 can ask for a 1000-fold barrier decrease in one step; the linearisation
     // does not hold that far and the blocked step costs the problem 3-6 extra iterations.  A floor of 0.03
     // costs +0.3 iterations on the mean of config 2 and removes the tail (max 11 -> 8 of 4096 problems; config 3:
     // mean 8.60 -> 8.49, max 14 -> 12), and a batch is as slow as its slowest problem.
     q.sigma_min = 0.03f;
-    if (const char* e = std::getenv("CMPC_SIGMA_MIN")) q.sigma_min = (float)std::atof(e);  // developer knob
-    for (int i = 0; i < 4; ++i) {
-        q.dev[i] = 0.f;
-        const std::string nm = "CMPC_DEV" + std::to_string(i);
-        if (const char* e = std::getenv(nm.c_str())) q.dev[i] = (float)std::atof(e);
-    }
+#ifdef CMPC_PROFILE
+    if (const char* e = std::getenv("CMPC_SIGMA_MIN")) q.sigma_min = (float)std::atof(e);
+    if (const char* e = std::getenv("CMPC_HWID_PROBE")) q.hwid_probe = std::atoi(e);
+#endif
 }
 
 static void fill_params(cmpc_handle h, CmpcParams& p)
@@ -542,6 +549,27 @@ int cmpc_advance(cmpc_handle h)
     return check_status(h, hinfo);
 }
 
+int cmpc_get_parameters(cmpc_handle h, float* P)
+{
+    if (!h || !P) return fail(h, CMPC_ERR_ARG, "cmpc_get_parameters: null argument");
+    int rc = ensure_buffers(h);
+    if (rc) return rc;
+    std::memcpy(P, h->hP.data(), sizeof(float) * h->hP.size());
+    return CMPC_OK;
+}
+
+int cmpc_get_parameters_device(cmpc_handle h, const float** dP)
+{
+    if (!h || !dP) return fail(h, CMPC_ERR_ARG, "cmpc_get_parameters_device: null argument");
+    int rc = ensure_buffers(h);
+    if (rc) return rc;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipMemcpyAsync(h->dP, h->hP.data(), sizeof(float) * h->hP.size(), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    *dP = h->dP;
+    return CMPC_OK;
+}
+
 int cmpc_get_solution(cmpc_handle h, float* X, float* info)
 {
     if (!h || !h->have_solution) return fail(h, CMPC_ERR_ARG, "cmpc_get_solution: no solution yet");
@@ -662,6 +690,39 @@ int cmpc_compact_output_device(cmpc_handle h, const float* dX, const float* dInf
 }
 
 // ---- 8f-1: contact schedules, batched (logic: cmpc_contacts.h) ----
+// ---- 8e: the gather of compact solutions across the GPUs of a node, through RCCL (ncclAllGather over xGMI).  librccl is opened on first use, so that the
+// library itself carries no link-time dependency on it: a single-GPU caller never loads it. ----
+namespace {
+typedef int (*nccl_allgather_fn)(const void*, void*, size_t, int /*ncclDataType_t*/, void* /*ncclComm_t*/, hipStream_t);
+nccl_allgather_fn load_allgather(std::string& why)
+{
+    static nccl_allgather_fn fn = nullptr;
+    static bool tried = false;
+    if (tried) { if (!fn) why = "librccl.so: ncclAllGather not available"; return fn; }
+    tried = true;
+    void* lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) { why = std::string("dlopen(librccl.so): ") + dlerror(); return nullptr; }
+    fn = reinterpret_cast<nccl_allgather_fn>(dlsym(lib, "ncclAllGather"));
+    if (!fn) why = "librccl.so has no ncclAllGather";
+    return fn;
+}
+}  // namespace
+
+int cmpc_allgather_compact_device(cmpc_handle h, void* nccl_comm, int world_size, const float* dLocal, float* dAll, void* stream)
+{
+    if (!h || !nccl_comm || world_size < 1 || !dLocal || !dAll) return fail(h, CMPC_ERR_ARG, "cmpc_allgather_compact_device: bad argument");
+    std::string why;
+    nccl_allgather_fn ag = load_allgather(why);
+    if (!ag) return fail(h, CMPC_ERR_HIP, "cmpc_allgather_compact_device: " + why);
+    HIPCHK(h, hipSetDevice(h->device));
+    hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+    const size_t count = (size_t)h->B * (size_t)(3 * (h->cfg.horizon + 1) + 38);   // floats of this rank's compact records (cmpc_compact_output_device)
+    const int rc = ag(dLocal, dAll, count, 7 /* ncclFloat32 */, nccl_comm, st);
+    if (rc != 0) return fail(h, CMPC_ERR_HIP, "ncclAllGather failed with code " + std::to_string(rc));
+    return CMPC_OK;
+}
+
 int cmpc_contacts_merge(int batch, int max_contacts, double now, const double* plan_t, const float* plan_pose, const int* plan_n,
                         const double* mpc_t, const float* mpc_pose, const int* mpc_n, double* out_t, float* out_pose, int* out_n, int* ok)
 {

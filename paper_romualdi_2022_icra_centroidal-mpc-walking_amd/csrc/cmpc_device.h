@@ -62,7 +62,7 @@ struct CmpcConsts {
     float sigma_min;             // lower bound of Mehrotra's centring parameter (caps the barrier decrease per iteration)
     float corners[24];           // [c][j][3]
     float wz2[CMPC_NMAX + 1];    // 2 w_z(k)^2, w_z(k) = (w_cz/2)(1+exp(-k))
-    float dev[4];                // developer knobs (env CMPC_DEV0..3), 0 in production
+    int hwid_probe;              // diagnostic build only: phase_export overwrites x[0..7] with the HW_ID of each wave
 };
 
 // The same layout as closed-form index functions.  Device code uses these: indexing the offset arrays

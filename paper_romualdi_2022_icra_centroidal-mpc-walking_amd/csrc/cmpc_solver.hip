@@ -37,6 +37,8 @@
 #include "cmpc_device.h"
 
 #include <cstdlib>
+#include <map>
+#include <mutex>
 
 #define NS CMPC_NS
 #define NF CMPC_NF
@@ -2878,10 +2880,12 @@ __device__ __attribute__((noinline)) void phase_export(lds_t lds, int Nrt, float
         for (int e = tid; e < NS * (N + 1); e += NT) dq[e] = c.LAM[e];
         for (int e = tid; e < NI * N; e += NT) { dq[NS * (N + 1) + e] = c.T[e]; dq[NS * (N + 1) + NI * N + e] = c.Z[e]; }
     }
-    if (prm.dev[2] != 0.f) {  // developer probe: where the hardware put each wave (overwrites x[0..3]; HW_ID: wave slot
+#ifdef CMPC_PROFILE
+    if (prm.hwid_probe) {     // developer probe: where the hardware put each wave (overwrites x[0..7]; HW_ID: wave slot
         __syncthreads();      // [3:0], SIMD [5:4], CU [11:8], SH [12], SE [15:13])
         if ((threadIdx.x & 63) == 0) x[threadIdx.x >> 6] = (float)(__builtin_amdgcn_s_getreg((31 << 11) | 4) & 0xffff);
     }
+#endif
 }
 
 // NC > 0: horizon known at compile time (every LDS offset becomes an immediate); NC == 0: runtime N
@@ -3101,40 +3105,46 @@ extern "C" int cmpc_profile_read(long long* out, int reset)
 extern "C" int cmpc_trace_read(float* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_trace), sizeof(float) * 64 * 8); }
 #endif
 
+// the kernel variant for a horizon and a factor storage: resident (512 threads, records in LDS, one workgroup per CU) or HBM-factor (256 threads, three per CU)
+typedef void (*cmpc_kernel_t)(CmpcParams);
+static cmpc_kernel_t solver_variant(int N, bool factors_global, int& nthreads)
+{
+    constexpr int NT = 256, NR = 512;
+    if (factors_global) {
+        nthreads = NT;
+        return N == 20 ? cmpc_solve_kernel<NT, 20, true> : (N == 30 ? cmpc_solve_kernel<NT, 30, true> : cmpc_solve_kernel<NT, 0, true>);
+    }
+    nthreads = NR;
+    switch (N) {  // horizons of the shipped configurations get compile-time layouts
+        case 10: return cmpc_solve_kernel<NR, 10, false>;
+        case 12: return cmpc_solve_kernel<NR, 12, false>;
+        case 13: return cmpc_solve_kernel<NR, 13, false>;  // ergoCubSN000
+        case 15: return cmpc_solve_kernel<NR, 15, false>;  // iCubGazeboV3
+        case 20: return cmpc_solve_kernel<NR, 20, false>;  // ergoCubGazeboV1
+        case 22: return cmpc_solve_kernel<NR, 22, false>;  // ergoCubSN001
+        default: return cmpc_solve_kernel<NR, 0, false>;
+    }
+}
+// once per handle (cmpc_create): raise the variant's dynamic-LDS limit to what this horizon needs (the runtime-N variants serve several horizons: never lowered)
+extern "C" int cmpc_prepare_solver(int N, int factors_global, size_t lds_bytes)
+{
+    int nthreads = 0;
+    const cmpc_kernel_t kern = solver_variant(N, factors_global != 0, nthreads);
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    static std::mutex mu;
+    static std::map<std::pair<int, const void*>, size_t> limit;   // (the attribute belongs to the function on ONE device)
+    std::lock_guard<std::mutex> lock(mu);
+    size_t& cur = limit[std::make_pair(dev, reinterpret_cast<const void*>(kern))];
+    if (lds_bytes <= cur) return 0;
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e == hipSuccess) cur = lds_bytes;
+    return (int)e;
+}
 extern "C" int cmpc_launch_solver(const CmpcParams* prm, size_t lds_bytes, hipStream_t stream)
 {
-    constexpr int NT = 256;     // HBM-factor variants: three workgroups per CU
-    constexpr int NR = 512;     // resident variants (one workgroup per CU): eight waves, the phases every thread takes part in scale
-    static const bool wide = !(std::getenv("CMPC_THREADS") && std::atoi(std::getenv("CMPC_THREADS")) == 256);   // developer knob
-    int nthreads = NT;
-    void (*kern)(CmpcParams) = nullptr;
-#ifdef CMPC_ONLY_N20  // developer builds: one instantiation
-    kern = cmpc_solve_kernel<NR, 20, false>; nthreads = NR; (void)wide;
-#else
-    if (prm->scratch) {
-        kern = prm->N == 20 ? cmpc_solve_kernel<NT, 20, true> : (prm->N == 30 ? cmpc_solve_kernel<NT, 30, true> : cmpc_solve_kernel<NT, 0, true>);
-    } else {
-        if (wide) {
-            nthreads = NR;
-            switch (prm->N) {  // horizons of the shipped configurations get compile-time layouts
-                case 10: kern = cmpc_solve_kernel<NR, 10, false>; break;
-                case 12: kern = cmpc_solve_kernel<NR, 12, false>; break;
-                case 13: kern = cmpc_solve_kernel<NR, 13, false>; break;  // ergoCubSN000
-                case 15: kern = cmpc_solve_kernel<NR, 15, false>; break;  // iCubGazeboV3
-                case 20: kern = cmpc_solve_kernel<NR, 20, false>; break;  // ergoCubGazeboV1
-                case 22: kern = cmpc_solve_kernel<NR, 22, false>; break;  // ergoCubSN001
-                default: kern = cmpc_solve_kernel<NR, 0, false>; break;
-            }
-        } else {
-            switch (prm->N) {
-                case 20: kern = cmpc_solve_kernel<NT, 20, false>; break;
-                default: kern = cmpc_solve_kernel<NT, 0, false>; break;
-            }
-        }
-    }
-#endif
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    if (e != hipSuccess) return (int)e;
+    int nthreads = 0;
+    const cmpc_kernel_t kern = solver_variant(prm->N, prm->scratch != nullptr, nthreads);
     CmpcParams kp = *prm;
     kp.lds_words = (int)(lds_bytes / 4);
     (void)hipGetLastError();   // (a stale error of an earlier, unrelated runtime call must not be read as this launch's)

@@ -9,6 +9,8 @@ from __future__ import annotations
 
 import numpy as np
 
+from .config import GRAVITY
+
 from .contacts import PlannedContact, pack_lists
 from .layout import Layout
 from .solver import BatchSolver
@@ -106,8 +108,12 @@ class WalkingRollout:
                 if not bool(ok.all().item()):
                     # the reference aborts the tick when updateContactPhaseList returns false (CentroidalMPCBlock.cpp:603-607): so does
                     # the roll-out -- the merged lists of the failing problems are empty and must not be sampled or solved
+                    # (every per-tick list gets its entry, so that the records stay aligned; bench.py fails the roll-out when it sees 'aborted_tick')
                     rec["merge_ok"].append(False)
                     rec["aborted_tick"] = i
+                    rec["tick_ms"].append(float("nan")); rec["retried"].append(0); rec["unconverged"].append(B)
+                    rec["iterations_mean"].append(float("nan")); rec["iterations_max"].append(0); rec["converged"].append(False)
+                    rec["solve_ms"].append(float("nan"))
                     break
             land = s.contacts_sample_device(now, lists, dP)
             # references at the knots (CentroidalMPCBlock.cpp:525-577 resamples the planner's; here a straight line)
@@ -127,7 +133,7 @@ class WalkingRollout:
                 for c in range(2):
                     dX0[:, L.pos[c]:L.pos[c] + 3 * (N + 1)] = dP[:, L.p_nom[c]:L.p_nom[c] + 3 * (N + 1)]
                     for j in range(4):
-                        dX0[:, L.f[c][j] + 2:L.f[c][j] + 3 * N:3] = 9.80665 / 8.0
+                        dX0[:, L.f[c][j] + 2:L.f[c][j] + 3 * N:3] = GRAVITY / 8.0   # (the library's cold start: cmpc_config.gravity / 8, which this package always sets to GRAVITY)
             else:
                 s.shift_solution_device(dX, dX0)
             if dump is not None and i == dump[0]:   # developer hook: (tick, path) -> the tick's P and X0
@@ -146,7 +152,7 @@ class WalkingRollout:
                     for c in range(2):
                         X02[:, L.pos[c]:L.pos[c] + 3 * (N + 1)] = P2[:, L.p_nom[c]:L.p_nom[c] + 3 * (N + 1)]
                         for j in range(4):
-                            X02[:, L.f[c][j] + 2:L.f[c][j] + 3 * N:3] = 9.80665 / 8.0
+                            X02[:, L.f[c][j] + 2:L.f[c][j] + 3 * N:3] = GRAVITY / 8.0
                     X2, I2 = self.solver2.solve_device(P2, X02)
                     I2[:, 0] += dInfo.index_select(0, idx)[:, 0]     # iterations of both attempts
                     I2[:, 3] += 10000.0                              # safeguard word: solved again from the cold start

@@ -22,7 +22,7 @@ from .layout import Layout
 
 def _c_config(cfg: CentroidalMPCConfig, tolerance=None, mu_min=None, max_iterations=None,
               exact_hessian=True, final_extrapolation=True, step_tolerance=None, mu_init=None,
-              tail_stages=3, tail_iterations=2, tail_trigger=2e-5) -> _capi.CmpcConfig:
+              tail_stages=3, tail_iterations=2, tail_trigger=2e-5, factors=None) -> _capi.CmpcConfig:
     c = _capi.CmpcConfig()
     c.horizon = cfg.N
     c.sampling_time = cfg.sampling_time
@@ -37,14 +37,16 @@ def _c_config(cfg: CentroidalMPCConfig, tolerance=None, mu_min=None, max_iterati
     c.max_iterations = max_iterations or cfg.ipopt_max_iteration
     # the reference's ipopt_tolerance (1e-4 / 1e-2) is looser than the parity target; the GPU
     # solver always converges at least to 1e-6 so that its answer is reproducible to 1e-4
-    c.tolerance = tolerance if tolerance is not None else min(cfg.ipopt_tolerance, 1e-6)
-    c.step_tolerance = step_tolerance if step_tolerance is not None else 100.0 * c.tolerance
+    # (0: the library's default -- 1e-6 up to N = 20, 5e-7 beyond; step tolerance and barrier floor follow it)
+    c.tolerance = tolerance if tolerance is not None else (cfg.ipopt_tolerance if cfg.ipopt_tolerance < 5e-7 else 0.0)
+    c.step_tolerance = step_tolerance if step_tolerance is not None else 0.0
     c.mu_init = mu_init if mu_init is not None else 0.0   # <= 0: per problem, from its initial infeasibility
-    c.mu_min = mu_min if mu_min is not None else 0.05 * c.tolerance
+    c.mu_min = mu_min if mu_min is not None else 0.0
     c.exact_hessian = int(exact_hessian)
     c.final_extrapolation = int(final_extrapolation)
     # tail polish (include/cmpc.h): the last stages re-solved when their extrapolation step is large
     c.tail_stages, c.tail_iterations, c.tail_trigger = int(tail_stages), int(tail_iterations), float(tail_trigger)
+    c.factor_storage = _capi.FACTORS[factors]   # None / "auto": by batch size and horizon; "lds" / "hbm": the resident / the HBM-factor variant
     return c
 
 

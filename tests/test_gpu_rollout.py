@@ -99,7 +99,9 @@ def test_rollout_aborts_the_tick_like_the_reference_when_the_merge_fails():
     t[3, 0] += 100.0          # from tick 2 on the planner of problem 3 no longer knows the left foot's current contact
     com0 = np.tile([0.0, 0.0, 0.7], (B, 1)); z = np.zeros((B, 3))
     rec = ro.run(5, com0, z, z, replan={2: (t, ro.plan[1], ro.plan[2])})
-    assert rec.get("aborted_tick") == 2 and rec["merge_ok"] == [True, True, False] and len(rec["converged"]) == 2
+    assert rec.get("aborted_tick") == 2 and rec["merge_ok"] == [True, True, False]
+    # the per-tick records stay aligned: the aborted tick has its (failed) entry in every list
+    assert rec["converged"] == [True, True, False] and len(rec["tick_ms"]) == len(rec["iterations_max"]) == len(rec["unconverged"]) == 3
 
 
 def test_walking_rollout_stays_in_hbm_and_on_its_feet():

@@ -119,6 +119,7 @@ def test_config4_shard_of_8192():
     s = cm.BatchSolver(cfg, B)
     X, info, rc = s.solve_host(P32, X032)
     assert rc == 0 and (info[:, 5] == 0).all(), s.last_error
+    parity.assert_no_sync_giveups(info)
     perm = np.random.default_rng(4).permutation(B)
     Xp, _, _ = s.solve_host(P32[perm], X032[perm])
     np.testing.assert_array_equal(Xp, X[perm])
@@ -186,6 +187,13 @@ def test_full_size_properties_config3():
     s = cm.BatchSolver(cfg, B)
     X, info, rc = s.solve_host(P32, X032)
     assert rc == 0 and (info[:, 5] == 0).all(), s.last_error
+    parity.assert_no_sync_giveups(info)
+    # the first 256 of them through the resident variant (one problem per compute unit: the streaming backward stage and its hand-off words)
+    sr = cm.BatchSolver(cfg, 256, factors="lds")
+    Xr, infor, rcr = sr.solve_host(P32[:256], X032[:256])
+    assert rcr == 0 and (infor[:, 5] == 0).all(), sr.last_error
+    parity.assert_no_sync_giveups(infor)
+    sr.close()
     perm = np.random.default_rng(0).permutation(B)
     Xp, _, _ = s.solve_host(P32[perm], X032[perm])
     np.testing.assert_array_equal(Xp, X[perm])
@@ -274,11 +282,10 @@ def test_solve_does_not_depend_on_stale_lds(factors, monkeypatch):
     """LDS arrives uninitialised: poison every CU's LDS with NaNs (test hook of the C ABI), then solve more
     problems than there are CUs so that later workgroups also inherit an earlier workgroup's image.  Results must
     be bit-identical to an unpoisoned solve and all converged.  (Regression: entries read under a zero weight.)"""
-    monkeypatch.setenv("CMPC_FACTORS", factors)
     B = 768
     cfg, P, X0 = cm.synthetic.config3_external_push(B, seed=11)
     P32, X032 = P.astype(np.float32), X0.astype(np.float32)
-    s = cm.BatchSolver(cfg, B)
+    s = cm.BatchSolver(cfg, B, factors=factors)
     X1, info1, rc1 = s.solve_host(P32, X032)
     assert rc1 == 0 and (info1[:, 5] == 0).all(), s.last_error
     assert s._lib.cmpc_test_poison_lds(s._h) == 0
@@ -357,15 +364,14 @@ def test_hbm_factor_and_resident_variants_agree(N, monkeypatch):
     P32, X032 = P.astype(np.float32), X0.astype(np.float32)
     out = {}
     for factors in ("lds", "hbm"):
-        monkeypatch.setenv("CMPC_FACTORS", factors)
-        s = cm.BatchSolver(cfg, 32)
+        s = cm.BatchSolver(cfg, 32, factors=factors)
         X, info, rc = s.solve_host(P32, X032)
         assert rc == 0 and (info[:, 5] == 0).all(), (factors, s.last_error)
         out[factors] = (X, info)
         s.close()
     # (the resident variants assemble a stage in the square-root form, the HBM-factor variants through the value function: the same optimum -- checked
     #  below -- by different float32 algebra, and the lagged termination test may then fire an iteration or two apart on a borderline problem)
-    assert np.abs(out["lds"][1][:, 0] - out["hbm"][1][:, 0]).max() <= 2
+    assert np.abs(out["lds"][1][:, 0] - out["hbm"][1][:, 0]).max() <= 1
     for b in range(32):
         e = parity.errors(cfg.N, P32[b], out["hbm"][0][b], out["lds"][0][b])
         assert e["com"] < 2e-5 and e["forces"] < 5e-5 and e["pos"] < 2e-5, (b, e)
@@ -380,13 +386,12 @@ def test_streaming_stage_matches_the_value_function_stage_on_stepping_problems(g
     P32, X032 = P.astype(np.float32), X0.astype(np.float32)
     out = {}
     for factors in ("lds", "hbm"):
-        monkeypatch.setenv("CMPC_FACTORS", factors)
-        s = cm.BatchSolver(cfg, P32.shape[0])
+        s = cm.BatchSolver(cfg, P32.shape[0], factors=factors)
         X, info, rc = s.solve_host(P32, X032)
         assert rc == 0 and (info[:, 5] == 0).all(), (factors, info[:, 5], s.last_error)
         out[factors] = (X, info)
         s.close()
-    assert np.abs(out["lds"][1][:, 0] - out["hbm"][1][:, 0]).max() <= 2, (out["lds"][1][:, 0], out["hbm"][1][:, 0])
+    assert np.abs(out["lds"][1][:, 0] - out["hbm"][1][:, 0]).max() <= 1, (out["lds"][1][:, 0], out["hbm"][1][:, 0])
     for b in range(P32.shape[0]):
         e = parity.errors(cfg.N, P32[b], out["hbm"][0][b], out["lds"][0][b])
         assert e["com"] < 3e-5 and e["forces"] < 1e-4 and e["pos"] < 3e-5, (b, e)
@@ -434,6 +439,7 @@ def test_full_size_properties_config5():
     s = cm.BatchSolver(cfg, B)
     X, info, rc = s.solve_host(P32, X032)
     assert rc == 0 and (info[:, 5] == 0).all(), s.last_error
+    parity.assert_no_sync_giveups(info)
     perm = np.random.default_rng(6).permutation(B)
     Xp, _, _ = s.solve_host(P32[perm], X032[perm])
     np.testing.assert_array_equal(Xp, X[perm])

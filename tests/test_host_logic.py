@@ -126,6 +126,17 @@ def test_c_abi_exports_every_declared_symbol():
         assert hasattr(lib, name), name
 
 
+def test_streaming_stage_roles_hold_the_same_number_of_barriers():
+    """The factorising wave and the consumer waves of the streaming backward stage run their stage loops in two different out-of-line functions
+    and meet at workgroup barriers: unequal counts would hang the workgroup (a GPU reset for everyone on the node), not fail a test.  Both loops are
+    written with one loop-header macro and hold one barrier per trip plus one before the loop; the library counts them on that skeleton (host code)."""
+    lib = cm._capi.lib()
+    for N in (2, 10, 12, 13, 15, 20, 22, 30, 40):
+        for k0 in sorted({0, 1, max(N - 3, 0), N - 1}):
+            a, b = lib.cmpc_sq_pass_barriers(N, k0, 0), lib.cmpc_sq_pass_barriers(N, k0, 1)
+            assert a == b == 1 + N - k0, (N, k0, a, b)
+
+
 def test_lds_images_fit_the_cu():
     """The LDS image the launcher asks for (host function, no GPU): the resident variants -- whole problem and the working sets of the streaming stage in LDS,
     one workgroup per CU -- fit the 160 KiB of a CU for every horizon the reference ships a configuration for (10..22); the HBM-factor image fits THREE times

@@ -130,6 +130,9 @@ def test_reference_solved_goldens_satisfy_kkt_on_the_reference_code(name, which,
         ref = ref_nlp.RefNLP(which)
     except (ImportError, FileNotFoundError):
         ref = None
+    # second order, all problems: the generator stored the smallest eigenvalue of the reduced Hessian it found on the reference's code (kkt[:, 3]);
+    # recomputed below for every fourth problem
+    assert (d["kkt"][:, 3] > -1e-8).all(), d["kkt"][:, 3].min()
     for b in range(d["P"].shape[0]):
         p = d["P"][b].astype(np.float64)
         x, lam = d["x_star"][b], d["lam_g"][b]

@@ -11,5 +11,5 @@ for B in ([int(a) for a in sys.argv[1:]] or [256, 257, 300, 512, 1024, 4096]):
     X, info, rc = s.solve_host(P, X0)
     it = info[:, 0].astype(int)
     bad = np.nonzero(info[:, 5] != 0)[0]
-    print("B", B, "rc", rc, "env", os.environ.get("CMPC_FACTORS"), "mean it %.2f" % it.mean(), "bad", len(bad), "first bad", bad[:8], "status", info[bad[:4], 5], "nan", int(np.isnan(X).any(axis=1).sum()), "good idx", np.nonzero(info[:, 5] == 0)[0][:12], "bad/256-chunk", [int((info[i:i+256, 5] != 0).sum()) for i in range(0, B, 256)], flush=True)
+    print("B", B, "rc", rc, "mean it %.2f" % it.mean(), "bad", len(bad), "first bad", bad[:8], "status", info[bad[:4], 5], "nan", int(np.isnan(X).any(axis=1).sum()), "good idx", np.nonzero(info[:, 5] == 0)[0][:12], "bad/256-chunk", [int((info[i:i+256, 5] != 0).sum()) for i in range(0, B, 256)], flush=True)
     s.close()

@@ -1,4 +1,4 @@
-"""Developer probe (GPU box): resident (CMPC_FACTORS=lds) against HBM-factor (hbm) variants at batch sizes around the CU count; solves/s of config-2 and config-3 problems."""
+"""Developer probe (GPU box): resident (factors="lds") against HBM-factor ("hbm") variants at batch sizes around the CU count; solves/s of config-2 and config-3 problems."""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -9,9 +9,8 @@ for name, gen in (("cfg2", cm.synthetic.config2_perturbed_com), ("cfg3", cm.synt
     for B in (256, 384, 512, 768, 1024):
         row = []
         for fac in ("lds", "hbm"):
-            os.environ["CMPC_FACTORS"] = fac
             cfg, P, X0 = gen(B)
-            s = cm.BatchSolver(cfg, B)
+            s = cm.BatchSolver(cfg, B, factors=fac)
             dP, dX0 = torch.from_numpy(P.astype(np.float32)).cuda(), torch.from_numpy(X0.astype(np.float32)).cuda()
             for _ in range(3):
                 s.solve_device(dP, dX0)

@@ -4,13 +4,12 @@ import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-os.environ["CMPC_FACTORS"] = "hbm"
 import cmpc_amd as cm
 cfg, P, X0 = cm.synthetic.config3_external_push(256)
 for rep in (1, 2, 3, 6, 12):
     B = 256 * rep
     P32 = np.tile(P.astype(np.float32), (rep, 1)); X032 = np.tile(X0.astype(np.float32), (rep, 1))
-    s = cm.BatchSolver(cfg, B)
+    s = cm.BatchSolver(cfg, B, factors="hbm")
     dP, dX0 = torch.from_numpy(P32).cuda(), torch.from_numpy(X032).cuda()
     dX, dI = s.solve_device(dP, dX0); torch.cuda.synchronize()
     ms = []

@@ -1,5 +1,5 @@
-"""Developer probe (GPU box): the same problems through the resident variant (CMPC_FACTORS=lds) and the HBM-factor variant
-(CMPC_FACTORS=hbm), several horizons, generators and seeds; prints the worst disagreement and any unconverged problem."""
+"""Developer probe (GPU box): the same problems through the resident variant (factors="lds") and the HBM-factor variant
+(factors="hbm"), several horizons, generators and seeds; prints the worst disagreement and any unconverged problem."""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -13,8 +13,7 @@ for N in (10, 12, 13, 15, 17, 20, 22):
         P32, X032 = P.astype(np.float32), X0.astype(np.float32)
         out = {}
         for f in ("lds", "hbm"):
-            os.environ["CMPC_FACTORS"] = f
-            s = cm.BatchSolver(cfg, B)
+            s = cm.BatchSolver(cfg, B, factors=f)
             X, info, rc = s.solve_host(P32, X032)
             out[f] = (X, info)
             s.close()
