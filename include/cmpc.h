@@ -56,7 +56,7 @@ typedef struct {
     double corners[2][4][3];  /* [CONTACT_i] corner_j, contacts in alphabetical name order        */
     /* solver options (ipopt_tolerance / ipopt_max_iteration take the place of IPOPT's) */
     int max_iterations;       /* Newton iteration budget per solve (default 40)                   */
-    double tolerance;         /* on the primal residuals and on max t*z (<= 0: default 1e-6 up to N = 20, 5e-7 beyond) */
+    double tolerance;         /* on the primal residuals and on max t*z (<= 0: default 1e-6 up to N = 20, 3e-7 beyond) */
     double step_tolerance;    /* on the last Newton step, max-norm over states and forces (default 1e-4) */
     double mu_init;           /* initial barrier parameter; <= 0 (default): per problem, from its
                                * initial infeasibility ep0: clamp(3.5 ep0^2, 0.03, 0.5)           */

@@ -181,6 +181,17 @@ struct Ctx {
 // LDS operations of one wave execute in issue order, so a write followed by reads of other lanes of the
 // SAME wave needs no wait, only a fence for the compiler
 __device__ inline void wave_lds_sync() { asm volatile("" ::: "memory"); }
+// LDS addresses as 32-bit address-space-3 pointers, made opaque to the optimiser (see forward_sweep): a load through one is ds_read vaddr offset:imm
+typedef __attribute__((address_space(3))) const float* ldsf_t;
+typedef __attribute__((address_space(3))) float* ldsw_t;
+__device__ inline ldsf_t lds_opaque(const float* p) { ldsf_t q = (ldsf_t)p; asm volatile("" : "+v"(q)); return q; }
+__device__ inline ldsw_t lds_opaque_w(float* p) { ldsw_t q = (ldsw_t)p; asm volatile("" : "+v"(q)); return q; }
+typedef float v4f __attribute__((ext_vector_type(4)));
+__device__ inline float4 lds_ld4(ldsf_t p)
+{
+    const v4f v = *reinterpret_cast<__attribute__((address_space(3))) const v4f*>(p);
+    return make_float4(v[0], v[1], v[2], v[3]);
+}
 
 // ---- access to the per-stage factor records.  LDS in the resident variants.  In the HBM-factor variants they sit in global
 // scratch and go through a buffer descriptor built once per phase from the wave-uniform base (a pointer argument of an
@@ -697,7 +708,6 @@ __device__ inline double rcp_d(double x)
 // 126 per factorisation at 8 cycles each, where rounds 1-3 issued 6 v_readlane + 3 v_pk_fma_f32 per column PAIR (525 + 260 instructions, a third of
 // the phase).  Measured in isolation: 27 cycles per four columns and pivot block against 81.  f32-input MFMA is an exact fmaf chain (MI355X_MICROARCH.md),
 // and the order per entry (pivot columns j0, j0 + 1, j0 + 2) is the one the packed FMAs had: the factors are bit-identical.
-typedef float v4f __attribute__((ext_vector_type(4)));
 #define VE(j) acc[(j) >> 2][(j) & 3]
 // ONE: the whole factorisation on one wave.  76 rows do not fit 64 lanes, but the L rows of the first blocks are finished
 // (and never read again: multipliers only come from rows below the pivot block, and L itself is not kept) long before the
@@ -2122,111 +2132,186 @@ __device__ int riccati_backward(lds_t lds, const Ctx& c, const CmpcConsts& prm, 
 // Matrix operands do not depend on the recursion: they are read at the top of the stage. ----
 // k0 > 0 (tail polish): the sweep starts at stage k0 with ds_k0 = 0 and the force step before it zero.
 // PART 0: the whole of it; 1: the sweep alone (wave 0, no barrier); 2: the barrier and the element-wise part (all threads).
-template <int NT, int UNR, bool G, int PART = 0>
-__device__ void riccati_forward(const Ctx& c, const CmpcConsts& prm, int tid, bool affine, int k0)
+// The sweep itself (one wave).  A wave executes one instruction of any kind per four cycles, so the sweep is as long as its instruction count: everything that
+// does not change from stage to stage -- per-lane operand addresses, role masks -- is set up once; a trip of UNR stages addresses its operands as pointer + immediate
+// and bumps the pointers once; results of lanes without a task go to words of the staging buffer nobody reads instead of being masked off (round 4: 340 -> ~170
+// instructions per stage).
+template <int UNR, bool G>
+__device__ __forceinline__ void forward_sweep(const Ctx& c, const CmpcConsts& prm, int tid, int k0)
 {
     const int N = c.N;
-    if (PART != 2 && tid < 64) {
-        const int r = tid & 31, half = tid >> 5, blk = r >> 2;
-        float* xb = c.ybuf;       // [ds (15), 1, -D du_prev (24)]
-        float* yb = c.ybuf + 40;  // y (32)
-        // per-lane offsets inside a stage record (loop invariant)
-        // y-step: column r of [WT; U[0..23]] against x, 20 terms per half;  du-step: row r of U against y
-        unsigned yoff[20], uoff[4];
+    const int r = tid & 31, half = tid >> 5, blk = r >> 2;
+    float* xb = c.ybuf;           // [ds (15), 1, -D du_prev (24)]
+    float* yb = c.ybuf + 40;      // y (32)
+    float* trash = c.ybuf + 72;   // 24 words nobody reads
+    // per-lane offsets inside a stage record (loop invariant)
+    // y-step: column r of [WT; U[0..23]] against x, 20 terms per half;  du-step: row r of U against y
+    unsigned yoff[20], uoff[4];
 #pragma unroll
-        for (int t = 0; t < 20; ++t) {
-            if (half == 0) yoff[t] = t < 16 ? wt_idx(t, r) : ub_row(t - 16) + r;
-            else {
-                const int m = 4 + t;
-                yoff[t] = blk >= (m >> 2) ? ub_row(m) + r - 4 * (m >> 2) : REC_ZERO;
-            }
+    for (int t = 0; t < 20; ++t) {
+        if (half == 0) yoff[t] = t < 16 ? wt_idx(t, r) : ub_row(t - 16) + r;
+        else {
+            const int m = 4 + t;
+            yoff[t] = blk >= (m >> 2) ? ub_row(m) + r - 4 * (m >> 2) : REC_ZERO;
         }
+    }
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int q4 = 4 * half + t;
-            uoff[t] = q4 >= blk ? ub_row(r) + 4 * (q4 - blk) : REC_ZERO;
-        }
-        // roles in the dynamics step: lanes 0..23 form the corner terms (axis ga of corner cj), lanes 0..14 then
-        // evaluate one row each of  ds+ = A ds + B du + d  with per-lane coefficients, branch-free:
-        //   out = sj ds_j + ce ds_je + cD sumD_a + cH (sumH_a + dt sum_ct gam_ct (e_ct x Fc_ct)_a) + cp (R_ct dq_ct)_a + d_j
-        const int ga = tid >> 3, cj = tid & 7;
-        const int ga1 = (ga + 1) % 3, ga2 = (ga + 2) % 3;
-        const int j = tid < NS ? tid : 0;
-        const int ja = j % 3, ja1 = (ja + 1) % 3, ja2 = (ja + 2) % 3, jct = j >= 12 ? 1 : 0;
-        const int je = j < 3 ? j + 3 : 0;
-        const float ce = j < 3 ? prm.dt : 0.f;
-        const float cD = (j >= 3 && j < 6) ? 1.f : 0.f, cH = (j >= 6 && j < 9) ? 1.f : 0.f;
-        const bool isPos = j >= 9;
-        const float Dm = prm.D[r % 3];
-        if (tid < 40) xb[tid] = tid == 15 ? 1.f : 0.f;
-        if (tid < NS) c.dS[NS * k0 + tid] = 0.f;
-        wave_lds_sync();
-        PROF2_DECL;
-#pragma unroll UNR   // (stages per trip: 4 in the resident variants -- a quarter of the address updates of the ~30 LDS operand
-        // pointers, +3 % -- and 2 in the HBM-factor variants, whose records come through the descriptor: +1 %, 4 brings no more)
-        for (int k = k0; k < N; ++k) {
+    for (int t = 0; t < 4; ++t) {
+        const int q4 = 4 * half + t;
+        uoff[t] = q4 >= blk ? ub_row(r) + 4 * (q4 - blk) : REC_ZERO;
+    }
+    // roles in the dynamics step: lanes 0..23 form the corner terms (axis ga of corner cj), lanes 0..14 then
+    // evaluate one row each of  ds+ = A ds + B du + d  with per-lane coefficients, branch-free:
+    //   out = sj ds_j + ce ds_je + cD sumD_a + cH (sumH_a + dt sum_ct gam_ct (e_ct x Fc_ct)_a) + cp (R_ct dq_ct)_a + d_j
+    const bool corner = tid < NF;
+    const int ga = corner ? tid >> 3 : 0, cj = corner ? tid & 7 : 0;
+    const int ga1 = (ga + 1) % 3, ga2 = (ga + 2) % 3;
+    const int j = tid < NS ? tid : 0;
+    const int ja = j % 3, ja1 = (ja + 1) % 3, ja2 = (ja + 2) % 3, jct = j >= 12 ? 1 : 0;
+    const int je = j < 3 ? j + 3 : 0;
+    const float ce = j < 3 ? prm.dt : 0.f;
+    const float cD = (j >= 3 && j < 6) ? 1.f : 0.f, cH = (j >= 6 && j < 9) ? 1.f : 0.f;
+    const float posm = j >= 9 ? 1.f : 0.f;
+    const float cDm0 = ja == 0 ? cD : 0.f, cDm1 = ja == 1 ? cD : 0.f, cDm2 = ja == 2 ? cD : 0.f;
+    const float cHm0 = ja == 0 ? cH : 0.f, cHm1 = ja == 1 ? cH : 0.f, cHm2 = ja == 2 ? cH : 0.f;
+    const float gdtm = corner ? prm.dt : 0.f, gsel = cj >= 4 ? 1.f : 0.f, jsel = jct ? 1.f : 0.f;
+    const float Dm = prm.D[r % 3];
+    const float dtc = prm.dt;
+    if (tid < 40) xb[tid] = tid == 15 ? 1.f : 0.f;
+    if (tid < NS) c.dS[NS * k0 + tid] = 0.f;
+    wave_lds_sync();
+    // operand pointers of stage k0: LDS addresses, each made opaque -- left to itself the optimiser notices that they all advance together, keeps ONE base and
+    // re-adds the lane's offset in front of every load (a v_add per operand and stage: 40 of the old 340 instructions)
+    ldsf_t yp[20];
+    ldsf_t upp[4];
+    if (!G) {
+#pragma unroll
+        for (int t = 0; t < 20; ++t) yp[t] = lds_opaque(c.Lf + (size_t)REC_N * k0 + yoff[t]);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) upp[t] = lds_opaque(c.Lf + (size_t)REC_N * k0 + uoff[t]);
+    }
+    ldsf_t gr1 = lds_opaque(c.geoA + GEO * k0 + 3 * cj + ga1);
+    ldsf_t gr2 = lds_opaque(c.geoA + GEO * k0 + 3 * cj + ga2);
+    ldsf_t gf1 = lds_opaque(c.geoA + GEO * k0 + 24 + ja1);
+    ldsf_t gf2 = lds_opaque(c.geoA + GEO * k0 + 24 + ja2);
+    ldsf_t gm0 = lds_opaque(c.sp + c.L.pGam(0) + k0);
+    ldsf_t gm1 = lds_opaque(c.sp + c.L.pGam(1) + k0);
+    ldsf_t rp = lds_opaque(c.sp + c.L.pR(jct) + 9 * k0 + ja);          // R(ja, 0..2) = rp[0], rp[3], rp[6] (vec(R) is column-major)
+    ldsf_t dp = lds_opaque(c.d + NS * k0 + j);
+    ldsf_t du0p = lds_opaque(c.dU + NU * k0 + 3 * cj + ga);
+    ldsf_t du1p = lds_opaque(c.dU + NU * k0 + 3 * cj + ga1);
+    ldsf_t du2p = lds_opaque(c.dU + NU * k0 + 3 * cj + ga2);
+    ldsf_t dqp = lds_opaque(c.dU + NU * k0 + 24 + 3 * jct);
+    // where results go: lanes without one keep writing to a fixed word of their own
+    ldsw_t dUs = lds_opaque_w(tid < NU ? c.dU + NU * k0 + tid : trash + (tid & 7));
+    const int dUst = tid < NU ? NU : 0;
+    ldsw_t dSs = lds_opaque_w(tid < NS ? c.dS + NS * (k0 + 1) + tid : trash + 8 + (tid & 7));
+    const int dSst = tid < NS ? NS : 0;
+    ldsw_t xbs = lds_opaque_w(tid < NS ? xb + tid : trash + 16 + (tid & 3));
+    ldsw_t xps = lds_opaque_w(tid < NF ? xb + 16 + tid : trash + 20 + (tid & 3));
+    ldsw_t ybs = lds_opaque_w(yb + r);
+    ldsf_t xsp = lds_opaque(xb + j), xep = lds_opaque(xb + je), x1p = lds_opaque(xb + ja1), x2p = lds_opaque(xb + ja2);
+    ldsf_t xvp = lds_opaque(xb + 20 * half), yvp = lds_opaque(yb + 16 * half);
+    PROF2_DECL;
+    auto stage = [&](int i, int k) {
+        float ym[20];
+        float4 um[4];
+        if (G) {
             const RecRef<G> rec(c.Lf, N, k);
-            float ym[20];
-            float4 um[4];
 #pragma unroll
             for (int t = 0; t < 20; ++t) ym[t] = rec.ld(yoff[t]);
 #pragma unroll
             for (int t = 0; t < 4; ++t) um[t] = rec.ld4(uoff[t]);
-            // stage data of the dynamics step (independent of the recursion as well)
-            const float* geo = c.geoA + GEO * k;
-            const float gam0 = gam_of(c, 0, k), gam1 = gam_of(c, 1, k);
-            const float g_r1 = tid < 24 ? geo[3 * cj + ga1] : 0.f, g_r2 = tid < 24 ? geo[3 * cj + ga2] : 0.f;
-            const float g_dt = tid < 24 ? prm.dt * (cj < 4 ? gam0 : gam1) : 0.f;
-            const float F01 = geo[24 + ja1], F02 = geo[24 + ja2], F11 = geo[27 + ja1], F12 = geo[27 + ja2];
-            const float* Rj = c.sp + c.L.pR(jct) + 9 * k;
-            const float R0 = Rm(Rj, ja, 0), R1 = Rm(Rj, ja, 1), R2 = Rm(Rj, ja, 2);
-            const float dk = c.d[NS * k + j];
-            const float gamj = jct ? gam1 : gam0;
-            PROF2(20);
-            float4 xv[5];
+        } else {
 #pragma unroll
-            for (int t = 0; t < 5; ++t) xv[t] = *reinterpret_cast<const float4*>(xb + 20 * half + 4 * t);
-            float ya = 0.f, yc = 0.f;
+            for (int t = 0; t < 20; ++t) ym[t] = yp[t][REC_N * i];
 #pragma unroll
-            for (int t = 0; t < 5; ++t) {
-                ya += ym[4 * t] * xv[t].x + ym[4 * t + 2] * xv[t].z;
-                yc += ym[4 * t + 1] * xv[t].y + ym[4 * t + 3] * xv[t].w;
-            }
-            const float y = half_sum(ya + yc);
-            if (tid < 32) yb[r] = y;
-            wave_lds_sync();
-            PROF2(21);
-            float4 yv[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) yv[q] = *reinterpret_cast<const float4*>(yb + 16 * half + 4 * q);
-            const float w = (dot4(um[0], yv[0]) + dot4(um[1], yv[1])) + (dot4(um[2], yv[2]) + dot4(um[3], yv[3]));
-            const float du = -half_sum(w);
-            if (tid < NU) c.dU[NU * k + tid] = du;
-            wave_lds_sync();
-            PROF2(22);
-            // ---- ds+ = A ds + B du + d ----
-            const float* duk = c.dU + NU * k;
-            const int cb = tid < 24 ? 3 * cj : 0;
-            const float u0 = duk[cb + ga], u1 = duk[cb + ga1], u2 = duk[cb + ga2];
-            const float xs = xb[j], xe = xb[je];
-            const float c1 = xb[ja1], c2 = xb[ja2];
-            const float p01 = xb[9 + ja1], p02 = xb[9 + ja2], p11 = xb[12 + ja1], p12 = xb[12 + ja2];
-            const float q0 = duk[24 + 3 * jct], q1 = duk[25 + 3 * jct], q2 = duk[26 + 3 * jct];
-            const float tD = oct_sum(g_dt * u0);
-            const float tH = oct_sum(g_dt * (g_r1 * u2 - g_r2 * u1));
-            const float sD = ja == 0 ? readlane_f(tD, 0) : (ja == 1 ? readlane_f(tD, 8) : readlane_f(tD, 16));
-            const float sH = ja == 0 ? readlane_f(tH, 0) : (ja == 1 ? readlane_f(tH, 8) : readlane_f(tH, 16));
-            const float cross = gam0 * ((p01 - c1) * F02 - (p02 - c2) * F01) + gam1 * ((p11 - c1) * F12 - (p12 - c2) * F11);
-            const float land = R0 * q0 + R1 * q1 + R2 * q2;
-            float out = (isPos ? gamj : 1.f) * xs + ce * xe + cD * sD + cH * (sH + prm.dt * cross) + dk;
-            if (isPos) out += (1.f - gamj) * land;
-            wave_lds_sync();
-            if (tid < NS) { c.dS[NS * (k + 1) + tid] = out; xb[tid] = out; }
-            if (tid < NF) xb[16 + tid] = -Dm * du;
-            wave_lds_sync();
-            PROF2(23);
+            for (int t = 0; t < 4; ++t) um[t] = lds_ld4(upp[t] + REC_N * i);
         }
+        // stage data of the dynamics step (independent of the recursion as well)
+        const float g_r1 = gr1[GEO * i], g_r2 = gr2[GEO * i];
+        const float F01 = gf1[GEO * i], F11 = gf1[GEO * i + 3], F02 = gf2[GEO * i], F12 = gf2[GEO * i + 3];
+        const float gam0 = gm0[i], gam1 = gm1[i];
+        const float R0 = rp[9 * i], R1 = rp[9 * i + 3], R2 = rp[9 * i + 6];
+        const float dk = dp[NS * i];
+        const float dgam = gam1 - gam0;
+        const float g_dt = gdtm * fmaf(gsel, dgam, gam0);
+        const float gamj = fmaf(jsel, dgam, gam0);
+        PROF2(20);
+        float4 xv[5];
+#pragma unroll
+        for (int t = 0; t < 5; ++t) xv[t] = lds_ld4(xvp + 4 * t);
+        float ya = 0.f, yc = 0.f;
+#pragma unroll
+        for (int t = 0; t < 5; ++t) {
+            ya += ym[4 * t] * xv[t].x + ym[4 * t + 2] * xv[t].z;
+            yc += ym[4 * t + 1] * xv[t].y + ym[4 * t + 3] * xv[t].w;
+        }
+        const float y = half_sum(ya + yc);
+        *ybs = y;                       // (both halves hold the same y: the same value to the same word)
+        wave_lds_sync();
+        PROF2(21);
+        float4 yv[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) yv[q] = lds_ld4(yvp + 4 * q);
+        const float w = (dot4(um[0], yv[0]) + dot4(um[1], yv[1])) + (dot4(um[2], yv[2]) + dot4(um[3], yv[3]));
+        const float du = -half_sum(w);
+        *dUs = du;
+        dUs += dUst;
+        wave_lds_sync();
+        PROF2(22);
+        // ---- ds+ = A ds + B du + d ----
+        const float u0 = du0p[NU * i], u1 = du1p[NU * i], u2 = du2p[NU * i];
+        const float xs = *xsp, xe = *xep;
+        const float c1 = x1p[0], c2 = x2p[0];
+        const float p01 = x1p[9], p02 = x2p[9], p11 = x1p[12], p12 = x2p[12];
+        const float q0 = dqp[NU * i], q1 = dqp[NU * i + 1], q2 = dqp[NU * i + 2];
+        const float tD = oct_sum(g_dt * u0);
+        const float tH = oct_sum(g_dt * (g_r1 * u2 - g_r2 * u1));
+        // the three axis sums of both kinds, broadcast; every lane takes its own by 0/1 coefficients (a select on the lane's axis made the compiler branch
+        // around each v_readlane: 40 instructions of control flow per stage)
+        const float sDH = cDm0 * readlane_f(tD, 0) + cDm1 * readlane_f(tD, 8) + cDm2 * readlane_f(tD, 16)
+                          + cHm0 * readlane_f(tH, 0) + cHm1 * readlane_f(tH, 8) + cHm2 * readlane_f(tH, 16);
+        const float cross = gam0 * ((p01 - c1) * F02 - (p02 - c2) * F01) + gam1 * ((p11 - c1) * F12 - (p12 - c2) * F11);
+        const float land = R0 * q0 + R1 * q1 + R2 * q2;
+        // (position rows: gam ds_j + (1 - gam) R dq; the others: ds_j + ...)
+        const float out = fmaf(posm, gamj - 1.f, 1.f) * xs + ce * xe + sDH + cH * dtc * cross + dk + posm * (1.f - gamj) * land;
+        wave_lds_sync();
+        *dSs = out;
+        dSs += dSst;
+        *xbs = out;
+        *xps = -Dm * du;
+        wave_lds_sync();
+        PROF2(23);
+    };
+    auto bump = [&](int n) {
+        if (!G) {
+#pragma unroll
+            for (int t = 0; t < 20; ++t) yp[t] += REC_N * n;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) upp[t] += REC_N * n;
+        }
+        gr1 += GEO * n; gr2 += GEO * n; gf1 += GEO * n; gf2 += GEO * n; gm0 += n; gm1 += n; rp += 9 * n; dp += NS * n;
+        du0p += NU * n; du1p += NU * n; du2p += NU * n; dqp += NU * n;
+    };
+    int k = k0;
+#pragma unroll 1
+    for (; k + UNR <= N; k += UNR) {
+#pragma unroll
+        for (int i = 0; i < UNR; ++i) stage(i, k + i);
+        bump(UNR);
     }
+#pragma unroll 1
+    for (; k < N; ++k) {
+        stage(0, k);
+        bump(1);
+    }
+}
+template <int NT, int UNR, bool G, int PART = 0>
+__device__ void riccati_forward(const Ctx& c, const CmpcConsts& prm, int tid, bool affine, int k0)
+{
+    const int N = c.N;
+    if (PART != 2 && tid < 64) forward_sweep<UNR, G>(c, prm, tid, k0);
     if (PART == 1) return;
     __syncthreads();
     for (int e = tid + NI * k0; e < N * NI; e += NT) {

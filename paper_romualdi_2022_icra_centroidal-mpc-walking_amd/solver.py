@@ -37,7 +37,7 @@ def _c_config(cfg: CentroidalMPCConfig, tolerance=None, mu_min=None, max_iterati
     c.max_iterations = max_iterations or cfg.ipopt_max_iteration
     # the reference's ipopt_tolerance (1e-4 / 1e-2) is looser than the parity target; the GPU
     # solver always converges at least to 1e-6 so that its answer is reproducible to 1e-4
-    # (0: the library's default -- 1e-6 up to N = 20, 5e-7 beyond; step tolerance and barrier floor follow it)
+    # (0: the library's default -- 1e-6 up to N = 20, 3e-7 beyond; step tolerance and barrier floor follow it)
     c.tolerance = tolerance if tolerance is not None else (cfg.ipopt_tolerance if cfg.ipopt_tolerance < 5e-7 else 0.0)
     c.step_tolerance = step_tolerance if step_tolerance is not None else 0.0
     c.mu_init = mu_init if mu_init is not None else 0.0   # <= 0: per problem, from its initial infeasibility

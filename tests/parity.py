@@ -62,7 +62,7 @@ def limits(N):
     3e-6 .. 8e-6).  History of the N = 30 CoM velocity: round 2 allowed 5e-4 and measured 2.3e-4 (unloaded corners of the LAST stages sit
     sqrt(mu / curvature) inside their friction pyramid at the barrier floor: the tail polish of round 3 removed that); round 3 allowed 1.3e-4 and
     measured 1.05e-4 (what is left is fed by complementarity products that lag above the floor at termination); since round 4 the default
-    tolerance is 5e-7 beyond N = 20 (cmpc_create) and the limit is 1e-4 like everything else (profiles/r04_accuracy_sweep.txt)."""
+    tolerance is 3e-7 beyond N = 20 (cmpc_create) and the limit is 1e-4 like everything else (profiles/r04_accuracy_sweep.txt)."""
     return dict(com=TOL, force0=TOL, pos=TOL, forces=TOL, dcom=TOL, h=2e-5)
 
 
