@@ -2333,110 +2333,182 @@ __device__ void riccati_forward(const Ctx& c, const CmpcConsts& prm, int tid, bo
 // holds w (0 on inactive rows).  Updates lq (slot 15 of the Ws rows) in place through the stored factors.
 // Per stage:  g = C^T w + fp_p + B^T fp_s ;  dl = L^{-1} g ;  lq += dl ;
 //             fp_s <- A^T fp_s - Ws^T dl ;  fp_p <- D L^{-T} dl ----
-template <int UNR, bool G, int PART = 0>
-__device__ void riccati_delta(const Ctx& c, const CmpcConsts& prm, int tid)
+// (lean form like forward_sweep: operand pointers set up once and addressed as pointer + immediate inside a trip of UNR stages, unmasked stores)
+template <int UNR, bool G>
+__device__ __forceinline__ void delta_sweep(const Ctx& c, const CmpcConsts& prm, int tid)
 {
     const int N = c.N;
-    if (tid < 64) {
-        const int r = tid & 31, half = tid >> 5, blk = r >> 2;
-        float* gb = c.ybuf;        // g (32)
-        float* lb = c.ybuf + 32;   // dl (32)
-        // dl-step: column r of U against g, 16 terms per half;  fp-step: row r of U (lanes 0..31) or row r of WT
-        // (lanes 32..47) against dl
-        unsigned loff[16], foff[8];
+    const int r = tid & 31, half = tid >> 5, blk = r >> 2;
+    float* gb = c.ybuf;        // g (32)
+    float* lb = c.ybuf + 32;   // dl (32)
+    float* trash = c.ybuf + 72;
+    // dl-step: column r of U against g, 16 terms per half;  fp-step: row r of U (lanes 0..31) or row r of WT
+    // (lanes 32..47) against dl
+    unsigned loff[16], foff[8];
 #pragma unroll
-        for (int t = 0; t < 16; ++t) {
-            const int m = 16 * half + t;
-            loff[t] = blk >= (m >> 2) ? ub_row(m) + r - 4 * (m >> 2) : REC_ZERO;
-        }
+    for (int t = 0; t < 16; ++t) {
+        const int m = 16 * half + t;
+        loff[t] = blk >= (m >> 2) ? ub_row(m) + r - 4 * (m >> 2) : REC_ZERO;
+    }
 #pragma unroll
-        for (int q = 0; q < 8; ++q)
-            foff[q] = half == 0 ? (q >= blk ? ub_row(r) + 4 * (q - blk) : REC_ZERO) : (r < 16 ? REC_WT + 32 * r + 4 * (q ^ (r & 7)) : REC_ZERO);
-        // A^T row roles of lanes 32..46 (state index j = r): out = s v[j] + ce v[je] + cg (v[6+a1] F[a2] - v[6+a2] F[a1])
-        const int j = r;
-        const int ja = j < 3 ? j : (j >= 9 ? (j - 9) % 3 : 0), ja1 = (ja + 1) % 3, ja2 = (ja + 2) % 3;
-        const int jct = j >= 12 ? 1 : 0;
-        const int gfo = j < 3 ? 30 : 24 + 3 * jct;    // Fsum or Fc of the foot (geometry record)
-        const int je = (j >= 3 && j < 6) ? j - 3 : 0;
-        // B^T roles of lanes 0..29
-        const int fa = tid % 3, fa1 = (fa + 1) % 3, fa2 = (fa + 2) % 3, fcj = tid / 3;   // force component tid < 24
-        const int qq = tid - 24, qct = qq >= 3 ? 1 : 0, qa = qq - 3 * qct;               // offset component 24 <= tid < 30
-        const float Dm = prm.D[r % 3];
-        if (tid < NXA) c.fpv[tid] = 0.f;
-        if (tid < 32) { gb[tid] = 0.f; }
-        wave_lds_sync();
-        PROF2_DECL;
-#pragma unroll UNR
-        for (int k = N - 1; k >= 0; --k) {
+    for (int q = 0; q < 8; ++q)
+        foff[q] = half == 0 ? (q >= blk ? ub_row(r) + 4 * (q - blk) : REC_ZERO) : (r < 16 ? REC_WT + 32 * r + 4 * (q ^ (r & 7)) : REC_ZERO);
+    // A^T row roles of lanes 32..46 (state index j = r): out = s v[j] + ce v[je] + cg (v[6+a1] F[a2] - v[6+a2] F[a1]) - W^T dl
+    const bool hi = half == 1 && r < NS;
+    const int j = hi ? r : 0;
+    const int ja = j < 3 ? j : (j >= 9 ? (j - 9) % 3 : 0), ja1 = (ja + 1) % 3, ja2 = (ja + 2) % 3;
+    const int jct = j >= 12 ? 1 : 0;
+    const int gfo = j < 3 ? 30 : 24 + 3 * jct;    // Fsum or Fc of the foot (geometry record)
+    const int je = (j >= 3 && j < 6) ? j - 3 : 0;
+    const float him = hi ? 1.f : 0.f;
+    const float hposm = (hi && j >= 9) ? 1.f : 0.f, hce = (hi && j >= 3 && j < 6) ? prm.dt : 0.f;
+    const float hcg0 = (hi && j < 3) ? prm.dt : 0.f, hcg1 = (hi && j >= 9) ? -prm.dt : 0.f, hjsel = jct ? 1.f : 0.f;
+    // B^T roles of lanes 0..29: force components (lanes 0..23) and landing offsets (24..29)
+    const bool isF = tid < NF, isQ = tid >= NF && tid < NU;
+    const int fi = isF ? tid : 0;
+    const int fa = fi % 3, fa1 = (fa + 1) % 3, fa2 = (fa + 2) % 3, fcj = fi / 3;
+    const int qq = isQ ? tid - 24 : 0, qct = qq >= 3 ? 1 : 0, qa = qq - 3 * qct;
+    const float fsel = (fcj >> 2) ? 1.f : 0.f, qsel = qct ? 1.f : 0.f;
+    const float lom = half == 0 ? 1.f : 0.f;
+    const float Dm = prm.D[r % 3];
+    const float dtc = prm.dt, mu = prm.mu_fr;
+    if (tid < NXA) c.fpv[tid] = 0.f;
+    if (tid < 32) { gb[tid] = 0.f; }
+    wave_lds_sync();
+    // operand pointers of stage N-1 (they move DOWN by a stage at a time: a trip addresses stage k - i as pointer + (UNR-1-i) strides from the trip's lowest stage)
+    ldsf_t lp[16];
+    ldsf_t fpp[8];
+    const int kt = N - 1;
+    if (!G) {
+#pragma unroll
+        for (int t = 0; t < 16; ++t) lp[t] = lds_opaque(c.Lf + (size_t)REC_N * kt + loff[t]);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) fpp[q] = lds_opaque(c.Lf + (size_t)REC_N * kt + foff[q]);
+    }
+    ldsf_t wp = lds_opaque(c.dT + NI * kt + 4 * fcj);                       // the corner's four friction-row coefficients
+    ldsf_t wqp = lds_opaque(c.dT + NI * kt + 32 + qq);                      // upper / lower (+6) row of the offset
+    ldsf_t rfp = lds_opaque(c.sp + c.L.pR(fcj >> 2) + 9 * kt + fa);        // R(fa, 0..2) at +0, +3, +6
+    ldsf_t rqp = lds_opaque(c.sp + c.L.pR(qct) + 9 * kt + 3 * qa);         // R(0..2, qa) at +0, +1, +2
+    ldsf_t rr1 = lds_opaque(c.geoA + GEO * kt + 3 * fcj + fa1);
+    ldsf_t rr2 = lds_opaque(c.geoA + GEO * kt + 3 * fcj + fa2);
+    ldsf_t hf1 = lds_opaque(c.geoA + GEO * kt + gfo + ja1);
+    ldsf_t hf2 = lds_opaque(c.geoA + GEO * kt + gfo + ja2);
+    ldsf_t gm0 = lds_opaque(c.sp + c.L.pGam(0) + kt);
+    ldsf_t gm1 = lds_opaque(c.sp + c.L.pGam(1) + kt);
+    typedef __attribute__((address_space(3))) const int* ldsi_t;
+    ldsi_t qmp = (ldsi_t)(c.qmask + kt);
+    asm volatile("" : "+v"(qmp));
+    // fixed addresses in the costate buffer
+    ldsf_t vN = lds_opaque(c.fpv + NS + fi), v3 = lds_opaque(c.fpv + 3 + fa), v6a = lds_opaque(c.fpv + 6 + fa1), v6b = lds_opaque(c.fpv + 6 + fa2);
+    ldsf_t vq = lds_opaque(c.fpv + 9 + 3 * qct);
+    ldsf_t hvj = lds_opaque(c.fpv + j), hve = lds_opaque(c.fpv + je), hv1 = lds_opaque(c.fpv + 6 + ja1), hv2 = lds_opaque(c.fpv + 6 + ja2);
+    ldsf_t gbp = lds_opaque(gb + 16 * half), lbp = lds_opaque(lb);
+    ldsw_t gbs = lds_opaque_w(tid < NU ? gb + tid : trash + (tid & 7));
+    ldsw_t lbs = lds_opaque_w(lb + r);
+    ldsw_t fps = lds_opaque_w(half == 0 ? (tid < NF ? c.fpv + NS + tid : trash + 8 + (tid & 7)) : (hi ? c.fpv + j : trash + 16 + (tid & 7)));
+    // the lq row of the record (slot 15 of the Ws rows) takes dl
+    ldsw_t lqs = lds_opaque_w((!G && tid < NU) ? c.Lf + (size_t)REC_N * kt + wt_idx(15, tid) : trash + (tid & 7));
+    const int lqst = (!G && tid < NU) ? REC_N : 0;
+    PROF2_DECL;
+    auto stage = [&](int o, int k) {      // o: strides above the trip's lowest stage
+        float lm[16];
+        float4 fm[8];
+        if (G) {
             const RecRef<G> rec(c.Lf, N, k);
-            float lm[16];
-            float4 fm[8];
 #pragma unroll
             for (int t = 0; t < 16; ++t) lm[t] = rec.ld(loff[t]);
 #pragma unroll
             for (int q = 0; q < 8; ++q) fm[q] = rec.ld4(foff[q]);
-            const float* geo = c.geoA + GEO * k;
-            const float* wk = c.dT + NI * k;
-            const float gam0 = gam_of(c, 0, k), gam1 = gam_of(c, 1, k);
-            PROF2(24);
-            // ---- g ----
-            if (tid < NF) {
-                const float* R = c.sp + c.L.pR(fcj >> 2) + 9 * k;
-                const float w0 = wk[4 * fcj], w1 = wk[4 * fcj + 1], w2 = wk[4 * fcj + 2], w3 = wk[4 * fcj + 3];
-                // sum_f w_f R (sx_f, sy_f, -mu)^T,  (sx, sy) = (+,+), (-,+), (-,-), (+,-)
-                const float wx = w0 - w1 - w2 + w3, wy = w0 + w1 - w2 - w3, ws = w0 + w1 + w2 + w3;
-                float g = Rm(R, fa, 0) * wx + Rm(R, fa, 1) * wy - prm.mu_fr * Rm(R, fa, 2) * ws;
-                const float* rr = geo + 3 * fcj;
-                const float* v = c.fpv;
-                g += v[NS + tid] + prm.dt * (fcj < 4 ? gam0 : gam1) * (v[3 + fa] + v[6 + fa1] * rr[fa2] - v[6 + fa2] * rr[fa1]);
-                gb[tid] = g;
-            } else if (tid < NU) {
-                const float* R = c.sp + c.L.pR(qct) + 9 * k;
-                const float* v = c.fpv + 9 + 3 * qct;
-                float g = wk[32 + qq] - wk[38 + qq];
-                if (qfree(c, k, qq)) g += (1.f - (qct ? gam1 : gam0)) * (Rm(R, 0, qa) * v[0] + Rm(R, 1, qa) * v[1] + Rm(R, 2, qa) * v[2]);
-                gb[tid] = g;
-            }
-            wave_lds_sync();
-            PROF2(25);
-            // ---- dl = L^{-1} g ----
-            float4 gv[4];
+        } else {
 #pragma unroll
-            for (int t = 0; t < 4; ++t) gv[t] = *reinterpret_cast<const float4*>(gb + 16 * half + 4 * t);
-            float la = 0.f, lc = 0.f;
+            for (int t = 0; t < 16; ++t) lm[t] = lp[t][REC_N * o];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                la += lm[4 * t] * gv[t].x + lm[4 * t + 2] * gv[t].z;
-                lc += lm[4 * t + 1] * gv[t].y + lm[4 * t + 3] * gv[t].w;
-            }
-            const float dl = half_sum(la + lc);
-            if (tid < 32) lb[r] = dl;
-            if (tid < NU) { const unsigned lo = wt_idx(15, tid); rec.st(lo, rec.ld(lo) + dl); }
-            wave_lds_sync();
-            PROF2(26);
-            // ---- fp ----
-            float4 dv[8];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) dv[q] = *reinterpret_cast<const float4*>(lb + 4 * q);
-            const float s = ((dot4(fm[0], dv[0]) + dot4(fm[1], dv[1])) + (dot4(fm[2], dv[2]) + dot4(fm[3], dv[3])))
-                            + ((dot4(fm[4], dv[4]) + dot4(fm[5], dv[5])) + (dot4(fm[6], dv[6]) + dot4(fm[7], dv[7])));
-            float out = 0.f;
-            if (half == 0) out = k > 0 ? Dm * s : 0.f;
-            else if (j < NS) {
-                const float* v = c.fpv;
-                const float* F = geo + gfo;
-                const float sj = j >= 9 ? (jct ? gam1 : gam0) : 1.f;
-                const float ce = (j >= 3 && j < 6) ? prm.dt : 0.f;
-                const float cg = j < 3 ? prm.dt : (j >= 9 ? -prm.dt * sj : 0.f);
-                out = sj * v[j] + ce * v[je] + cg * (v[6 + ja1] * F[ja2] - v[6 + ja2] * F[ja1]) - s;
-            }
-            wave_lds_sync();
-            if (half == 0) { if (tid < NF) c.fpv[NS + tid] = out; }
-            else if (j < NS) c.fpv[j] = out;
-            wave_lds_sync();
-            PROF2(27);
+            for (int q = 0; q < 8; ++q) fm[q] = lds_ld4(fpp[q] + REC_N * o);
         }
+        const float gam0 = gm0[o], gam1 = gm1[o];
+        const float dgam = gam1 - gam0;
+        PROF2(24);
+        // ---- g = C^T w + fp_p + B^T fp_s: a force component (lanes 0..23) or a landing offset (24..29) ----
+        float g;
+        if (isF) {
+            const float w0 = wp[NI * o], w1 = wp[NI * o + 1], w2 = wp[NI * o + 2], w3 = wp[NI * o + 3];
+            // sum_f w_f R (sx_f, sy_f, -mu)^T,  (sx, sy) = (+,+), (-,+), (-,-), (+,-)
+            const float wx = w0 - w1 - w2 + w3, wy = w0 + w1 - w2 - w3, ws = w0 + w1 + w2 + w3;
+            g = rfp[9 * o] * wx + rfp[9 * o + 3] * wy - mu * rfp[9 * o + 6] * ws;
+            g += vN[0] + dtc * fmaf(fsel, dgam, gam0) * (v3[0] + v6a[0] * rr2[GEO * o] - v6b[0] * rr1[GEO * o]);
+        } else {
+            const float fr = (float)((qmp[o] >> qq) & 1);
+            g = wqp[NI * o] - wqp[NI * o + 6];
+            g += fr * (1.f - fmaf(qsel, dgam, gam0)) * (rqp[9 * o] * vq[0] + rqp[9 * o + 1] * vq[1] + rqp[9 * o + 2] * vq[2]);
+        }
+        *gbs = g;
+        wave_lds_sync();
+        PROF2(25);
+        // ---- dl = L^{-1} g ----
+        float4 gv[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) gv[t] = lds_ld4(gbp + 4 * t);
+        float la = 0.f, lc = 0.f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            la += lm[4 * t] * gv[t].x + lm[4 * t + 2] * gv[t].z;
+            lc += lm[4 * t + 1] * gv[t].y + lm[4 * t + 3] * gv[t].w;
+        }
+        const float dl = half_sum(la + lc);
+        *lbs = dl;                      // (both halves hold the same dl)
+        if (G) {
+            if (tid < NU) { const RecRef<G> rec(c.Lf, N, k); const unsigned lo = wt_idx(15, tid); rec.st(lo, rec.ld(lo) + dl); }
+        } else {
+            *lqs = *lqs + dl;
+            lqs -= lqst;
+        }
+        wave_lds_sync();
+        PROF2(26);
+        // ---- fp_s <- A^T fp_s - Ws^T dl (lanes 32..46);  fp_p <- D L^{-T} dl (lanes 0..23) ----
+        float4 dv[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) dv[q] = lds_ld4(lbp + 4 * q);
+        const float sm = ((dot4(fm[0], dv[0]) + dot4(fm[1], dv[1])) + (dot4(fm[2], dv[2]) + dot4(fm[3], dv[3])))
+                         + ((dot4(fm[4], dv[4]) + dot4(fm[5], dv[5])) + (dot4(fm[6], dv[6]) + dot4(fm[7], dv[7])));
+        const float gamj = fmaf(hjsel, dgam, gam0);
+        const float sj = fmaf(hposm, gamj - 1.f, 1.f);
+        const float cg = fmaf(hcg1, gamj, hcg0);
+        const float hiv = sj * hvj[0] + hce * hve[0] + cg * (hv1[0] * hf2[GEO * o] - hv2[0] * hf1[GEO * o]) - sm;
+        const float out = lom * (k > 0 ? Dm : 0.f) * sm + him * hiv;
+        wave_lds_sync();
+        *fps = out;
+        wave_lds_sync();
+        PROF2(27);
+    };
+    auto bump = [&](int n) {          // n stages down
+        if (!G) {
+#pragma unroll
+            for (int t = 0; t < 16; ++t) lp[t] -= REC_N * n;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) fpp[q] -= REC_N * n;
+        }
+        wp -= NI * n; wqp -= NI * n; rfp -= 9 * n; rqp -= 9 * n; rr1 -= GEO * n; rr2 -= GEO * n; hf1 -= GEO * n; hf2 -= GEO * n;
+        gm0 -= n; gm1 -= n; qmp -= n;
+    };
+    int k = N - 1;
+    // (the stages that do not fill a trip first, one at a time)
+#pragma unroll 1
+    for (; (k + 1) % UNR != 0; --k) {
+        stage(0, k);
+        bump(1);
     }
+#pragma unroll 1
+    for (; k >= UNR - 1; k -= UNR) {
+        bump(UNR - 1);               // to the trip's lowest stage
+#pragma unroll
+        for (int i = 0; i < UNR; ++i) stage(UNR - 1 - i, k - i);
+        bump(1);                     // to the stage below the trip
+    }
+}
+template <int UNR, bool G, int PART = 0>
+__device__ void riccati_delta(const Ctx& c, const CmpcConsts& prm, int tid)
+{
+    if (tid < 64) delta_sweep<UNR, G>(c, prm, tid);
     if (PART == 0) __syncthreads();
 }
 
@@ -2552,7 +2624,7 @@ __device__ void costate_update(const Ctx& c, const CmpcConsts& prm, int tid, flo
 // sweep (CMPC_SWEEP_WAVE0_ONLY); the barrier and the element-wise part behind it are a function of their own that needs no callee-saved
 // register.  (Inlining the sweeps into the kernel body instead was measured: 101 VGPRs of the body spilled, some inside the stage loops.)
 #ifndef CMPC_SWEEP_WAVE0_ONLY
-#define CMPC_SWEEP_WAVE0_ONLY(FG) (FG)
+#define CMPC_SWEEP_WAVE0_ONLY(FG) (1)
 #endif
 #ifndef CMPC_SWEEP_WAVE
 #define CMPC_SWEEP_WAVE 0   // which wave of an HBM-factor workgroup runs the sweeps (the sweep code sees tid - 64 * CMPC_SWEEP_WAVE)
@@ -2584,7 +2656,7 @@ template <int NT, int NC, bool FG, int PART>
 __device__ __attribute__((noinline)) void phase_delta_part(lds_t lds, int Nrt, float* fg_base)
 {
     CMPC_PHASE_PROLOGUE;
-    riccati_delta<NC == 0 ? 1 : (FG ? 2 : CMPC_SWEEP_UNROLL), FG, PART>(c, prm, PART == 1 ? tid - 64 * CMPC_SWEEP_WAVE : tid);
+    riccati_delta<NC == 0 ? 1 : 2, FG, PART>(c, prm, PART == 1 ? tid - 64 * CMPC_SWEEP_WAVE : tid);
 }
 template <int NT, int NC, bool FG>
 __device__ __forceinline__ void phase_delta(lds_t lds, int Nrt, float* fg_base)

@@ -502,4 +502,6 @@ def test_tail_polish_only_moves_the_tail(monkeypatch):
     assert np.abs(L.x_com(Xa)[:, :k0 + 1] - L.x_com(Xb)[:, :k0 + 1]).max() < 1e-5
     Xr = _oracle(cfg, P32[polished], X032[polished])
     wa, wb = _worst(cfg, P32[polished], Xa[polished], Xr), _worst(cfg, P32[polished], Xb[polished], Xr)
-    assert wb["forces"] < wa["forces"] and wb["dcom"] < wa["dcom"], (wa, wb)
+    # the polish is about the FORCES of the last knots (unloaded corners at the apex of their friction pyramid); the CoM velocity it leaves where the
+    # tolerance put it: since the default tolerance beyond N = 20 is 3e-7 that is 3..5e-5 with and without the polish (it used to improve with it at 1e-6)
+    assert wb["forces"] < wa["forces"] and wb["dcom"] < max(wa["dcom"], 0.6 * parity.TOL), (wa, wb)
