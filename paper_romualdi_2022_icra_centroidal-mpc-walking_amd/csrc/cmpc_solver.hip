@@ -20,16 +20,21 @@
 // rescaling, the backward sweep, one per sweep, step lengths, corrector targets, update + step norms, the last step (extrapolation + tail
 // polish), export.  Two variants: "resident" (512 threads, per-stage factor records in LDS, one workgroup per CU, B <= #CU) and
 // "HBM-factor" (256 threads, records in global scratch, three workgroups per CU).
-// Backward sweep of the resident variants: the streaming square-root stage (see CMPC_SQRT_BACKWARD and sq_consume_body) -- wave 0
-// factorises and publishes its columns block by block, waves 1-7 assemble the next stage's Z-independent part meanwhile and subtract
-// Z^T Z from it one MFMA tile per wave as the blocks come; one barrier per stage, one call per pass and role (sq_factor_loop,
-// sq_consume_loop).  Backward sweep of the HBM-factor variants: two calls per stage (stage_mid: phase 3; stage_post_pre: phase 4 and
-// phases 1-2 of the next stage), four barriers (wave numbers of the four-wave shape):
+// What bounds every single-wave phase is INSTRUCTION COUNT: a wave issues at most one instruction of any kind -- scalar bookkeeping and
+// exec-mask juggling included -- per four cycles (float64, conversions and transcendentals eight).  Hence, since round 4: the trailing updates
+// of the fused factorisation on the matrix pipe (v_mfma_f32_4x4x1 with A-block broadcast: no v_readlane at all), the consumers of the
+// streaming stage and the vector sweeps in "lean" form (everything fixed over a pass decoded once into per-lane plans / opaque LDS pointers,
+// straight-line stage bodies on clamped indices, unmasked stores).
+// Backward sweep of the resident variants: the streaming square-root stage (sq_factor_loop, sq_consume_loop) -- wave 0 factorises and
+// publishes its columns block by block, waves 1-7 assemble the next stage's Z-independent part meanwhile and subtract Z^T Z from it one
+// MFMA tile per wave as the blocks come; one barrier per stage, one call per pass and role.
+// Backward sweep of the HBM-factor variants: two calls per stage (stage_mid: phase 3; stage_post_pre: phase 4 and phases 1-2 of the next
+// stage), four barriers:
 //   1. G = P [B;E]                        sparse: every column of A, B has <= 3 non-zeros
 //   2. Quu, Qus (waves 0-1, float32), Quu diagonal blocks (wave 2, float64), Pd and qu (wave 3, float64)
-//   3. fused Cholesky + panel solve       waves 0-1, matrix rows in registers: lanes 0-29 hold the rows of
-//      Quu, lanes 30-63 rows of [Qus | I | qu]^T, so L^{-1}[Qus | I | qu] falls out of the same rank-3
-//      updates (3x3 pivot blocks in float64, v_readlane broadcasts, packed FMAs, no LDS traffic);
+//   3. fused Cholesky + panel solve       wave 0, matrix rows in registers: lanes 0-29 hold the rows of Quu, lanes 30-63 rows of
+//      [Qus | I | qu]^T (the identity rows of the last columns take over the lanes of finished L rows), so L^{-1}[Qus | I | qu] falls
+//      out of the same rank-3 updates (3x3 pivot blocks in float64, trailing updates on the matrix pipe, no LDS traffic);
 //      meanwhile waves 2-3 build Qss, qs and the column descriptors of the next stage
 //   4. P = [Qss 0; 0 D] - W^T W           30-term dot products on 16-byte LDS reads
 // The vector sweeps (forward, corrector right-hand side, costates) run on one wave without
@@ -51,22 +56,11 @@
 #define RLD 36     // leading dim of the row-major float panels (16-byte aligned rows)
 #define NPAN 46    // panel rows: 15 (Qus^T) + 30 (I) + 1 (qu)
 #define GEO 36     // floats of stage geometry: r[24] | Fc[6] | Fsum[3] | pad
-// the factorisation of phase 3 on one wave (1) or two (0), per variant (FG = factors in HBM, three workgroups per CU)
-#ifndef CMPC_ONE_WAVE_FACTOR
-#define CMPC_ONE_WAVE_FACTOR(FG) (FG)
-#endif
-#ifndef CMPC_PHASE4_MFMA
-#define CMPC_PHASE4_MFMA 1   // phase 4 (W^T W) of the resident variants on v_mfma_f32_16x16x4_f32; 0: the 2x2 register tiles on the VALU everywhere (A/B: DESIGN 6)
-#endif
-// "Square-root" backward stage of the resident eight-wave variants (CMPC_SQ): the value function P = [Qss 0; 0 D] - W^T W is never formed.
-// With T = [B~ A~] (39 x 45, <= 4 non-zeros per column) and Z = W T, the next stage's [Quu Qus; Qsu Qss], qu, qs are
-//   (cost / barrier terms + T^T [Qss 0; 0 D] T)  -  Z^T Z :
-// the bracket needs nothing of this stage's factorisation and is built by the idle waves WHILE it runs; what is left behind it is one sparse
-// row-combination pass (Z) and one 48 x 48 x 32 product on the matrix cores -- two phases and three barriers per stage instead of four and four.
-#ifndef CMPC_SQRT_BACKWARD
-#define CMPC_SQRT_BACKWARD 1
-#endif
-#define CMPC_SQ(NT, FG) (CMPC_SQRT_BACKWARD && !(FG) && (NT) >= 512)
+// Two backward stages.  HBM-factor variants (four waves, three workgroups per CU): the value-function stage, phases 1-4 above.  Resident variants (eight waves, one
+// workgroup per CU): the streaming SQUARE-ROOT stage -- the value function P = [Qss 0; 0 D] - W^T W is never formed.  With T = [B~ A~] (39 x 45, <= 4 non-zeros per
+// column) and Z = W T, the next stage's [Quu Qus; Qsu Qss], qu, qs are  (cost / barrier terms + T^T [Qss 0; 0 D] T)  -  Z^T Z : the bracket needs nothing of this
+// stage's factorisation and is built by the other waves WHILE it runs; what is left behind it is Z^T Z, one 16 x 16 tile per wave on the matrix cores as the pivot
+// blocks come out (see "The streaming square-root stage" below).
 #define SQ_TILE_WAVES 6        // consumer waves of the streaming stage that own a tile (and a share of the assembly): the two completion counts advance by this per stage
 #define SQ_SPIN_MAX (1 << 20)  // looks at a progress word or a count before a waiting wave gives up (raises the failure flag: the pass ends as a failed factorisation)
 #define SQ_PUB_FLOATS (10 * NPAN * 4 + 128 * 4)   // published W^T: ten pivot blocks x 46 panel rows x float4, and a slot per lane of two waves for lanes without a panel row
@@ -112,11 +106,11 @@ __device__ float g_trace[64 * 8];  // per iteration of workgroup 0: mu, ep, ec, 
 #define PROF(slot) do { long long n_ = __builtin_amdgcn_s_memtime(); if (threadIdx.x == 0 && blockIdx.x == 0) g_prof[slot] += n_ - pt_; pt_ = n_; } while (0)
 #define PROF2_DECL long long pt2_ = __builtin_amdgcn_s_memtime()
 // (first lane of the wave that builds qu / the diagonal blocks in phase 2: the wave numbers depend on the thread count NT)
-#define PROF3(slot) do { long long n_ = __builtin_amdgcn_s_memtime(); if (threadIdx.x == (NT >= 512 ? 320 : 192) && blockIdx.x == 0) g_prof[slot] += n_ - pt2_; pt2_ = n_; } while (0)
-#define PROF4(slot) do { long long n_ = __builtin_amdgcn_s_memtime(); if (threadIdx.x == (NT >= 512 ? 256 : 128) && blockIdx.x == 0) g_prof[slot] += n_ - pt2_; pt2_ = n_; } while (0)
+#define PROF3(slot) do { long long n_ = __builtin_amdgcn_s_memtime(); if (threadIdx.x == 192 && blockIdx.x == 0) g_prof[slot] += n_ - pt2_; pt2_ = n_; } while (0)
+#define PROF4(slot) do { long long n_ = __builtin_amdgcn_s_memtime(); if (threadIdx.x == 128 && blockIdx.x == 0) g_prof[slot] += n_ - pt2_; pt2_ = n_; } while (0)
 #define PROF2(slot) do { long long n_ = __builtin_amdgcn_s_memtime(); if (threadIdx.x == 0 && blockIdx.x == 0) g_prof[slot] += n_ - pt2_; pt2_ = n_; } while (0)
 // (first lane of the value-gradient wave of phase 4)
-#define PROF5(slot) do { long long n_ = __builtin_amdgcn_s_memtime(); if (threadIdx.x == (NT >= 512 ? 448 : 216) && blockIdx.x == 0) g_prof[slot] += n_ - pt2_; pt2_ = n_; } while (0)
+#define PROF5(slot) do { long long n_ = __builtin_amdgcn_s_memtime(); if (threadIdx.x == 216 && blockIdx.x == 0) g_prof[slot] += n_ - pt2_; pt2_ = n_; } while (0)
 // fire-and-forget stamp of the consumer waves (no wait on the atomic): slot 32 + 5 * wave + i
 #define CPROF(i) do { if (ln == 0 && blockIdx.x == 0 && k < N) atomicAdd(reinterpret_cast<unsigned long long*>(&g_prof[32 + 5 * wv + (i)]), (unsigned long long)(__builtin_amdgcn_s_memtime() - pc0_)); } while (0)
 // finer stamps of the consumers (slots 64 + 8 * wave + i)
@@ -772,11 +766,11 @@ struct RowStore {
     }
 };
 // pivot block B (columns 3 B .. 3 B + 2).  Returns true if a pivot was not positive.
-template <int B, bool ONE, bool PUB, typename ST>
+template <int B, bool PUB, typename ST>
 __device__ __forceinline__ bool chol_block(v4f (&acc)[8], double (&dd)[3], int lane, int fixedmask, CholPub& pb, ST& st)
 {
     constexpr int j0 = 3 * B;
-    if (ONE && B == LATE_B) {
+    if (B == LATE_B) {
         if (lane < NLATE) {
             const float* idr = pb.idstrip + id_row(LATE_M0 + lane);
 #pragma unroll
@@ -860,22 +854,22 @@ __device__ __forceinline__ bool chol_block(v4f (&acc)[8], double (&dd)[3], int l
     return bad;
 }
 // ---- fused Cholesky + panel solve, one wave, rows in registers, 3x3 pivot blocks (see the comment block above rcp_d) ----
-template <bool ONE, bool PUB, typename ST>
+template <bool PUB, typename ST>
 __device__ __forceinline__ bool chol_solve_fused(v4f (&acc)[8], double (&dd)[3], int lane, int fixedmask, ST& st, const float* idstrip, float* pub = nullptr,
                                                  int pubstride = 0, int* pflag = nullptr, int seq0 = 0, float* publate = nullptr)
 {
     CholPub pb{pub, pubstride, pflag, seq0, publate, idstrip};
     bool bad = false;
-    bad |= chol_block<0, ONE, PUB>(acc, dd, lane, fixedmask, pb, st);
-    bad |= chol_block<1, ONE, PUB>(acc, dd, lane, fixedmask, pb, st);
-    bad |= chol_block<2, ONE, PUB>(acc, dd, lane, fixedmask, pb, st);
-    bad |= chol_block<3, ONE, PUB>(acc, dd, lane, fixedmask, pb, st);
-    bad |= chol_block<4, ONE, PUB>(acc, dd, lane, fixedmask, pb, st);
-    bad |= chol_block<5, ONE, PUB>(acc, dd, lane, fixedmask, pb, st);
-    bad |= chol_block<6, ONE, PUB>(acc, dd, lane, fixedmask, pb, st);
-    bad |= chol_block<7, ONE, PUB>(acc, dd, lane, fixedmask, pb, st);
-    bad |= chol_block<8, ONE, PUB>(acc, dd, lane, fixedmask, pb, st);
-    bad |= chol_block<9, ONE, PUB>(acc, dd, lane, fixedmask, pb, st);
+    bad |= chol_block<0, PUB>(acc, dd, lane, fixedmask, pb, st);
+    bad |= chol_block<1, PUB>(acc, dd, lane, fixedmask, pb, st);
+    bad |= chol_block<2, PUB>(acc, dd, lane, fixedmask, pb, st);
+    bad |= chol_block<3, PUB>(acc, dd, lane, fixedmask, pb, st);
+    bad |= chol_block<4, PUB>(acc, dd, lane, fixedmask, pb, st);
+    bad |= chol_block<5, PUB>(acc, dd, lane, fixedmask, pb, st);
+    bad |= chol_block<6, PUB>(acc, dd, lane, fixedmask, pb, st);
+    bad |= chol_block<7, PUB>(acc, dd, lane, fixedmask, pb, st);
+    bad |= chol_block<8, PUB>(acc, dd, lane, fixedmask, pb, st);
+    bad |= chol_block<9, PUB>(acc, dd, lane, fixedmask, pb, st);
     if constexpr (ST::EARLY) {
         st.template chunk<6>(acc[6]);
         st.template chunk<7>(acc[7]);
@@ -885,7 +879,7 @@ __device__ __forceinline__ bool chol_solve_fused(v4f (&acc)[8], double (&dd)[3],
 
 // phase 3 of a backward stage, kept out of line so that its ~40 VGPRs of matrix rows and its
 // stream of v_readlane broadcasts get a register allocation of their own
-template <bool ONE, bool G, bool PUB = false>
+template <bool G, bool PUB = false>
 __device__ __forceinline__ void stage_factor(const float* QuuF, const double* QuuD, float* Pan, const RecRef<G>& rec, const float* idstrip,
                                           const float* Dp, int* flag, int tid, int fixedmask, float* pub = nullptr, int* pflag = nullptr, int seq0 = 0)
 {
@@ -893,7 +887,7 @@ __device__ __forceinline__ void stage_factor(const float* QuuF, const double* Qu
     // panel row of lanes >= 30.  Two waves: rows 0..33 on wave 0, 34..45 on wave 1 (both repeat the L rows).  One wave: Qus rows
     // 0..14, the qu row (NPAN - 1), identity rows m = 0..17; identity rows 18..29 take over lanes 0..11 at block LATE_B.
     const int pi = lane - 30;
-    const int prow = ONE ? (pi < NS ? pi : (pi == NS ? NPAN - 1 : pi - 1)) : pi + 34 * wv;
+    const int prow = pi < NS ? pi : (pi == NS ? NPAN - 1 : pi - 1);
     const bool isL = lane < NU;
     const bool active = isL || prow < NPAN;
     v4f acc[8];
@@ -921,14 +915,14 @@ __device__ __forceinline__ void stage_factor(const float* QuuF, const double* Qu
     RowStore<G, PUB> st(rec, Pan, Dp);
     typedef RowStore<G, PUB> ST;
     if (ST::EARLY && !isL && active) st.set_row(prow);
-    const bool bad = chol_solve_fused<ONE, PUB>(acc, dd, lane, fixedmask, st, idstrip, pubp, (!isL && active) ? NPAN * 4 : 0, pflag, seq0,
+    const bool bad = chol_solve_fused<PUB>(acc, dd, lane, fixedmask, st, idstrip, pubp, (!isL && active) ? NPAN * 4 : 0, pflag, seq0,
                                                 PUB ? pub + (NS + LATE_M0 + (lane < NLATE ? lane : 0)) * 4 : nullptr);
     PROF2(29);
     if (bad && tid == 0) *flag = 1;
     if constexpr (!ST::EARLY) {
         // (records in HBM: every chunk after the last block, and nothing of the store's addressing alive across the block loop -- the 168-register
         //  variants have no room for it: held there it pushed stage_mid into the callee-saved registers and their scratch saves)
-        const bool late = ONE && lane < NLATE;             // this lane now holds identity row LATE_M0 + lane
+        const bool late = lane < NLATE;                    // this lane now holds identity row LATE_M0 + lane
         if (late || (!isL && active)) {
             st.set_row(late ? NS + LATE_M0 + lane : prow);
             st.template chunk<0>(acc[0]); st.template chunk<1>(acc[1]); st.template chunk<2>(acc[2]); st.template chunk<3>(acc[3]);
@@ -1100,23 +1094,12 @@ __device__ inline void stage_pre_body(const Ctx& c, const CmpcConsts& prm, int t
     const bool pk = k > 0;
     const float* u = c.U + NU * k;
     PROF_DECL;
-        // ---- phase 1: G = P [B;E] (39 x 30): thread <-> column, its three non-zeros in registers, rows strided over RG
-        // row groups (8 with 256 threads, 16 with 512) ----
+        // ---- phase 1: G = P [B;E] (39 x 30): thread <-> column, its three non-zeros in registers, rows strided over RG = 8
+        // row groups ----
         {
-            // (eight waves: 14 row groups = 420 threads -- three rows each, as with 16 -- leave the last wave free for Pd = P [d; 0] + pv in float64,
-            // which phase 2's qu wave would otherwise compute first: the longest chain of phase 2, measured 1.97 k of its 2.4 k cycles)
-            constexpr int RG = NT >= 512 ? 14 : NT / 32, RR = (NXA + RG - 1) / RG;
+            constexpr int RG = NT / 32, RR = (NXA + RG - 1) / RG;
             const int nrow = havep ? NXA : NS;
-            if (NT >= 512 && tid >= 448) {
-                const int r = tid - 448;
-                if (r < NXA) {
-                    double acc = 0.0;
-#pragma unroll
-                    for (int a = 0; a < NS; ++a) acc += (double)Pcur[a * PLD + r] * (double)c.d[NS * k + a];   // (P holds both triangles: row a, column r)
-                    const double pvr = c.pv[r];
-                    c.Pd[r] = (r < NS || havep) ? pvr + acc : pvr;   // (rows >= NS of the terminal P do not exist: discarded)
-                }
-            } else if (tid < RG * NU) {
+            if (tid < RG * NU) {
                 const int i = tid % NU, r0 = tid / NU;
                 const int b0 = c.Brow[3 * i], b1 = c.Brow[3 * i + 1], b2 = c.Brow[3 * i + 2];
                 const float w0 = c.Bval[3 * i], w1 = c.Bval[3 * i + 1], w2 = c.Bval[3 * i + 2];
@@ -1139,11 +1122,9 @@ __device__ inline void stage_pre_body(const Ctx& c, const CmpcConsts& prm, int t
         // its 3x3 diagonal blocks and the 450 of the panel rows Qus^T.  Wave 2: the diagonal blocks of Quu in float64
         // (cost, barrier and Levenberg terms).  Wave 3: qu in float64. ----
         PROF2_DECL;
-        // (512 threads: waves 0-3 one round of triples, wave 4 the diagonal blocks, wave 5 Pd and qu; waves 6-7 idle here)
-        constexpr int T2 = NT >= 512 ? 256 : 128;    // threads on the float32 triples
+        constexpr int T2 = 128;    // threads on the float32 triples
         if (tid < T2) {
-            if (NT >= 512) quu_qus_triples<1>(c, prm, k, havep, tid, tpk);
-            else quu_qus_triples<2>(c, prm, k, havep, tid, tpk);   // triples 0..255; the next wave takes 256..284 after its float64 blocks
+            quu_qus_triples<2>(c, prm, k, havep, tid, tpk);   // triples 0..255; the next wave takes 256..284 after its float64 blocks
             PROF2(5);
         } else if (tid < T2 + 64) {
           // ---- the ten 3x3 diagonal blocks of Quu in float64 (60 lower entries).  Branch-free on clamped indices so that all
@@ -1185,7 +1166,7 @@ __device__ inline void stage_pre_body(const Ctx& c, const CmpcConsts& prm, int t
             c.QuuF[i * RLD + j] = 0.f;  // the float copy of a diagonal block collects the updates by earlier blocks
             PROF4(7);
           }
-          if (NT < 512 && t < 285 - 256) quu_qus_triples<1>(c, prm, k, havep, 256 + t, 0);
+          if (t < 285 - 256) quu_qus_triples<1>(c, prm, k, havep, 256 + t, 0);
         } else if (tid < T2 + 128) {
           // ---- Pd = P [d; 0] + pv (float64), then qu, which reads it (same wave: LDS order suffices).  Every lane of the wave
           // computes both on clamped indices, branch-free: two levels of loads instead of a chain of small dependent ones ----
@@ -1212,7 +1193,7 @@ __device__ inline void stage_pre_body(const Ctx& c, const CmpcConsts& prm, int t
           const bool fr = qfree(c, k, q);
           const int b0 = c.Brow[3 * iq], b1 = c.Brow[3 * iq + 1], b2 = c.Brow[3 * iq + 2];
           const double w0 = c.Bval[3 * iq], w1 = c.Bval[3 * iq + 1], w2 = c.Bval[3 * iq + 2];
-          if (NT < 512) {   // (eight waves: done in phase 1 on a wave of its own)
+          {
             double acc = 0.0;
 #pragma unroll
             for (int a = 0; a < NS; ++a) acc += (double)pc[a] * (double)dc[a];
@@ -1236,8 +1217,6 @@ __device__ inline void stage_pre_body(const Ctx& c, const CmpcConsts& prm, int t
             c.Pan[(NPAN - 1) * RLD + iq] = (float)g;
             PROF3(8);
           }
-        } else if (NT >= 512 && tid >= T2 + 128 && tid < T2 + 128 + 285 - 256) {
-          quu_qus_triples<1>(c, prm, k, havep, 256 + tid - (T2 + 128), 0);   // (eight waves: the last 29 triples on an idle wave)
         }
         __syncthreads();
         PROF(2);
@@ -1271,71 +1250,10 @@ __device__ inline void stage_post_body(const Ctx& c, const CmpcConsts& prm, int 
     const float* u = c.U + NU * k;
     PROF_DECL;
         // ---- phase 4: P = [Qss 0; 0 D] - W^T W  (rows of the panel are W^T rows; p rows pre-scaled by -D) ----
-        // W^T W on the matrix cores in the resident variants (eight waves, one problem per CU: latency counts): the stage's Schur-complement
-        // ("condensing") GEMM, 39 x 39 x 30 -- v_mfma_f32_16x16x4_f32, the six lower-triangle 16 x 16 tiles of the 48 x 48 cover, one tile per
-        // wave.  Both operands of a tile are rows of the panel (row i = column i of W, 32 floats with columns 30, 31 stored as zeros), so lane
-        // (m = lane & 15, kq = lane >> 4) reads TWO float4 per operand -- panel row 16 I + m, floats 4 kq .. 4 kq + 3 and 16 + 4 kq .. -- and
-        // feeds component t of them to MFMA t: the K index a lane group supplies is then a = 4 kq + t (+ 16), the same map for A and B, and the
-        // eight MFMAs cover a = 0 .. 31 once (two accumulators of four: the dependent latency of 40 cycles sits behind the 32-cycle issue).
-        // Result of lane (m, kq), register i: P[16 I + 4 kq + i][16 J + m].  Every LDS read of the tile -- operands and the four values the
-        // products are subtracted from -- is issued before the first wait, branch-free on clamped indices.  Measured (B = 256, phase 4 per
-        // whole solve, A/B inside one gpurun call): +1.6 % against the 2x2 register tiles (32 ds_read_b128 + 120 FMA per thread), see DESIGN 6;
-        // the value gradient keeps its own wave (folded into row 45 of the tiles (2, J) -- the lq row of the panel -- it lengthens those
-        // tiles' epilogue by more than the wave it frees: measured +0.1 % instead of +1.6 %).  The HBM-factor variants (four waves, three workgroups per CU: throughput counts) keep the register tiles: six tiles of a
-        // 48 x 48 cover are twice the arithmetic of the 39 x 39 triangle and two of them per wave -- measured -1.5 % there.
-        if (CMPC_PHASE4_MFMA && !LEAN) {
-            PROF2_DECL;
-            const bool pk4 = k > 0;
-            const int wv4 = tid >> 6, ln = tid & 63, m4 = ln & 15, kq = ln >> 4;
-            const int ncol4 = pk4 ? NXA : NS, ntile = pk4 ? 6 : 1;   // (the first stage of the horizon keeps a 15 x 15 value function)
-            typedef float v4f __attribute__((ext_vector_type(4)));
-            const float D0 = prm.D[0], D1 = prm.D[1], D2 = prm.D[2];
-            for (int t = wv4; t < ntile; t += NT / 64) {
-                const int I = t >= 3 ? 2 : (t >= 1 ? 1 : 0), J = t - I * (I + 1) / 2;
-                const int i0 = 16 * I + 4 * kq, jj = 16 * J + m4;
-                const float* ra = c.Pan + (16 * I + m4) * RLD + 4 * kq;
-                const float* rb = c.Pan + (16 * J + m4) * RLD + 4 * kq;
-                const float4 a0 = *reinterpret_cast<const float4*>(ra), a1 = *reinterpret_cast<const float4*>(ra + 16);
-                const float4 b0 = *reinterpret_cast<const float4*>(rb), b1 = *reinterpret_cast<const float4*>(rb + 16);
-                // what the products are subtracted from: Qss (rows < 15), D on the diagonal of the force block, 0 elsewhere
-                float bs[4];
-                const int jc = jj < NS ? jj : NS;                    // (Qb rows are 16 floats: column 15 is padding)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int ii = i0 + i;
-                    const float qb = Qb[(ii < NS ? ii : NS - 1) * 16 + jc];
-                    const int r3 = ii - 3 * ((ii * 43) >> 7);        // ii % 3 (= (ii - NS) % 3: NS is a multiple of 3)
-                    const float dd = r3 == 0 ? D0 : (r3 == 1 ? D1 : D2);
-                    bs[i] = ii < NS ? qb : (ii == jj ? dd : 0.f);
-                }
-                v4f c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
-                c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, b0.x, c0, 0, 0, 0);
-                c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, b1.x, c1, 0, 0, 0);
-                c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, b0.y, c0, 0, 0, 0);
-                c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, b1.y, c1, 0, 0, 0);
-                c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, b0.z, c0, 0, 0, 0);
-                c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, b1.z, c1, 0, 0, 0);
-                c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, b0.w, c0, 0, 0, 0);
-                c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, b1.w, c1, 0, 0, 0);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int ii = i0 + i;
-                    if (jj <= ii && ii < ncol4) {
-                        const float r = bs[i] - (c0[i] + c1[i]);
-                        Pnew[ii * PLD + jj] = r;
-                        Pnew[jj * PLD + ii] = r;
-                    }
-                }
-            }
-            PROF2(18);
-        } else
         {
-            // 2x2 output tiles: thread <-> tile (bi, bj), bj <= bi, of the 39x39 (or 15x15) lower triangle.  With 512 threads
-            // a tile belongs to a pair of lanes: each takes half of the 30-term dot products (four of the eight float4
-            // columns), the halves meet through one DPP swap, each lane stores one row of the tile.
+            // 2x2 output tiles: thread <-> tile (bi, bj), bj <= bi, of the 39x39 (or 15x15) lower triangle.
             const int nb = pk ? 20 : 8;
-            constexpr bool SPLIT = NT >= 512;
-            const int tile = SPLIT ? (tid >> 1) : tid, khalf = SPLIT ? (tid & 1) : 0;
+            const int tile = tid;
             if (tile < nb * (nb + 1) / 2) {
                 const int t = (tqp >> 16) & 0xffff;   // tri[tile]
                 const int bi = t >> 8, bj = t & 255;
@@ -1351,22 +1269,7 @@ __device__ inline void stage_post_body(const Ctx& c, const CmpcConsts& prm, int 
                 };
                 const float b00 = base_of(i0, j0), b01 = base_of(i0, j0 + 1), b10 = base_of(i0 + 1, j0), b11 = base_of(i0 + 1, j0 + 1);
                 float a00 = 0.f, a01 = 0.f, a10 = 0.f, a11 = 0.f;
-                if (SPLIT) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int q4 = 4 * khalf + q;
-                        const float4 x0 = ri0[q4], x1 = ri1[q4], y0 = rj0[q4], y1 = rj1[q4];
-                        a00 += (x0.x * y0.x + x0.y * y0.y) + (x0.z * y0.z + x0.w * y0.w);
-                        a01 += (x0.x * y1.x + x0.y * y1.y) + (x0.z * y1.z + x0.w * y1.w);
-                        a10 += (x1.x * y0.x + x1.y * y0.y) + (x1.z * y0.z + x1.w * y0.w);
-                        a11 += (x1.x * y1.x + x1.y * y1.y) + (x1.z * y1.z + x1.w * y1.w);
-                    }
-                    // the other half from the neighbouring lane (quad_perm [1,0,3,2])
-                    a00 += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(a00), 0xB1, 0xF, 0xF, true));
-                    a01 += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(a01), 0xB1, 0xF, 0xF, true));
-                    a10 += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(a10), 0xB1, 0xF, 0xF, true));
-                    a11 += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(a11), 0xB1, 0xF, 0xF, true));
-                } else if (LEAN) {
+                {
                     // The 168-register variants (three workgroups per CU) take the 32 row loads in two rounds: hoisted all
                     // at once they need the callee-saved registers, and saving those at every call of this function was
                     // 18 GB of scratch traffic per 4096-problem batch (columns 30, 31 of the panel are stored as zeros).
@@ -1382,17 +1285,6 @@ __device__ inline void stage_post_body(const Ctx& c, const CmpcConsts& prm, int 
                             a11 += (x1.x * y1.x + x1.y * y1.y) + (x1.z * y1.z + x1.w * y1.w);
                         }
                     }
-                } else {
-#pragma unroll
-                for (int q4 = 0; q4 < 8; ++q4) {
-                    const float4 x0 = ri0[q4], x1 = ri1[q4], y0 = rj0[q4], y1 = rj1[q4];
-                    a00 += x0.x * y0.x + x0.y * y0.y; a01 += x0.x * y1.x + x0.y * y1.y;
-                    a10 += x1.x * y0.x + x1.y * y0.y; a11 += x1.x * y1.x + x1.y * y1.y;
-                    if (q4 < 7) {  // columns 30, 31 are padding
-                        a00 += x0.z * y0.z + x0.w * y0.w; a01 += x0.z * y1.z + x0.w * y1.w;
-                        a10 += x1.z * y0.z + x1.w * y0.w; a11 += x1.z * y1.z + x1.w * y1.w;
-                    }
-                }
                 }
                 auto put = [&](int i, int j, float base, float acc) {
                     if (j > i || i >= ncol) return;
@@ -1400,16 +1292,15 @@ __device__ inline void stage_post_body(const Ctx& c, const CmpcConsts& prm, int 
                     Pnew[i * PLD + j] = r;
                     Pnew[j * PLD + i] = r;
                 };
-                if (!SPLIT || khalf == 0) { put(i0, j0, b00, a00); put(i0, j0 + 1, b01, a01); }
-                if (!SPLIT || khalf == 1) { put(i0 + 1, j0, b10, a10); put(i0 + 1, j0 + 1, b11, a11); }
+                put(i0, j0, b00, a00); put(i0, j0 + 1, b01, a01);
+                put(i0 + 1, j0, b10, a10); put(i0 + 1, j0 + 1, b11, a11);
             }
         }
         {
             PROF2_DECL;
-            constexpr bool SPLIT = NT >= 512;
             // gradient of the value function (float64)
             const int ncol = pk ? NXA : NS;
-            constexpr int TG = SPLIT ? 448 : 216;    // threads beyond the tile owners (210, or 420 with split tiles)
+            constexpr int TG = 216;    // threads beyond the 210 tile owners
             if (tid >= TG && tid < TG + NXA) {
                 const int i = tid - TG;
                 double v = 0.0;
@@ -1481,9 +1372,9 @@ __device__ __attribute__((noinline)) void stage_mid(lds_t lds, int Nrt, float* f
     const int k = __builtin_amdgcn_readfirstlane(k_in);
     const bool use_exact = __builtin_amdgcn_readfirstlane((int)exact_in) != 0;
     PROF_DECL;
-    if (tid < (CMPC_ONE_WAVE_FACTOR(FG) ? 64 : 128)) {
+    if (tid < 64) {
         const int fixedmask = (~c.qmask[k]) & 63;
-        stage_factor<CMPC_ONE_WAVE_FACTOR(FG), FG>(c.QuuF, c.QuuD, c.Pan, RecRef<FG>(c.Lf, N, k), c.idstrip, prm.D, c.flag, tid, fixedmask);
+        stage_factor<FG>(c.QuuF, c.QuuD, c.Pan, RecRef<FG>(c.Lf, N, k), c.idstrip, prm.D, c.flag, tid, fixedmask);
     } else if (tid >= 128) {
         use_desc_set(c, k & 1);
         stage_qss_body<NT>(c, prm, tid, k, c.P0, c.Qb, tqp);
@@ -1577,7 +1468,7 @@ __device__ __attribute__((noinline)) void sq_factor_loop(lds_t lds, int Nrt, flo
         const int fixedmask = (~c.qmask[k]) & 63;
         SQPROF_DECL;
         // (one wave: its second SIMD's worth of issue slots goes to the consumers -- the eight-wave shape is bound by what waves 1-7 can issue under the factorisation)
-        stage_factor<true, FG, true>(c.QuuF + s * MSET, s ? c.QuuD1 : c.QuuD, c.Pan + s * MSET, RecRef<FG>(c.Lf, N, k), c.idstrip, prm.D, c.flag, tid,
+        stage_factor<FG, true>(c.QuuF + s * MSET, s ? c.QuuD1 : c.QuuD, c.Pan + s * MSET, RecRef<FG>(c.Lf, N, k), c.idstrip, prm.D, c.flag, tid,
                                      fixedmask, c.ZT, c.prog + tid, 16 * ord);
         SQPROF(9);         // (wave 0: the factorisation alone)
         __syncthreads();
@@ -2092,7 +1983,7 @@ __device__ inline int riccati_backward_sq(lds_t lds, const Ctx& c, float* fg_bas
 template <int NT, int NC, bool FG>
 __device__ int riccati_backward(lds_t lds, const Ctx& c, const CmpcConsts& prm, int tid, float* fg_base, bool use_exact, float reg, float cmu, int k0 = 0)
 {
-    if constexpr (CMPC_SQ(NT, FG)) return riccati_backward_sq<NT, NC, FG>(lds, c, fg_base, use_exact, reg, cmu, k0);
+    if constexpr (!FG) return riccati_backward_sq<NT, NC, FG>(lds, c, fg_base, use_exact, reg, cmu, k0);   // (resident variants: the streaming square-root stage)
     const int N = c.N;
     for (int e = tid; e < NXA * PLD; e += NT) c.P0[e] = 0.f;
     if (tid == 0) *c.flag = 0;
@@ -2109,8 +2000,8 @@ __device__ int riccati_backward(lds_t lds, const Ctx& c, const CmpcConsts& prm, 
     int tpk, tqp;
     {
         const int id0 = tid, id1 = tid + 128;                       // (ids >= 135 are panel triples: no look-up)
-        tpk = (id0 < 135 ? c.tri[id0 / 3] : 0) | ((NT < 512 && id1 < 135 ? c.tri[id1 / 3] : 0) << 16);
-        const int tq = tid - 128, tile = NT >= 512 ? tid >> 1 : tid;
+        tpk = (id0 < 135 ? c.tri[id0 / 3] : 0) | ((id1 < 135 ? c.tri[id1 / 3] : 0) << 16);
+        const int tq = tid - 128, tile = tid;
         tqp = ((tq >= 0 && tq < 120) ? c.tri[tq] : 0) | ((tile < 210 ? c.tri[tile] : 0) << 16);
     }
     // P0 holds the value function of stage k+1 and is overwritten in place by phase 4 (its last reader, Qss, ran in phase 3)
