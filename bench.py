@@ -160,6 +160,46 @@ class Runner:
         self.dist.all_gather(out, t)
         return [o.cpu().tolist() for o in out]
 
+    def _timed(self, solver, step, gather, steps, warmup, dP, dX0, dX, dInfo):
+        """warm-up steps, then the timed region; returns (elapsed seconds: max over ranks, launch durations in ms, all-gather ms or None)"""
+        torch = self.torch
+        for _ in range(warmup):
+            step()
+        # Launch duration by HIP events on the stream the kernel is launched on.  An event record is a barrier packet on the stream: four per step (the
+        # library's own pair, cmpc_last_solve_ms, and a pair here) left 36 us between back-to-back launches of the 0.85 ms kernel (rocprofv3 kernel trace,
+        # tools/gpu_launch_gaps.sh).  So the library's pair is switched off for the timed region (cmpc_set_timing), and without a collective between the
+        # launches ONE pair brackets all of them: launch duration = that / steps (it includes the dispatch gap between launches).  With a collective
+        # between the launches every launch keeps a pair of its own.
+        solver.set_timing(False)
+        ks = solver.launch_stream
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2 * steps if self.coll else 2)]
+        self.barrier()
+        t0 = time.perf_counter()
+        if self.coll:
+            for i in range(steps):
+                ev[2 * i].record(ks)
+                solver.solve_device(dP, dX0, dX, dInfo)
+                ev[2 * i + 1].record(ks)
+                gather()
+        else:
+            ev[0].record(ks)
+            for i in range(steps):
+                solver.solve_device(dP, dX0, dX, dInfo)
+            ev[1].record(ks)
+        self.barrier()
+        elapsed = self.max_over_ranks(time.perf_counter() - t0)
+        solver.set_timing(True)
+        kern_ms = np.array([ev[2 * i].elapsed_time(ev[2 * i + 1]) for i in range(steps)]) if self.coll else np.array([ev[0].elapsed_time(ev[1]) / steps])
+        ag_ms = None
+        if self.coll:  # packing + collective alone, for the record
+            self.barrier()
+            t1 = time.perf_counter()
+            for _ in range(10):
+                gather()
+            self.barrier()
+            ag_ms = self.max_over_ranks((time.perf_counter() - t1) / 10 * 1e3)
+        return elapsed, kern_ms, ag_ms
+
     def run(self, name, steps, warmup, batch=0):
         """Times `steps` steps of one workload; returns (measurement dict on every rank, host-side problem data)."""
         torch, cm = self.torch, self.cm
@@ -186,30 +226,15 @@ class Runner:
             solver.solve_device(dP, dX0, dX, dInfo)
             return gather() if self.coll else None
 
-        for _ in range(warmup):
-            step()
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2 * steps)]
+        # everything from here to the end of the timed region is queued on the solver's launch stream (torch's current stream inside this block): the solve, the
+        # packing kernel and the collective follow each other in stream order, with no cross-stream event dependency between them
         ks = solver.launch_stream       # the HIP stream the solve kernel is launched on
-        self.barrier()
-        t0 = time.perf_counter()
-        for i in range(steps):
-            ev[2 * i].record(ks)
-            solver.solve_device(dP, dX0, dX, dInfo)
-            ev[2 * i + 1].record(ks)
-            if self.coll:
-                gather()
-        self.barrier()
-        elapsed = self.max_over_ranks(time.perf_counter() - t0)
-        kern_ms = np.array([ev[2 * i].elapsed_time(ev[2 * i + 1]) for i in range(steps)])
+        ks.wait_stream(torch.cuda.current_stream(self.dev))
+        with torch.cuda.stream(ks):
+            m_ = self._timed(solver, step, gather, steps, warmup, dP, dX0, dX, dInfo)
+        torch.cuda.current_stream(self.dev).wait_stream(ks)
+        elapsed, kern_ms, ag_ms = m_
         info = dInfo.cpu().numpy()
-        ag_ms = None
-        if self.coll:  # packing + collective alone, for the record
-            self.barrier()
-            t1 = time.perf_counter()
-            for _ in range(10):
-                gather()
-            self.barrier()
-            ag_ms = self.max_over_ranks((time.perf_counter() - t1) / 10 * 1e3)
         iters = info[:, 0]
         giveups = float(np.floor(info[:, 3] / 1e6).sum())    # info[3] carries 1e6 per give-up at a hand-off word of the streaming stage (include/cmpc.h)
         per_rank = self.gather_floats([float(kern_ms.mean()), float(iters.sum()), float(iters.max()), float((info[:, 5] == 0).sum()), float(B), giveups])
@@ -249,18 +274,21 @@ class Runner:
         dX = torch.empty((1, dX0.shape[1]), dtype=torch.float32, device=self.dev)
         dInfo = torch.empty((1, 8), dtype=torch.float32, device=self.dev)
         ks = solver.launch_stream
-        for i in range(3):
-            solver.solve_device(dP[i:i + 1], dX0[i:i + 1], dX, dInfo)
+        solver.set_timing(False)        # (the event pair of this loop is the measurement; the library's own pair would sit inside it)
         torch.cuda.synchronize()
         ms, its = [], []
-        for i in range(n):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(ks)
-            solver.solve_device(dP[i:i + 1], dX0[i:i + 1], dX, dInfo)
-            e1.record(ks)
+        with torch.cuda.stream(ks):
+            for i in range(3):
+                solver.solve_device(dP[i:i + 1], dX0[i:i + 1], dX, dInfo)
             torch.cuda.synchronize()
-            ms.append(e0.elapsed_time(e1))
-            its.append(float(dInfo[0, 0].item()))
+            for i in range(n):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(ks)
+                solver.solve_device(dP[i:i + 1], dX0[i:i + 1], dX, dInfo)
+                e1.record(ks)
+                torch.cuda.synchronize()
+                ms.append(e0.elapsed_time(e1))
+                its.append(float(dInfo[0, 0].item()))
         ms = np.array(ms)
         return {"workload": f"B=1: one config-2 problem per launch, {n} different problems", "p50_ms": round(float(np.median(ms)), 4),
                 "p90_ms": round(float(np.quantile(ms, 0.9)), 4), "iterations_mean": round(float(np.mean(its)), 2),
@@ -435,7 +463,7 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": m["workload"], "batch_per_gpu": m["batch_per_gpu"], "batch_total": m["batch_total"],
                        "horizon": m["horizon"], "precision": "f32 storage+factorisation, f64 residuals"},
-            "p50_solve_latency_ms": round(float(np.median(data["kern_ms"])), 4),
+            "p50_solve_latency_ms": round(float(np.median(data["kern_ms"])), 4),   # (of the whole batch's launch; without a collective: the region's mean, see run())
             "iterations_mean": m["iterations_mean"], "iterations_max": m["iterations_max"],
             "converged_fraction": m["converged_fraction"],
             "sync_giveups": m["sync_giveups"],

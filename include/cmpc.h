@@ -128,8 +128,12 @@ int cmpc_set_warm_policy(cmpc_handle h, int warm_budget, int restart_in_kernel);
 /* host buffers (includes the PCIe copies; synchronous). info may be NULL. Returns
  * CMPC_ERR_NOT_CONVERGED if any problem's status != 0 (the solutions are still written). */
 int cmpc_solve(cmpc_handle h, const float* P, const float* X0, float* X, float* info);
-/* duration of the last solve kernel in ms (HIP events on the launch stream); < 0 if none */
+/* duration of the last solve kernel in ms (HIP events on the launch stream); < 0 if none, or if timing is off */
 float cmpc_last_solve_ms(cmpc_handle h);
+/* The event pair every solve launch is bracketed with (what cmpc_last_solve_ms reads) costs the stream two barrier packets per solve: measured ~9 us each
+ * between back-to-back launches on MI355X.  enabled = 0 stops recording them (a caller that queues solves back to back and times them itself);
+ * default: enabled.  No reference counterpart (the reference times its tick on the host, CentroidalMPCBlock.cpp:615-634). */
+int cmpc_set_timing(cmpc_handle h, int enabled);
 /* test hook: fills the LDS of every compute unit with NaN bit patterns (a kernel on the handle's stream), so that a
  * test can show that a solve does not depend on what an earlier workgroup or kernel left there.  No reference
  * counterpart. */

@@ -42,7 +42,7 @@ FACTORS = {None: 0, "auto": 0, "lds": 1, "hbm": 2}   # cmpc_config.factor_storag
 
 EXPORTS = [
     "cmpc_default_config", "cmpc_dims", "cmpc_create", "cmpc_destroy", "cmpc_last_error",
-    "cmpc_batch", "cmpc_stream", "cmpc_solve_device", "cmpc_solve", "cmpc_last_solve_ms",
+    "cmpc_batch", "cmpc_stream", "cmpc_solve_device", "cmpc_solve", "cmpc_last_solve_ms", "cmpc_set_timing",
     "cmpc_eval_nlp_device", "cmpc_nlp_sparsity", "cmpc_set_state", "cmpc_set_reference",
     "cmpc_set_contacts", "cmpc_set_initial_guess", "cmpc_advance", "cmpc_get_solution",
     "cmpc_get_output", "cmpc_set_reference_from_planner", "cmpc_plant_step_device", "cmpc_test_poison_lds",
@@ -85,6 +85,8 @@ def lib():
             L.cmpc_solve_device_warm.argtypes = [vp, fp, fp, fp, fp, vp]
         L.cmpc_solve.argtypes = [vp, fp, fp, fp, fp]
         L.cmpc_last_solve_ms.argtypes = [vp]
+        if hasattr(L, "cmpc_set_timing"):
+            L.cmpc_set_timing.argtypes = [vp, C.c_int]
         if hasattr(L, "cmpc_set_warm_policy"):
             L.cmpc_set_warm_policy.argtypes = [vp, C.c_int, C.c_int]
         L.cmpc_test_poison_lds.argtypes = [vp]

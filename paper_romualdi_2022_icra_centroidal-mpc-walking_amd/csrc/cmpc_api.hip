@@ -41,6 +41,7 @@ struct cmpc_handle_s {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
+    bool timing = true;          // record the event pair around every solve launch (cmpc_set_timing)
     float* dP = nullptr;
     float* dX0 = nullptr;
     float* dX = nullptr;
@@ -312,11 +313,11 @@ static int solve_device_impl(cmpc_handle h, const float* dP, const float* dX0, f
     if (warm || h->force_warm) {  // dX0 is a previous solution shifted by one knot: start near the central path
         p.mu_init = (float)h->mu_warm; p.mu_adapt = 0.f; p.t_floor = (float)h->floor_warm; p.warm = 1;
     }
-    HIPCHK(h, hipEventRecord(h->ev0, st));
+    if (h->timing) HIPCHK(h, hipEventRecord(h->ev0, st));
     int rc = cmpc_launch_solver(&p, h->lds, st);
     if (rc != 0) return fail(h, CMPC_ERR_HIP, std::string("solver launch: ") + hipGetErrorString((hipError_t)rc));
-    HIPCHK(h, hipEventRecord(h->ev1, st));
-    h->timed = true;
+    if (h->timing) HIPCHK(h, hipEventRecord(h->ev1, st));
+    h->timed = h->timing;
     return CMPC_OK;
 }
 
@@ -357,6 +358,14 @@ int cmpc_test_poison_lds(cmpc_handle h)
     // one workgroup per CU at a time (160 KiB each); several waves of them so that every CU is visited
     hipLaunchKernelGGL(poison_lds_kernel, dim3(2048), dim3(256), bytes, h->stream, bytes / 4, reinterpret_cast<unsigned*>(h->dInfo));
     HIPCHK(h, hipGetLastError());
+    return CMPC_OK;
+}
+
+int cmpc_set_timing(cmpc_handle h, int enabled)
+{
+    if (!h) return CMPC_ERR_ARG;
+    h->timing = enabled != 0;
+    if (!h->timing) h->timed = false;
     return CMPC_OK;
 }
 
@@ -535,11 +544,11 @@ int cmpc_advance(cmpc_handle h)
         fill_params(h, p);
         p.P = h->dP; p.X0 = h->dX0; p.X = h->dX; p.info = h->dInfo;
         if (h->warm) { p.mu_init = (float)h->mu_warm; p.mu_adapt = 0.f; p.t_floor = (float)h->floor_warm; p.warm = 1; }
-        HIPCHK(h, hipEventRecord(h->ev0, h->stream));
+        if (h->timing) HIPCHK(h, hipEventRecord(h->ev0, h->stream));
         int lrc = cmpc_launch_solver(&p, h->lds, h->stream);
         if (lrc != 0) return fail(h, CMPC_ERR_HIP, std::string("solver launch: ") + hipGetErrorString((hipError_t)lrc));
-        HIPCHK(h, hipEventRecord(h->ev1, h->stream));
-        h->timed = true;
+        if (h->timing) HIPCHK(h, hipEventRecord(h->ev1, h->stream));
+        h->timed = h->timing;
         h->warm = false;
     }
     std::vector<float> hinfo((size_t)h->B * CMPC_INFO_N);

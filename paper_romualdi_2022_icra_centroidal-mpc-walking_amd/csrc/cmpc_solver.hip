@@ -1494,7 +1494,7 @@ struct ConsPlan {
     float wa3, wb3;
     // where the four results of the lane go (float index from QuuF of the set) and their mirror images (Qss is kept with both triangles)
     int d0, d1, d2, d3, e0, e1, e2, e3;
-    // role of the wave: waves 1, 2, 3 the float64 parts (diagonal blocks, q_u, q_s), waves 5, 6, 7 Y, wave 7 also the gradient column
+    // role of the wave: waves 1, 2, 3 the float64 parts (diagonal blocks, q_u, q_s), waves 5, 6, 7 Y; wave 7 carries the gradient column and no tile
     int ri[14];
     float rf[6];
 };
@@ -1542,9 +1542,12 @@ __device__ inline void cons_plan_build(ConsPlan& pl, const Ctx& c, const CmpcCon
         pl.t_zsel = (isss && pr == 2) ? 1.f : 0.f;
     }
     // ---- tile ----
+    int d[4], e[4];
     {
-        const int wvc = wv < 0 ? 0 : wv;
-        const int I = wvc >= 3 ? 2 : (wvc >= 1 ? 1 : 0), J = wvc - I * (I + 1) / 2;
+        // tiles of the lower triangle of the 3 x 3 tile grid on consumer waves 0..4: (0,0) | (2,0) | (2,1) | (1,0) and (1,1) | (2,2); wave 5 (the gradient column) has none.
+        // The pair shares its operand rows 16..31 -- the second tile costs one more matrix-pipe instruction per block -- and sits on a Y wave: those are done with
+        // the assembly first, and their plan has room for the second tile's destinations (ri[5..12]).
+        const int I = wv == 0 ? 0 : (wv == 3 ? 1 : 2), J = wv == 2 ? 1 : (wv == 4 ? 2 : 0);
         auto operand = [&](int row, int& p0, int& p1, int& p2, int& p3, int& w, float& w3) {
             const bool ok = row < NU + NS;
             int r0 = 0, r1 = 0, r2 = 0;
@@ -1555,21 +1558,24 @@ __device__ inline void cons_plan_build(ConsPlan& pl, const Ctx& c, const CmpcCon
         };
         operand(16 * I + m4, pl.pa0, pl.pa1, pl.pa2, pl.pa3, pl.wa, pl.wa3);
         operand(16 * J + m4, pl.pb0, pl.pb1, pl.pb2, pl.pb3, pl.wb, pl.wb3);
-        const int jj = 16 * J + m4;
-        int d[4], e[4];
+        auto results = [&](int TI, int TJ, bool owned) {
+            const int jj = 16 * TJ + m4;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int ii = 16 * I + 4 * kq + i;
-            const bool ok = jj <= ii && ii < NU + NS;
-            int p = ii * RLD + jj, p2 = p;
-            if (ii >= NU) {
-                if (jj < NU) { p = NU * RLD + (ii - NU) * RLD + jj; p2 = p; }
-                else { p = NU * RLD + NPAN * RLD + 16 * (ii - NU) + (jj - NU); p2 = NU * RLD + NPAN * RLD + 16 * (jj - NU) + (ii - NU); }
+            for (int i = 0; i < 4; ++i) {
+                const int ii = 16 * TI + 4 * kq + i;
+                const bool ok = owned && jj <= ii && ii < NU + NS;
+                int p = ii * RLD + jj, p2 = p;
+                if (ii >= NU) {
+                    if (jj < NU) { p = NU * RLD + (ii - NU) * RLD + jj; p2 = p; }
+                    else { p = NU * RLD + NPAN * RLD + 16 * (ii - NU) + (jj - NU); p2 = NU * RLD + NPAN * RLD + 16 * (jj - NU) + (ii - NU); }
+                }
+                d[i] = ok ? p : SQ_TRASH + i; e[i] = ok ? p2 : SQ_TRASH + i;
             }
-            d[i] = ok ? p : SQ_TRASH + i; e[i] = ok ? p2 : SQ_TRASH + i;
-        }
+        };
+        results(I, J, wv >= 0 && wv < 5);
         pl.d0 = d[0]; pl.d1 = d[1]; pl.d2 = d[2]; pl.d3 = d[3];
         pl.e0 = e[0]; pl.e1 = e[1]; pl.e2 = e[2]; pl.e3 = e[3];
+        results(1, 1, wv == 3);            // (kept until the role part below: wave 3 stores them in ri[5..12])
     }
     // ---- role ----
 #pragma unroll
@@ -1621,21 +1627,26 @@ __device__ inline void cons_plan_build(ConsPlan& pl, const Ctx& c, const CmpcCon
         plan_rows(rows, cl, r0, r1, r2);
         pl.ri[0] = 3 * cl; pl.ri[1] = 16 * r0 + 4 * q; pl.ri[2] = 16 * r1 + 4 * q; pl.ri[3] = 16 * r2 + 4 * q;
         pl.ri[4] = col < NU + NS ? NS * RLD + 16 * col + 4 * q : -1;     // float index from Pan of the set, or none
+        if (wv == 3) {
+            // the second tile's results and their mirror images
+            pl.ri[5] = d[0]; pl.ri[6] = d[1]; pl.ri[7] = d[2]; pl.ri[8] = d[3];
+            pl.ri[9] = e[0]; pl.ri[10] = e[1]; pl.ri[11] = e[2]; pl.ri[12] = e[3];
+        }
         if (wv == 5) {
-            // gradient column: z_g of a pair of pivot blocks by eight lanes per entry (term gt and gt + 8 of the sixteen), then lane <-> published row
+            // gradient column: z_g of a pair of pivot blocks by eight lanes per entry (term gt and gt + 8 of the sixteen; entry ge = 3 block + component in lanes 8 ge ..),
+            // then lane <-> published row
             const int ge = ln >> 3, gt = ln & 7;
             const int gcomp = ge % 3, gblk = ge < 3 ? 0 : 1;
             const int grow2 = gt == 7 ? NPAN - 1 : gt + 8;
             pl.ri[5] = (NPAN * gblk + gt) * 4 + gcomp; pl.ri[6] = (NPAN * gblk + grow2) * 4 + gcomp;
             pl.ri[7] = gt; pl.ri[8] = gt == 7 ? 0 : gt + 8;
-            pl.ri[9] = (gt == 0 && ge < 6) ? 4 * gblk + gcomp : 8 + (ln & 7);          // z_g slot, or a word of the staging buffer nobody reads
-            pl.ri[10] = 4 * (ln < NS ? ln : (ln == NS ? NPAN - 1 : (ln < NPAN ? ln - 1 : 0)));   // the lane's published row
-            // last step: M[45][j] -= sum_a w_a(j) v[r_a(j)], lane j < 45
+            pl.ri[10] = 4 * (ln < NS ? ln : (ln == NS ? NPAN - 1 : (ln < NPAN ? ln - 1 : 0)));   // the lane's published row: v of panel row r lives in lane r (r < NS) or r + 1
+            // last step: M[45][j] -= sum_a w_a(j) v[r_a(j)], lane j < 45: the four v are fetched from their lanes (ds_bpermute: byte address 4 lane)
             const int jr = ln < NU + NS ? ln : NU + NS - 1;
             plan_rows(rows, jr, r0, r1, r2);
-            pl.ri[11] = r0 | (r1 << 8) | (r2 << 16) | ((jr < NF ? NS + jr : 0) << 24);
+            auto vlane = [](int r) { return r < NS ? r : r + 1; };
+            pl.ri[11] = vlane(r0) | (vlane(r1) << 8) | (vlane(r2) << 16) | (vlane(jr < NF ? NS + jr : 0) << 24);
             pl.ri[12] = 3 * jr;
-            pl.ri[13] = ln < NPAN ? 16 + (ln < NS ? ln : (ln == NS ? NPAN - 1 : ln - 1)) : 64 + (ln & 15);   // where the lane's v goes in the staging buffer
             pl.rf[0] = gt == 7 ? 1.f : 0.f; pl.rf[1] = gblk ? 1.f : 0.f; pl.rf[2] = jr < NF ? -prm.D[jr % 3] : 0.f;
             pl.rf[3] = ln < NU ? 1.f : 0.f; pl.rf[4] = ln < NU + NS ? 1.f : 0.f;
         }
@@ -1831,83 +1842,102 @@ __device__ __forceinline__ void sq_consume_stage(const Ctx& c, const CmpcConsts&
             a = wa0 * x0 + wa1 * x1 + wa2 * x2 + pl.wa3 * x3;
             bv = wb0 * y0 + wb1 * y1 + wb2 * y2 + pl.wb3 * y3;
         };
-        // The gradient column (row 45 of M) on the wave of tile (2, 2): v = W^T z_g a pair of pivot blocks at a time -- see the plan (ri[5..13]) --, and at the end
-        // M[45][j] -= sum_a w_a(j) v[r_a(j)], the same sparse combination as a row of Z^T.
+        // The gradient column (row 45 of M) has a wave of its own (no tile: with one it left the stage ~450 cycles after the others, every stage): v = W^T z_g a pair
+        // of pivot blocks at a time -- see the plan (ri[5..12]) --, and at the end M[45][j] -= sum_a w_a(j) v[r_a(j)], the same sparse combination as a row of Z^T.
+        // No LDS round trip: the six z of a pair are broadcast by v_readlane, the four v of the last step come from their lanes by ds_bpermute.
         const bool grole = wv == 5;
-        float* zbuf = c.ybuf;                 // (the sweeps' 16-byte aligned staging buffer, idle during the backward pass): z_g of the pair [block][4], then v from float 16 on
-        float vacc = 0.f;
-        float gw0 = 0.f, gw1 = 0.f, gz0 = 0.f, gz1 = 0.f, gz2 = 0.f;
-        double gbase = 0.0;
         if (grole) {
-            gw0 = c.d[NS * kb + pl.ri[7]];
-            gw1 = pl.rf[0] != 0.f ? 1.f : c.d[NS * kb + pl.ri[8]];
-            gz0 = Bval[pl.ri[12]]; gz1 = Bval[pl.ri[12] + 1]; gz2 = Bval[pl.ri[12] + 2];
-        }
-        auto gradient_pair = [&](int b, bool skip0, bool skip1) {
-            const int o = NPAN * 4 * b;
-            const float4 xa = *reinterpret_cast<const float4*>(Wb + o + pl.ri[10]);
-            const float4 xb = *reinterpret_cast<const float4*>(Wb + o + NPAN * 4 + pl.ri[10]);
-            float z = oct_sum(gw0 * Wb[o + pl.ri[5]] + gw1 * Wb[o + pl.ri[6]]);
-            if ((skip0 && pl.rf[1] == 0.f) || (skip1 && pl.rf[1] != 0.f)) z = 0.f;
-            zbuf[pl.ri[9]] = z;
-            wave_lds_sync();
-            const float4 z0 = *reinterpret_cast<const float4*>(zbuf), z1 = *reinterpret_cast<const float4*>(zbuf + 4);
-            if (!skip0) vacc += xa.x * z0.x + xa.y * z0.y + xa.z * z0.z;
-            if (!skip1) vacc += xb.x * z1.x + xb.y * z1.y + xb.z * z1.z;
-            wave_lds_sync();
-        };
-        float bs0 = 0.f, bs1 = 0.f, bs2 = 0.f, bs3 = 0.f;
-        CPROF(2);
-        // blocks 0..7 (the forces: never skipped) in pairs: the loads of both in flight, two chained MFMAs
+            float vacc = 0.f;
+            const float gw0 = c.d[NS * kb + pl.ri[7]];
+            const float gw1 = pl.rf[0] != 0.f ? 1.f : c.d[NS * kb + pl.ri[8]];
+            const float gz0 = Bval[pl.ri[12]], gz1 = Bval[pl.ri[12] + 1], gz2 = Bval[pl.ri[12] + 2];
+            double gbase = 0.0;
+            auto gradient_pair = [&](int b, bool skip0, bool skip1) {
+                const int o = NPAN * 4 * b;
+                const float4 xa = *reinterpret_cast<const float4*>(Wb + o + pl.ri[10]);
+                const float4 xb = *reinterpret_cast<const float4*>(Wb + o + NPAN * 4 + pl.ri[10]);
+                const float z = oct_sum(gw0 * Wb[o + pl.ri[5]] + gw1 * Wb[o + pl.ri[6]]);
+                if (!skip0) vacc += xa.x * readlane_f(z, 0) + xa.y * readlane_f(z, 8) + xa.z * readlane_f(z, 16);
+                if (!skip1) vacc += xb.x * readlane_f(z, 24) + xb.y * readlane_f(z, 32) + xb.z * readlane_f(z, 40);
+            };
+            CPROF(2);
 #pragma unroll
-        for (int b = 0; b < 8; b += 2) {
-            need(b + 2);
-            float a0, b0, a1, b1;
-            operands(b, a0, b0);
-            operands(b + 1, a1, b1);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc, 0, 0, 0);
-            if (grole) gradient_pair(b, false, false);   // (its loads behind the tile's: fetched together with the operand rows they cost 1.5 %)
-            if (b == 0) {
-                // every consumer wave's part of the assembly must be in LDS before the tiles are subtracted from it (long there by now); then what the tile is
-                // subtracted from is fetched -- far ahead of the last blocks, off the tail of the stage
-                gaveup = !lds_wait_ge(c.flag + 3, SQ_TILE_WAVES * (ord + 1)) || gaveup;
-                bs0 = Mn[pl.d0]; bs1 = Mn[pl.d1]; bs2 = Mn[pl.d2]; bs3 = Mn[pl.d3];
-                if (grole) gbase = pl.rf[3] != 0.f ? c.pv[ln < NU ? ln : 0] : qsn[ln >= NU && ln < NU + NS ? ln - NU : 0];
+            for (int b = 0; b < 8; b += 2) {
+                need(b + 2);
+                gradient_pair(b, false, false);
+                if (b == 0) {
+                    // (q_u of wave 2 and q_s of wave 3 must be there: the assembly count covers them)
+                    gaveup = !lds_wait_ge(c.flag + 3, SQ_TILE_WAVES * (ord + 1)) || gaveup;
+                    gbase = pl.rf[3] != 0.f ? c.pv[ln < NU ? ln : 0] : qsn[ln >= NU && ln < NU + NS ? ln - NU : 0];
+                }
             }
-        }
-        CPROF(3);
-        // blocks 8, 9: the landing offsets of the two feet
-        if (!sk8 && !sk9) {
-            need(10);
-            float a0, b0, a1, b1;
-            operands(8, a0, b0);
-            operands(9, a1, b1);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc, 0, 0, 0);
-        } else if (!sk8 || !sk9) {
-            const int b = sk8 ? 9 : 8;
-            need(b + 1);
-            float a0, b0;
-            operands(b, a0, b0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc, 0, 0, 0);
-        }
-        if (grole && !(sk8 && sk9)) gradient_pair(8, sk8, sk9);
-        CPROF2(4);
-        {
-            const float r0 = bs0 - acc[0], r1 = bs1 - acc[1], r2 = bs2 - acc[2], r3 = bs3 - acc[3];
-            Mn[pl.d0] = r0; Mn[pl.d1] = r1; Mn[pl.d2] = r2; Mn[pl.d3] = r3;
-            if (wv == 2 || wv >= 4) { Mn[pl.e0] = r0; Mn[pl.e1] = r1; Mn[pl.e2] = r2; Mn[pl.e3] = r3; }   // (tiles with entries of Qss: both triangles)
-        }
-        if (grole) {
-            zbuf[pl.ri[13]] = vacc;
-            wave_lds_sync();
-            const float* vb = zbuf + 16;
+            CPROF(3);
+            if (!(sk8 && sk9)) {
+                need(sk9 ? 9 : 10);
+                gradient_pair(8, sk8, sk9);
+            }
+            CPROF2(4);
             const unsigned rw = (unsigned)pl.ri[11];
-            const float val = gz0 * vb[rw & 255u] + gz1 * vb[(rw >> 8) & 255u] + gz2 * vb[(rw >> 16) & 255u] + pl.rf[2] * vb[rw >> 24];
+            const int vi = __float_as_int(vacc);
+            auto vof = [&](unsigned lane) { return __int_as_float(__builtin_amdgcn_ds_bpermute((int)(lane << 2), vi)); };
+            const float val = gz0 * vof(rw & 255u) + gz1 * vof((rw >> 8) & 255u) + gz2 * vof((rw >> 16) & 255u) + pl.rf[2] * vof(rw >> 24);
             const double res = gbase - (double)val;
             if (ln < NU) Pann[(NPAN - 1) * RLD + ln] = (float)res;
             else if (ln < NU + NS) qsn[ln - NU] = res;
+        } else {
+            const bool two = wv == 3;             // tiles (1, 0) and (1, 1): the second is a x a of the same operand rows
+            v4f acc2 = {0.f, 0.f, 0.f, 0.f};
+            float bs0 = 0.f, bs1 = 0.f, bs2 = 0.f, bs3 = 0.f, bt0 = 0.f, bt1 = 0.f, bt2 = 0.f, bt3 = 0.f;
+            CPROF(2);
+            // blocks 0..7 (the forces: never skipped) in pairs: the loads of both in flight, two chained MFMAs
+#pragma unroll
+            for (int b = 0; b < 8; b += 2) {
+                need(b + 2);
+                float a0, b0, a1, b1;
+                operands(b, a0, b0);
+                operands(b + 1, a1, b1);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc, 0, 0, 0);
+                if (two) acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, a0, acc2, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc, 0, 0, 0);
+                if (two) acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, a1, acc2, 0, 0, 0);
+                if (b == 0) {
+                    // every consumer wave's part of the assembly must be in LDS before the tiles are subtracted from it (long there by now); then what the tile is
+                    // subtracted from is fetched -- far ahead of the last blocks, off the tail of the stage
+                    gaveup = !lds_wait_ge(c.flag + 3, SQ_TILE_WAVES * (ord + 1)) || gaveup;
+                    bs0 = Mn[pl.d0]; bs1 = Mn[pl.d1]; bs2 = Mn[pl.d2]; bs3 = Mn[pl.d3];
+                    if (two) { bt0 = Mn[pl.ri[5]]; bt1 = Mn[pl.ri[6]]; bt2 = Mn[pl.ri[7]]; bt3 = Mn[pl.ri[8]]; }
+                }
+            }
+            CPROF(3);
+            // blocks 8, 9: the landing offsets of the two feet
+            if (!sk8 && !sk9) {
+                need(10);
+                float a0, b0, a1, b1;
+                operands(8, a0, b0);
+                operands(9, a1, b1);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc, 0, 0, 0);
+                if (two) acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, a0, acc2, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc, 0, 0, 0);
+                if (two) acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, a1, acc2, 0, 0, 0);
+            } else if (!sk8 || !sk9) {
+                const int b = sk8 ? 9 : 8;
+                need(b + 1);
+                float a0, b0;
+                operands(b, a0, b0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc, 0, 0, 0);
+                if (two) acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, a0, acc2, 0, 0, 0);
+            }
+            CPROF2(4);
+            {
+                const float r0 = bs0 - acc[0], r1 = bs1 - acc[1], r2 = bs2 - acc[2], r3 = bs3 - acc[3];
+                Mn[pl.d0] = r0; Mn[pl.d1] = r1; Mn[pl.d2] = r2; Mn[pl.d3] = r3;
+                if (wv == 2 || wv == 4) { Mn[pl.e0] = r0; Mn[pl.e1] = r1; Mn[pl.e2] = r2; Mn[pl.e3] = r3; }   // (tiles with entries of Qss: both triangles)
+            }
+            if (two) {
+                const float r0 = bt0 - acc2[0], r1 = bt1 - acc2[1], r2 = bt2 - acc2[2], r3 = bt3 - acc2[3];
+                Mn[pl.ri[5]] = r0; Mn[pl.ri[6]] = r1; Mn[pl.ri[7]] = r2; Mn[pl.ri[8]] = r3;
+                Mn[pl.ri[9]] = r0; Mn[pl.ri[10]] = r1; Mn[pl.ri[11]] = r2; Mn[pl.ri[12]] = r3;
+            }
         }
         CPROF(4);
     }

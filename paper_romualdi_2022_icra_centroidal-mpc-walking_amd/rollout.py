@@ -69,7 +69,21 @@ class WalkingRollout:
             com_speed = last / t_last if t_last > 0 else 0.0
         self.com_speed = com_speed
 
-    def run(self, ticks, com0, dcom0, h0, push=None, push_ticks=0, warm=True, dump=None, replan=None, slow=None, record="full"):
+    def run(self, *args, **kwargs):
+        """The roll-out (see _run for the arguments), with the solver's launch stream as torch's current stream: every device call of a tick -- the library's
+        kernels and the torch ops between them -- is then queued on ONE non-default stream, in order, without the event dependencies a call from the default
+        stream needs (BatchSolver._stream_pair: two per call, ~24 us of idle GPU each time)."""
+        torch = self.torch
+        ls = self.solver.launch_stream
+        cur = torch.cuda.current_stream(self.dev)
+        ls.wait_stream(cur)
+        try:
+            with torch.cuda.stream(ls):
+                return self._run(*args, **kwargs)
+        finally:
+            cur.wait_stream(ls)
+
+    def _run(self, ticks, com0, dcom0, h0, push=None, push_ticks=0, warm=True, dump=None, replan=None, slow=None, record="full"):
         """com0/dcom0/h0 [B,3] numpy; push [B,3] (mass-normalised force held for the first `push_ticks` ticks);
         replan {tick: (t, pose, n)}: the planner's lists from that tick on (the reference's generator re-plans while walking);
         slow (threshold, list): developer hook -- (tick, problem, P row, X0 row, info row) of every solve with more iterations;

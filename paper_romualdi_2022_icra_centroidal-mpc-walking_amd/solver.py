@@ -90,16 +90,9 @@ class BatchSolver:
             dX = torch.empty_like(dX0)
         if dInfo is None:
             dInfo = torch.empty((self.batch, _capi.INFO), dtype=torch.float32, device=dP.device)
+        cur = None
         if stream is None:
-            # a side stream of our own, ordered after torch's current stream and joined back into it:
-            # (the default stream's handle is 0, which the C ABI reads as "the handle's stream")
-            if self._stream is None:
-                self._stream = torch.cuda.Stream(dP.device)
-            cur = torch.cuda.current_stream(dP.device)
-            self._stream.wait_stream(cur)
-            stream = self._stream.cuda_stream
-        else:
-            cur = None
+            stream, cur = self._stream_pair(dP.device)
         fn = self._lib.cmpc_solve_device_warm if warm else self._lib.cmpc_solve_device
         rc = fn(self._h, dP.data_ptr(), dX0.data_ptr(), dX.data_ptr(), dInfo.data_ptr(), stream)
         if rc != 0:
@@ -107,6 +100,20 @@ class BatchSolver:
         if cur is not None:
             cur.wait_stream(self._stream)
         return dX, dInfo
+
+    def _stream_pair(self, dev):
+        """(raw hipStream_t to launch on, torch stream to join back into or None).  Torch's current stream itself when it is not the default stream -- no
+        cross-stream dependency at all; run a loop of device calls under `with torch.cuda.stream(solver.launch_stream):` to get that.  The default stream's
+        handle is 0, which the C ABI reads as "the handle's own stream": there the call goes to a side stream ordered after the default stream and joined
+        back into it -- two event dependencies per call, measured at 24 us of idle GPU per solve between back-to-back launches (tools/gpu_enqueue_probe.py)."""
+        import torch
+        cur = torch.cuda.current_stream(dev)
+        if cur.cuda_stream != 0:
+            return cur.cuda_stream, None
+        if self._stream is None:
+            self._stream = torch.cuda.Stream(dev)
+        self._stream.wait_stream(cur)
+        return self._stream.cuda_stream, cur
 
     @property
     def launch_stream(self):
@@ -139,6 +146,11 @@ class BatchSolver:
     def last_solve_ms(self) -> float:
         return float(self._lib.cmpc_last_solve_ms(self._h))
 
+    def set_timing(self, enabled: bool = True):
+        """cmpc_set_timing: record (default) or not the event pair around every solve launch that last_solve_ms() reads."""
+        if hasattr(self._lib, "cmpc_set_timing"):
+            self._lib.cmpc_set_timing(self._h, 1 if enabled else 0)
+
     def compact_output_device(self, dX, dInfo, out=None):
         """[B, 3(N+1) + 38] compact record of every problem (what distributed.compact_output builds with torch ops), by
         one kernel on the solver's stream; torch CUDA tensors."""
@@ -147,14 +159,12 @@ class BatchSolver:
         if out is None:
             out = torch.empty((self.batch, W), dtype=torch.float32, device=dX.device)
         assert out.is_contiguous() and tuple(out.shape) == (self.batch, W)
-        if self._stream is None:
-            self._stream = torch.cuda.Stream(dX.device)
-        cur = torch.cuda.current_stream(dX.device)
-        self._stream.wait_stream(cur)
-        rc = self._lib.cmpc_compact_output_device(self._h, dX.data_ptr(), dInfo.data_ptr(), out.data_ptr(), self._stream.cuda_stream)
+        st, cur = self._stream_pair(dX.device)
+        rc = self._lib.cmpc_compact_output_device(self._h, dX.data_ptr(), dInfo.data_ptr(), out.data_ptr(), st)
         if rc != 0:
             raise RuntimeError(f"cmpc_compact_output_device failed ({rc}): {self.last_error}")
-        cur.wait_stream(self._stream)
+        if cur is not None:
+            cur.wait_stream(self._stream)
         return out
 
     def plant_step_device(self, dX, dP, dState, dStateOut=None, dZmp=None, step=0.01, substeps=6,
@@ -166,31 +176,25 @@ class BatchSolver:
             dStateOut = torch.empty_like(dState)
         if dZmp is None:
             dZmp = torch.empty((self.batch, 2), dtype=torch.float32, device=dState.device)
-        if self._stream is None:
-            self._stream = torch.cuda.Stream(dState.device)
-        cur = torch.cuda.current_stream(dState.device)
-        self._stream.wait_stream(cur)
+        st, cur = self._stream_pair(dState.device)
         rc = self._lib.cmpc_plant_step_device(self._h, dX.data_ptr(), dP.data_ptr(), dState.data_ptr(), dStateOut.data_ptr(),
-                                              dZmp.data_ptr(), float(step), int(substeps), float(zmp_half_x), float(zmp_half_y),
-                                              self._stream.cuda_stream)
+                                              dZmp.data_ptr(), float(step), int(substeps), float(zmp_half_x), float(zmp_half_y), st)
         if rc != 0:
             raise RuntimeError(f"cmpc_plant_step_device failed ({rc}): {self.last_error}")
-        cur.wait_stream(self._stream)
+        if cur is not None:
+            cur.wait_stream(self._stream)
         return dStateOut, dZmp
 
 
     # ---- SURVEY 8f-1 / 8f-2 on the device (torch CUDA tensors; everything stays in HBM) ----
     def _launch(self, dev, fn):
-        """runs fn(raw_stream) on the solver's stream, ordered after torch's current stream and joined back into it"""
-        import torch
-        if self._stream is None:
-            self._stream = torch.cuda.Stream(dev)
-        cur = torch.cuda.current_stream(dev)
-        self._stream.wait_stream(cur)
-        rc = fn(self._stream.cuda_stream)
+        """runs fn(raw_stream) on torch's current stream (the default stream: on the solver's side stream, ordered after it and joined back; _stream_pair)"""
+        st, cur = self._stream_pair(dev)
+        rc = fn(st)
         if rc != 0:
             raise RuntimeError(f"libcmpc_hip call failed ({rc}): {self.last_error}")
-        cur.wait_stream(self._stream)
+        if cur is not None:
+            cur.wait_stream(self._stream)
 
     def contacts_merge_device(self, now, plan, mpc, out=None):
         """updateContactPhaseList (CentroidalMPCBlock.cpp:32-110) for the batch: plan / mpc / out = (t[B,2,M,2] float64,

@@ -175,6 +175,22 @@ def test_device_and_host_entry_points_agree():
     torch.cuda.synchronize()
     np.testing.assert_array_equal(dX.cpu().numpy(), Xh)  # same kernel, same inputs: bit-identical
     assert s.last_solve_ms() > 0
+    # launched from a non-default current stream the call goes straight onto that stream (no side stream, no event dependencies): same answer, in stream order
+    # with the torch ops around it; cmpc_set_timing(0) stops the event pair around the launch and cmpc_last_solve_ms says so
+    s.set_timing(False)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        dP2 = torch.from_numpy(P32).cuda(non_blocking=False) * 1.0     # (a torch op on the side stream in front of the solve)
+        dX2, dI2 = s.solve_device(dP2, torch.from_numpy(X032).cuda())
+        twice = dX2 * 2.0                                               # (and one behind it)
+    side.synchronize()
+    np.testing.assert_array_equal(dX2.cpu().numpy(), Xh)
+    np.testing.assert_array_equal(twice.cpu().numpy(), 2.0 * Xh)
+    assert s.last_solve_ms() < 0
+    s.set_timing(True)
+    s.solve_device(torch.from_numpy(P32).cuda(), torch.from_numpy(X032).cuda())
+    assert s.last_solve_ms() > 0
 
 
 def test_full_size_properties_config3():
