@@ -729,7 +729,7 @@ struct CholPub { float* pub; int stride; int* pflag; int seq0; float* publate; c
 // Float4s left of an identity row's diagonal block go to row 30 of U, a row whose only readers are lanes that discard what they compute (REC_ZERO is row 31).
 template <bool G, bool PUB>
 struct RowStore {
-    static constexpr bool EARLY = !G;   // (measured at B = 256: 247.2 k solves/s with the early stores, 244.8 k without)
+    static constexpr bool EARLY = !G;   // (measured at B = 256: 247.2 k solves/s with the early stores, 244.8 k without; records in HBM: see chol_block)
     const RecRef<G>& rec;
     float* prow_p;      // panel row (not PUB)
     float sc;           // its scale: the p rows of the panel are kept pre-multiplied by -D
@@ -840,9 +840,11 @@ __device__ __forceinline__ bool chol_block(v4f (&acc)[8], double (&dd)[3], int l
         trail_rank1<G0>(acc, a1, x1);
         trail_rank1<G0>(acc, a2, x2);
     }
-    // chunks whose last column this block finished (behind the matrix-pipe instructions: the stores drain while those execute).  LDS records only: a
-    // ds_write takes its data when it issues; with the records in HBM (global_store_dwordx4) the same early stores delivered wrong rows -- the accumulator
-    // registers are renamed by the matrix-pipe instructions right behind the store -- so those variants store after the last block, as before.
+    // chunks whose last column this block finished (behind the matrix-pipe instructions: the stores drain while those execute).  LDS records only.  With the
+    // records in HBM the same early stores are SLOWER (config 3 412.4 k -> 405.8 k solves/s, config 5 266.6 k -> 261.6 k: global_store_dwordx4 from inside the
+    // critical wave's block loop, three workgroups per CU competing for the memory pipeline), and the panel copy of an identity row that takes over a lane at
+    // LATE_B would need its chunks 0..3 written as zeros (phase 4 reads them; a first attempt left them unwritten and delivered wrong rows -- not, as first
+    // thought, a register hazard): those variants store after the last block.
     if constexpr (ST::EARLY) {
         if constexpr (B == 1) st.template chunk<0>(acc[0]);
         if constexpr (B == 2) st.template chunk<1>(acc[1]);

@@ -11,11 +11,18 @@ cm._capi.LIB_PATH = os.path.join(os.path.dirname(cm._capi.LIB_PATH), os.environ.
 #  variants and a -DCMPC_SQRT_BACKWARD=0 build fill the ph1..ph4 slots instead)
 names = ["(ph0: under ph3 now)", "ph1 G", "ph2 Quu,panel,Pd,qu", "ph3 chol+solve | sq: barrier wait", "ph4 P update", "ph2/w0: values", "ph2/w0: stores", "ph2/w2: diag blocks", "ph2/w3: qu", "sq: factorisation (w0)",
          "residuals", "backward(total)", "fwd1", "steps+muaff", "delta", "fwd2", "steplen+costate", "update+conv"]
+kw = {}
 if os.environ.get("CMPC_PROBE") == "push":
     cfg, P, X0 = cm.synthetic.walking_push_n12("tmp")
+elif os.environ.get("CMPC_PROBE") == "config3":    # HBM-factor variant, three workgroups on every CU
+    cfg, P, X0 = cm.synthetic.config3_external_push(768)
+    kw = dict(factors="hbm")
+elif os.environ.get("CMPC_PROBE") == "config5":
+    cfg, P, X0 = cm.synthetic.config5_footstep_candidates(768)
+    kw = dict(factors="hbm")
 else:
     cfg, P, X0 = cm.synthetic.config2_perturbed_com(256)
-s = cm.BatchSolver(cfg, P.shape[0])
+s = cm.BatchSolver(cfg, P.shape[0], **kw)
 X, info, rc = s.solve_host(P, X0)
 out = (C.c_longlong * 128)()
 cm._capi.lib().cmpc_profile_read(out, 1)
