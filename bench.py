@@ -19,6 +19,9 @@ plus the single-problem (B=1) solve latency the metric names, and
     rollout  B=1024 per GPU, 60 ticks of the warm-started receding-horizon walking roll-out (the reference's operating mode:
              is_warm_start_enabled true, ergoCubGazeboV1/centroidal_mpc.ini:9; CentroidalMPCBlock.cpp:586-631 + the plant of
              WholeBodyQPBlock.cpp:1083-1150): seven launches per tick, everything resident in HBM            (secondary; weak)
+    inflight two independent config-2 batches in flight on two streams (two handles): a batch is as slow as its slowest problem, and the CUs its early
+             finishers release start the other batch -- what a Monte-Carlo campaign of many batches gets; NOT the headline, whose steps run one at a time
+             as the ticks of a receding horizon must                                                          (secondary; N = 1 only)
 """
 import argparse
 import json
@@ -46,7 +49,7 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=0, help="problems per GPU of the primary workload (0: its BASELINE size)")
     ap.add_argument("--workload", default="config2", choices=["config2", "config3", "config4", "config5"])
-    ap.add_argument("--secondary", default="config3,config5,config4,latency,rollout",
+    ap.add_argument("--secondary", default="config3,config5,config4,latency,rollout,inflight",
                     help="comma list of extra workloads reported under `secondary` ('' or 'none': skip)")
     ap.add_argument("--secondary-steps", type=int, default=5)
     ap.add_argument("--cpu-sample", type=int, default=6144)
@@ -295,6 +298,37 @@ class Runner:
                 "ms_per_iteration": round(float(ms.sum() / np.sum(its)), 4)}
 
 
+    def in_flight(self, nfl=2, steps=40):
+        """Independent config-2 batches, `nfl` of them in flight: one handle and one stream each, launches issued round-robin.  Same kernel, same batch as the
+        headline; only the order of issue differs."""
+        torch, cm = self.torch, self.cm
+        cfg, P, X0 = cm.synthetic.config2_perturbed_com(256, seed=0)
+        dP, dX0 = torch.from_numpy(P.astype(np.float32)).to(self.dev), torch.from_numpy(X0.astype(np.float32)).to(self.dev)
+        solvers = [cm.BatchSolver(cfg, 256, device=self.devidx) for _ in range(nfl)]
+        outs = [(torch.empty_like(dX0), torch.empty((256, 8), dtype=torch.float32, device=self.dev)) for _ in range(nfl)]
+        raw = [s.launch_stream.cuda_stream for s in solvers]
+        for s in solvers:
+            s.set_timing(False)
+
+        def run(k):
+            for i in range(k):
+                j = i % nfl
+                solvers[j].solve_device(dP, dX0, outs[j][0], outs[j][1], stream=raw[j])
+        torch.cuda.synchronize()
+        run(2 * nfl)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run(steps)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        ok = all(bool((o[1][:, 5] == 0).all().item()) for o in outs)
+        same = all(bool(torch.equal(o[0], outs[0][0])) for o in outs[1:])
+        for s in solvers:
+            s.close()
+        return {"workload": f"config2 (B=256, horizon 20), {nfl} independent batches in flight on {nfl} streams, {steps} launches",
+                "value": round(256 * steps / dt, 1), "unit": "solves/s", "ms_per_batch": round(dt / steps * 1e3, 4), "batches_in_flight": nfl,
+                "all_converged": ok, "batches_bit_identical": same}
+
     def rollout(self, B=1024, ticks=60):
         """The reference's operating mode, timed end to end: every tick = merge the planner's footsteps with the MPC-adjusted current
         contact, sample the list, write the measured state, shift the previous solution, solve (warm), adjust the next footstep,
@@ -401,6 +435,10 @@ def main():
             continue
         if s == "rollout":
             secondary["rollout"] = R.rollout()
+            continue
+        if s == "inflight":
+            if R.world == 1:
+                secondary["two_batches_in_flight"] = R.in_flight()
             continue
         sm, sd = R.run(s, args.secondary_steps, 2)
         secondary[s] = sm

@@ -1832,7 +1832,7 @@ __device__ __forceinline__ void sq_consume_stage(const Ctx& c, const CmpcConsts&
                 avail = __builtin_amdgcn_readfirstlane(lds_peek(c.prog)) - seq0;
                 if (avail >= nblk) break;
                 if (++spins > SQ_SPIN_MAX) { gaveup = true; avail = 16; break; }
-                __builtin_amdgcn_s_sleep(1);
+                __builtin_amdgcn_s_sleep(1);                // (polling the stage's last block without the sleep changes nothing: measured)
             }
         };
         const float* pa0 = Wb + pl.pa0; const float* pa1 = Wb + pl.pa1; const float* pa2 = Wb + pl.pa2; const float* pa3 = Wb + pl.pa3;
@@ -1865,6 +1865,14 @@ __device__ __forceinline__ void sq_consume_stage(const Ctx& c, const CmpcConsts&
             CPROF(2);
 #pragma unroll
             for (int b = 0; b < 8; b += 2) {
+                if (b == 6 && sk8 && sk9) {
+                    // (the last pair one block at a time, like the tiles)
+                    need(7);
+                    gradient_pair(6, false, true);
+                    need(8);
+                    gradient_pair(6, true, false);
+                    continue;
+                }
                 need(b + 2);
                 gradient_pair(b, false, false);
                 if (b == 0) {
@@ -1874,7 +1882,12 @@ __device__ __forceinline__ void sq_consume_stage(const Ctx& c, const CmpcConsts&
                 }
             }
             CPROF(3);
-            if (!(sk8 && sk9)) {
+            if (!sk8 && !sk9) {
+                need(9);
+                gradient_pair(8, false, true);
+                need(10);
+                gradient_pair(8, true, false);
+            } else if (!(sk8 && sk9)) {
                 need(sk9 ? 9 : 10);
                 gradient_pair(8, sk8, sk9);
             }
@@ -1894,8 +1907,21 @@ __device__ __forceinline__ void sq_consume_stage(const Ctx& c, const CmpcConsts&
             // blocks 0..7 (the forces: never skipped) in pairs: the loads of both in flight, two chained MFMAs
 #pragma unroll
             for (int b = 0; b < 8; b += 2) {
-                need(b + 2);
                 float a0, b0, a1, b1;
+                if (b == 6 && sk8 && sk9) {
+                    // the last pair of a stage without landing-offset blocks, one block at a time: only block 7's operands and one matrix-pipe instruction are
+                    // left when the factorising wave publishes its last block
+                    need(7);
+                    operands(6, a0, b0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc, 0, 0, 0);
+                    if (two) acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, a0, acc2, 0, 0, 0);
+                    need(8);
+                    operands(7, a1, b1);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc, 0, 0, 0);
+                    if (two) acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, a1, acc2, 0, 0, 0);
+                    continue;
+                }
+                need(b + 2);
                 operands(b, a0, b0);
                 operands(b + 1, a1, b1);
                 acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc, 0, 0, 0);
@@ -1913,12 +1939,13 @@ __device__ __forceinline__ void sq_consume_stage(const Ctx& c, const CmpcConsts&
             CPROF(3);
             // blocks 8, 9: the landing offsets of the two feet
             if (!sk8 && !sk9) {
-                need(10);
                 float a0, b0, a1, b1;
+                need(9);
                 operands(8, a0, b0);
-                operands(9, a1, b1);
                 acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc, 0, 0, 0);
                 if (two) acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, a0, acc2, 0, 0, 0);
+                need(10);
+                operands(9, a1, b1);
                 acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc, 0, 0, 0);
                 if (two) acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, a1, acc2, 0, 0, 0);
             } else if (!sk8 || !sk9) {
