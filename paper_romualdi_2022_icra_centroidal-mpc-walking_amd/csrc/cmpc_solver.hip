@@ -798,6 +798,9 @@ __device__ __forceinline__ bool chol_block(v4f (&acc)[8], double (&dd)[3], int l
     // Float64 only where cancellation decides the answer: the Schur pivots p1, p2 of the block (barrier terms ~1e9 next to
     // cost curvature ~20) through two accurate reciprocals.  The entries of L are float32 numbers anyway (rows are stored
     // and applied in float32): they come from the float32 casts of the pivots and v_rsq_f32.
+    // (Elimination order on purpose.  The division-free form -- p1 = n1 / a, p2 = det / n1 from the minors n1 = a c - b^2 and det -- halves the dependent chain
+    // and was 1 % faster, but a corner with ONE active friction row has a rank-one 1e9 term in its block: the determinant then cancels twice, 1e27 against
+    // 4e11, and p2 loses every digit; the push goldens went from 1.6e-5 to 1.06e-4 on the forces.  profiles/r04_experiments_not_kept.txt, item 13.)
     const double i00 = rcp_d(d00);
     const double m10 = d10 * i00, m20 = d20 * i00;
     const double p1 = d11 - m10 * d10;
