@@ -1844,7 +1844,7 @@ __device__ __forceinline__ void sq_consume_stage(const Ctx& c, const CmpcConsts&
             const int o = NPAN * 4 * b;
             const float x0 = pa0[o], x1 = pa1[o], x2 = pa2[o], x3 = pa3[o];
             const float y0 = pb0[o], y1 = pb1[o], y2 = pb2[o], y3 = pb3[o];   // (a diagonal tile loads the same four again: no branch in the load stream)
-            a = wa0 * x0 + wa1 * x1 + wa2 * x2 + pl.wa3 * x3;
+            a = -(wa0 * x0 + wa1 * x1 + wa2 * x2 + pl.wa3 * x3);   // (the A operand negated: the accumulator then holds  assembled - Z^T Z  itself)
             bv = wb0 * y0 + wb1 * y1 + wb2 * y2 + pl.wb3 * y3;
         };
         // The gradient column (row 45 of M) has a wave of its own (no tile: with one it left the stage ~450 cycles after the others, every stage): v = W^T z_g a pair
@@ -1905,7 +1905,6 @@ __device__ __forceinline__ void sq_consume_stage(const Ctx& c, const CmpcConsts&
         } else {
             const bool two = wv == 3;             // tiles (1, 0) and (1, 1): the second is a x a of the same operand rows
             v4f acc2 = {0.f, 0.f, 0.f, 0.f};
-            float bs0 = 0.f, bs1 = 0.f, bs2 = 0.f, bs3 = 0.f, bt0 = 0.f, bt1 = 0.f, bt2 = 0.f, bt3 = 0.f;
             CPROF(2);
             // blocks 0..7 (the forces: never skipped) in pairs: the loads of both in flight, two chained MFMAs
 #pragma unroll
@@ -1917,26 +1916,27 @@ __device__ __forceinline__ void sq_consume_stage(const Ctx& c, const CmpcConsts&
                     need(7);
                     operands(6, a0, b0);
                     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc, 0, 0, 0);
-                    if (two) acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, a0, acc2, 0, 0, 0);
+                    if (two) acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, -a0, acc2, 0, 0, 0);
                     need(8);
                     operands(7, a1, b1);
                     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc, 0, 0, 0);
-                    if (two) acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, a1, acc2, 0, 0, 0);
+                    if (two) acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, -a1, acc2, 0, 0, 0);
                     continue;
                 }
                 need(b + 2);
                 operands(b, a0, b0);
                 operands(b + 1, a1, b1);
                 acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc, 0, 0, 0);
-                if (two) acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, a0, acc2, 0, 0, 0);
+                if (two) acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, -a0, acc2, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc, 0, 0, 0);
-                if (two) acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, a1, acc2, 0, 0, 0);
+                if (two) acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, -a1, acc2, 0, 0, 0);
                 if (b == 0) {
                     // every consumer wave's part of the assembly must be in LDS before the tiles are subtracted from it (long there by now); then what the tile is
-                    // subtracted from is fetched -- far ahead of the last blocks, off the tail of the stage
+                    // subtracted from is fetched and ADDED to the accumulator (the products enter negated) -- far ahead of the last blocks: behind the last block
+                    // only its matrix-pipe instruction and the stores are left
                     gaveup = !lds_wait_ge(c.flag + 3, SQ_TILE_WAVES * (ord + 1)) || gaveup;
-                    bs0 = Mn[pl.d0]; bs1 = Mn[pl.d1]; bs2 = Mn[pl.d2]; bs3 = Mn[pl.d3];
-                    if (two) { bt0 = Mn[pl.ri[5]]; bt1 = Mn[pl.ri[6]]; bt2 = Mn[pl.ri[7]]; bt3 = Mn[pl.ri[8]]; }
+                    acc += v4f{Mn[pl.d0], Mn[pl.d1], Mn[pl.d2], Mn[pl.d3]};
+                    if (two) acc2 += v4f{Mn[pl.ri[5]], Mn[pl.ri[6]], Mn[pl.ri[7]], Mn[pl.ri[8]]};
                 }
             }
             CPROF(3);
@@ -1946,27 +1946,27 @@ __device__ __forceinline__ void sq_consume_stage(const Ctx& c, const CmpcConsts&
                 need(9);
                 operands(8, a0, b0);
                 acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc, 0, 0, 0);
-                if (two) acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, a0, acc2, 0, 0, 0);
+                if (two) acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, -a0, acc2, 0, 0, 0);
                 need(10);
                 operands(9, a1, b1);
                 acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc, 0, 0, 0);
-                if (two) acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, a1, acc2, 0, 0, 0);
+                if (two) acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, -a1, acc2, 0, 0, 0);
             } else if (!sk8 || !sk9) {
                 const int b = sk8 ? 9 : 8;
                 need(b + 1);
                 float a0, b0;
                 operands(b, a0, b0);
                 acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc, 0, 0, 0);
-                if (two) acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, a0, acc2, 0, 0, 0);
+                if (two) acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, -a0, acc2, 0, 0, 0);
             }
             CPROF2(4);
             {
-                const float r0 = bs0 - acc[0], r1 = bs1 - acc[1], r2 = bs2 - acc[2], r3 = bs3 - acc[3];
+                const float r0 = acc[0], r1 = acc[1], r2 = acc[2], r3 = acc[3];
                 Mn[pl.d0] = r0; Mn[pl.d1] = r1; Mn[pl.d2] = r2; Mn[pl.d3] = r3;
                 if (wv == 2 || wv == 4) { Mn[pl.e0] = r0; Mn[pl.e1] = r1; Mn[pl.e2] = r2; Mn[pl.e3] = r3; }   // (tiles with entries of Qss: both triangles)
             }
             if (two) {
-                const float r0 = bt0 - acc2[0], r1 = bt1 - acc2[1], r2 = bt2 - acc2[2], r3 = bt3 - acc2[3];
+                const float r0 = acc2[0], r1 = acc2[1], r2 = acc2[2], r3 = acc2[3];
                 Mn[pl.ri[5]] = r0; Mn[pl.ri[6]] = r1; Mn[pl.ri[7]] = r2; Mn[pl.ri[8]] = r3;
                 Mn[pl.ri[9]] = r0; Mn[pl.ri[10]] = r1; Mn[pl.ri[11]] = r2; Mn[pl.ri[12]] = r3;
             }
