@@ -1719,7 +1719,7 @@ __device__ __forceinline__ void sq_consume_stage(const Ctx& c, const CmpcConsts&
             const float* qcol = Qc + pl.ri[0];
             const float* dk = c.d + NS * kb;
             double acc = 0.0;
-#pragma unroll
+#pragma unroll 5     // (fully unrolled, its thirty loads in flight were the register peak of the whole consumer loop: 30 more callee-saved registers saved per wave and pass)
             for (int a = 0; a < NS; ++a) acc += (double)qcol[16 * a] * (double)dk[a];
             const double hs = qsc[pl.ri[0]] + acc;
             const float du = c.U[NU * (havep ? kb + 1 : kb) + pl.ri[1]] - u[pl.ri[1]];
@@ -1759,7 +1759,7 @@ __device__ __forceinline__ void sq_consume_stage(const Ctx& c, const CmpcConsts&
             const float* qcol = Qc + pl.ri[0];
             const float* dk = c.d + NS * kb;
             double acc = 0.0;
-#pragma unroll
+#pragma unroll 5     // (fully unrolled, its thirty loads in flight were the register peak of the whole consumer loop: 30 more callee-saved registers saved per wave and pass)
             for (int a = 0; a < NS; ++a) acc += (double)qcol[16 * a] * (double)dk[a];
             if (ln < NS) hs[ln] = qsc[pl.ri[0]] + acc;
         }
