@@ -1497,8 +1497,9 @@ struct ConsPlan {
     // the lane's two tile operands: published rows (float index kq + 4 r into the publication buffer) and where their weights are
     int pa0, pa1, pa2, pa3, pb0, pb1, pb2, pb3, wa, wb;
     float wa3, wb3;
-    // where the four results of the lane go (float index from QuuF of the set) and their mirror images (Qss is kept with both triangles)
-    int d0, d1, d2, d3, e0, e1, e2, e3;
+    // where the four results of the lane go (float index from QuuF of the set); their mirror images (Qss is kept with both triangles: tiles (2,1), (2,2) and the
+    // second tile of the pair) live in ri[9..12] of the waves that own such a tile -- role slots those waves do not use
+    int d0, d1, d2, d3;
     // role of the wave: waves 1, 2, 3 the float64 parts (diagonal blocks, q_u, q_s), waves 5, 6, 7 Y; wave 7 carries the gradient column and no tile
     int ri[14];
     float rf[6];
@@ -1579,8 +1580,7 @@ __device__ inline void cons_plan_build(ConsPlan& pl, const Ctx& c, const CmpcCon
         };
         results(I, J, wv >= 0 && wv < 5);
         pl.d0 = d[0]; pl.d1 = d[1]; pl.d2 = d[2]; pl.d3 = d[3];
-        pl.e0 = e[0]; pl.e1 = e[1]; pl.e2 = e[2]; pl.e3 = e[3];
-        results(1, 1, wv == 3);            // (kept until the role part below: wave 3 stores them in ri[5..12])
+        if (wv == 3) results(1, 1, true);  // (d, e kept until the role part below: waves 2 and 4 store e, wave 3 the second tile's d and e)
     }
     // ---- role ----
 #pragma unroll
@@ -1624,6 +1624,7 @@ __device__ inline void cons_plan_build(ConsPlan& pl, const Ctx& c, const CmpcCon
         pl.ri[2] = gfo + ja1; pl.ri[3] = gfo + ja2; pl.ri[4] = (j >= 3 && j < 6) ? j - 3 : 0; pl.ri[5] = 6 + ja1; pl.ri[6] = 6 + ja2;
         pl.rf[0] = j != 2 ? qdiag(prm, 0, j) : 0.f; pl.rf[1] = j == 2 ? 1.f : 0.f; pl.rf[2] = jct ? 1.f : 0.f;
         pl.rf[3] = j < 3 ? 1.f : 0.f; pl.rf[4] = (j >= 3 && j < 6) ? 1.f : 0.f; pl.rf[5] = j >= 9 ? 1.f : 0.f;
+        pl.ri[9] = e[0]; pl.ri[10] = e[1]; pl.ri[11] = e[2]; pl.ri[12] = e[3];         // mirror images of tile (2, 1)
     } else if (wv >= 3) {
         // Y^T = (Qss [B A])^T: one float4 per lane (180 of the 192)
         const int t = 64 * (wv - 3) + ln, col = t >> 2, q = t & 3;
@@ -1636,6 +1637,8 @@ __device__ inline void cons_plan_build(ConsPlan& pl, const Ctx& c, const CmpcCon
             // the second tile's results and their mirror images
             pl.ri[5] = d[0]; pl.ri[6] = d[1]; pl.ri[7] = d[2]; pl.ri[8] = d[3];
             pl.ri[9] = e[0]; pl.ri[10] = e[1]; pl.ri[11] = e[2]; pl.ri[12] = e[3];
+        } else if (wv == 4) {
+            pl.ri[9] = e[0]; pl.ri[10] = e[1]; pl.ri[11] = e[2]; pl.ri[12] = e[3];     // mirror images of tile (2, 2)
         }
         if (wv == 5) {
             // gradient column: z_g of a pair of pivot blocks by eight lanes per entry (term gt and gt + 8 of the sixteen; entry ge = 3 block + component in lanes 8 ge ..),
@@ -1963,7 +1966,7 @@ __device__ __forceinline__ void sq_consume_stage(const Ctx& c, const CmpcConsts&
             {
                 const float r0 = acc[0], r1 = acc[1], r2 = acc[2], r3 = acc[3];
                 Mn[pl.d0] = r0; Mn[pl.d1] = r1; Mn[pl.d2] = r2; Mn[pl.d3] = r3;
-                if (wv == 2 || wv == 4) { Mn[pl.e0] = r0; Mn[pl.e1] = r1; Mn[pl.e2] = r2; Mn[pl.e3] = r3; }   // (tiles with entries of Qss: both triangles)
+                if (wv == 2 || wv == 4) { Mn[pl.ri[9]] = r0; Mn[pl.ri[10]] = r1; Mn[pl.ri[11]] = r2; Mn[pl.ri[12]] = r3; }   // (tiles with entries of Qss: both triangles)
             }
             if (two) {
                 const float r0 = acc2[0], r1 = acc2[1], r2 = acc2[2], r3 = acc2[3];
