@@ -2171,24 +2171,26 @@ __device__ __forceinline__ void forward_sweep(const Ctx& c, const CmpcConsts& pr
     PROF2_DECL;
     // records in HBM: the operands of a stage are fetched ONE STAGE AHEAD (they do not depend on the recursion): an L2 / fabric round trip of ~250-500 cycles per stage and
     // sweep was exposed at the top of every stage (4 % of a config-3 solve, profiles/r03_pmc_wait_config3.json)
+    // (only the twenty scalars of the y-step: the four float4 of the du-step are issued at the top of their own stage and arrive under the y-step; a stage ahead
+    //  as well they cost sixteen more registers, and at 168 the sweep then reloaded two spilled pointers at the top of every trip, each behind an s_waitcnt vmcnt(0))
     float ymn[20];
-    float4 umn[4];
     auto fetch = [&](int k) {
         const RecRef<G> rec(c.Lf, N, k);
 #pragma unroll
         for (int t = 0; t < 20; ++t) ymn[t] = rec.ld(yoff[t]);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) umn[t] = rec.ld4(uoff[t]);
     };
     if (G) fetch(k0);
     auto stage = [&](int i, int k) {
         float ym[20];
         float4 um[4];
         if (G) {
+            {
+                const RecRef<G> rec(c.Lf, N, k);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) um[t] = rec.ld4(uoff[t]);
+            }
 #pragma unroll
             for (int t = 0; t < 20; ++t) ym[t] = ymn[t];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) um[t] = umn[t];
             fetch(k + 1 < N ? k + 1 : k);
         } else {
 #pragma unroll
