@@ -713,10 +713,10 @@ __device__ inline double rcp_d(double x)
 // where row m of the identity starts in the strips (float offset, a multiple of 4)
 __device__ inline int id_row(int m) { return ID_STRIP_LEN * (m & 3) + 32 + (m & 3) - m; }
 // rank-1 update of the column groups G0 .. 7 (av: -x of the L rows below the pivot block, 0 elsewhere; bv: the lane's own x)
-template <int G0>
+template <int G0, int GE = 8>
 __device__ __forceinline__ void trail_rank1(v4f (&acc)[8], float av, float bv)
 {
-#define CMPC_R1(G) if constexpr (G >= G0) acc[G] = __builtin_amdgcn_mfma_f32_4x4x1f32(av, bv, acc[G], 4, G, 0);
+#define CMPC_R1(G) if constexpr (G >= G0 && G < GE) acc[G] = __builtin_amdgcn_mfma_f32_4x4x1f32(av, bv, acc[G], 4, G, 0);
     CMPC_R1(0) CMPC_R1(1) CMPC_R1(2) CMPC_R1(3) CMPC_R1(4) CMPC_R1(5) CMPC_R1(6) CMPC_R1(7)
 #undef CMPC_R1
 }
@@ -766,10 +766,15 @@ struct RowStore {
     }
 };
 // pivot block B (columns 3 B .. 3 B + 2).  Returns true if a pivot was not positive.
-template <int B, bool PUB, typename ST>
+// FIX: every landing offset of the stage is fixed (double stance: fixedmask == 63, decided once per stage by the caller).  Their rows and columns are identity rows
+// and columns: blocks 8, 9 have nothing to do (that much is also tested at run time below), AND the trailing updates of column groups 6, 7 (columns 24..29 + padding) add
+// exact zeros -- the update of column 24 + i is (-x of L row 24 + i) x (the lane's x), and the x of an identity row is zero in every block: 48 of the stage's 126
+// matrix-pipe instructions, left out at compile time.  (Left out behind a branch per block the same saving was a loss: profiles/r04_experiments_not_kept.txt, item 18.)
+template <int B, bool PUB, bool FIX, typename ST>
 __device__ __forceinline__ bool chol_block(v4f (&acc)[8], double (&dd)[3], int lane, int fixedmask, CholPub& pb, ST& st)
 {
     constexpr int j0 = 3 * B;
+    if constexpr (FIX && B >= 8) return false;
     if (B == LATE_B) {
         if (lane < NLATE) {
             const float* idr = pb.idstrip + id_row(LATE_M0 + lane);
@@ -839,9 +844,10 @@ __device__ __forceinline__ bool chol_block(v4f (&acc)[8], double (&dd)[3], int l
         const bool below = (unsigned)(ln - (j0 + 3)) < (unsigned)(NU - (j0 + 3));
         const float a0 = below ? -x0 : 0.f, a1 = below ? -x1 : 0.f, a2 = below ? -x2 : 0.f;
         constexpr int G0 = (j0 + 3) >> 2;
-        trail_rank1<G0>(acc, a0, x0);
-        trail_rank1<G0>(acc, a1, x1);
-        trail_rank1<G0>(acc, a2, x2);
+        constexpr int GE = FIX ? 6 : 8;
+        trail_rank1<G0, GE>(acc, a0, x0);
+        trail_rank1<G0, GE>(acc, a1, x1);
+        trail_rank1<G0, GE>(acc, a2, x2);
     }
     // chunks whose last column this block finished (behind the matrix-pipe instructions: the stores drain while those execute).  LDS records only.  With the
     // records in HBM the same early stores are SLOWER (config 3 412.4 k -> 405.8 k solves/s, config 5 266.6 k -> 261.6 k: global_store_dwordx4 from inside the
@@ -859,22 +865,22 @@ __device__ __forceinline__ bool chol_block(v4f (&acc)[8], double (&dd)[3], int l
     return bad;
 }
 // ---- fused Cholesky + panel solve, one wave, rows in registers, 3x3 pivot blocks (see the comment block above rcp_d) ----
-template <bool PUB, typename ST>
+template <bool PUB, bool FIX, typename ST>
 __device__ __forceinline__ bool chol_solve_fused(v4f (&acc)[8], double (&dd)[3], int lane, int fixedmask, ST& st, const float* idstrip, float* pub = nullptr,
                                                  int pubstride = 0, int* pflag = nullptr, int seq0 = 0, float* publate = nullptr)
 {
     CholPub pb{pub, pubstride, pflag, seq0, publate, idstrip};
     bool bad = false;
-    bad |= chol_block<0, PUB>(acc, dd, lane, fixedmask, pb, st);
-    bad |= chol_block<1, PUB>(acc, dd, lane, fixedmask, pb, st);
-    bad |= chol_block<2, PUB>(acc, dd, lane, fixedmask, pb, st);
-    bad |= chol_block<3, PUB>(acc, dd, lane, fixedmask, pb, st);
-    bad |= chol_block<4, PUB>(acc, dd, lane, fixedmask, pb, st);
-    bad |= chol_block<5, PUB>(acc, dd, lane, fixedmask, pb, st);
-    bad |= chol_block<6, PUB>(acc, dd, lane, fixedmask, pb, st);
-    bad |= chol_block<7, PUB>(acc, dd, lane, fixedmask, pb, st);
-    bad |= chol_block<8, PUB>(acc, dd, lane, fixedmask, pb, st);
-    bad |= chol_block<9, PUB>(acc, dd, lane, fixedmask, pb, st);
+    bad |= chol_block<0, PUB, FIX>(acc, dd, lane, fixedmask, pb, st);
+    bad |= chol_block<1, PUB, FIX>(acc, dd, lane, fixedmask, pb, st);
+    bad |= chol_block<2, PUB, FIX>(acc, dd, lane, fixedmask, pb, st);
+    bad |= chol_block<3, PUB, FIX>(acc, dd, lane, fixedmask, pb, st);
+    bad |= chol_block<4, PUB, FIX>(acc, dd, lane, fixedmask, pb, st);
+    bad |= chol_block<5, PUB, FIX>(acc, dd, lane, fixedmask, pb, st);
+    bad |= chol_block<6, PUB, FIX>(acc, dd, lane, fixedmask, pb, st);
+    bad |= chol_block<7, PUB, FIX>(acc, dd, lane, fixedmask, pb, st);
+    bad |= chol_block<8, PUB, FIX>(acc, dd, lane, fixedmask, pb, st);
+    bad |= chol_block<9, PUB, FIX>(acc, dd, lane, fixedmask, pb, st);
     if constexpr (ST::EARLY) {
         st.template chunk<6>(acc[6]);
         st.template chunk<7>(acc[7]);
@@ -884,7 +890,9 @@ __device__ __forceinline__ bool chol_solve_fused(v4f (&acc)[8], double (&dd)[3],
 
 // phase 3 of a backward stage, kept out of line so that its ~40 VGPRs of matrix rows and its
 // stream of v_readlane broadcasts get a register allocation of their own
-template <bool G, bool PUB = false>
+// FIXSEL: which copy of the ten blocks (chol_block's FIX): 1 / 0 chosen by the caller at compile time (stage_mid of the HBM-factor variants exists in both forms and its
+// caller branches: inside ONE function the second copy cost 17 callee-saved registers at 168), -1: chosen here, once per stage, by a scalar branch (streaming stage)
+template <bool G, bool PUB = false, int FIXSEL = -1>
 __device__ __forceinline__ void stage_factor(const float* QuuF, const double* QuuD, float* Pan, const RecRef<G>& rec, const float* idstrip,
                                           const float* Dp, int* flag, int tid, int fixedmask, float* pub = nullptr, int* pflag = nullptr, int seq0 = 0)
 {
@@ -920,8 +928,17 @@ __device__ __forceinline__ void stage_factor(const float* QuuF, const double* Qu
     RowStore<G, PUB> st(rec, Pan, Dp);
     typedef RowStore<G, PUB> ST;
     if (ST::EARLY && !isL && active) st.set_row(prow);
-    const bool bad = chol_solve_fused<PUB>(acc, dd, lane, fixedmask, st, idstrip, pubp, (!isL && active) ? NPAN * 4 : 0, pflag, seq0,
-                                                PUB ? pub + (NS + LATE_M0 + (lane < NLATE ? lane : 0)) * 4 : nullptr);
+    // (two copies of the ten blocks, chosen once per stage by a scalar branch: see chol_block)
+    float* const publate = PUB ? pub + (NS + LATE_M0 + (lane < NLATE ? lane : 0)) * 4 : nullptr;
+    const int pubstride = (!isL && active) ? NPAN * 4 : 0;
+    bool bad;
+    if constexpr (FIXSEL == 1) bad = chol_solve_fused<PUB, true>(acc, dd, lane, fixedmask, st, idstrip, pubp, pubstride, pflag, seq0, publate);
+    else if constexpr (FIXSEL == 0) bad = chol_solve_fused<PUB, false>(acc, dd, lane, fixedmask, st, idstrip, pubp, pubstride, pflag, seq0, publate);
+    else {
+        const bool allfixed = (__builtin_amdgcn_readfirstlane(fixedmask) & 63) == 63;   // (wave-uniform by construction; made provably so: a scalar branch)
+        bad = allfixed ? chol_solve_fused<PUB, true>(acc, dd, lane, fixedmask, st, idstrip, pubp, pubstride, pflag, seq0, publate)
+                       : chol_solve_fused<PUB, false>(acc, dd, lane, fixedmask, st, idstrip, pubp, pubstride, pflag, seq0, publate);
+    }
     PROF2(29);
     if (bad && tid == 0) *flag = 1;
     if constexpr (!ST::EARLY) {
@@ -1370,7 +1387,7 @@ __device__ __attribute__((noinline)) void stage_desc(lds_t lds, int Nrt, float* 
 // variants), Qss and the descriptors of stage k-1 on the others -- and the barrier behind it.  stage_post_pre: phase 4 of stage k,
 // then phases 1-2 of stage k-1.  (Four calls per stage cost 2 % in prologues and stage addresses; all of it behind ONE call is
 // within +-0.5 % of two.  The one-call variant is how the buffer-store problem described at RecRef<true> was found.)
-template <int NT, int NC, bool FG>
+template <int NT, int NC, bool FG, bool FIX = false>
 __device__ __attribute__((noinline)) void stage_mid(lds_t lds, int Nrt, float* fg_base, int k_in, bool exact_in, float cmu, int tqp)
 {
     CMPC_PHASE_PROLOGUE;
@@ -1379,7 +1396,7 @@ __device__ __attribute__((noinline)) void stage_mid(lds_t lds, int Nrt, float* f
     PROF_DECL;
     if (tid < 64) {
         const int fixedmask = (~c.qmask[k]) & 63;
-        stage_factor<FG>(c.QuuF, c.QuuD, c.Pan, RecRef<FG>(c.Lf, N, k), c.idstrip, prm.D, c.flag, tid, fixedmask);
+        stage_factor<FG, false, FIX ? 1 : 0>(c.QuuF, c.QuuD, c.Pan, RecRef<FG>(c.Lf, N, k), c.idstrip, prm.D, c.flag, tid, fixedmask);
     } else if (tid >= 128) {
         use_desc_set(c, k & 1);
         stage_qss_body<NT>(c, prm, tid, k, c.P0, c.Qb, tqp);
@@ -2072,7 +2089,9 @@ __device__ int riccati_backward(lds_t lds, const Ctx& c, const CmpcConsts& prm, 
     // P0 holds the value function of stage k+1 and is overwritten in place by phase 4 (its last reader, Qss, ran in phase 3)
     stage_pre<NT, NC, FG>(lds, N, fg_base, N - 1, false, use_exact, reg, cmu, tpk);
     for (int k = N - 1; k >= k0; --k) {
-        stage_mid<NT, NC, FG>(lds, N, fg_base, k, use_exact, cmu, tqp);
+        // (a double-stance stage has its own copy of the factorisation: chol_block's FIX)
+        if (((~__builtin_amdgcn_readfirstlane(c.qmask[k])) & 63) == 63) stage_mid<NT, NC, FG, true>(lds, N, fg_base, k, use_exact, cmu, tqp);
+        else stage_mid<NT, NC, FG, false>(lds, N, fg_base, k, use_exact, cmu, tqp);
         if (k > k0 || k0 == 0) stage_post_pre<NT, NC, FG>(lds, N, fg_base, k, use_exact, reg, cmu, tpk, tqp);   // (the value function of stage k0 > 0 has no reader)
     }
     // (a non-positive pivot raises the flag and the stages after it run on garbage, harmlessly -- every array they write is
