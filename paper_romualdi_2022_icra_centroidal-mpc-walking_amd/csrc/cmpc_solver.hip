@@ -181,6 +181,7 @@ typedef __attribute__((address_space(3))) float* ldsw_t;
 __device__ inline ldsf_t lds_opaque(const float* p) { ldsf_t q = (ldsf_t)p; asm volatile("" : "+v"(q)); return q; }
 __device__ inline ldsw_t lds_opaque_w(float* p) { ldsw_t q = (ldsw_t)p; asm volatile("" : "+v"(q)); return q; }
 typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v2f __attribute__((ext_vector_type(2)));
 __device__ inline float4 lds_ld4(ldsf_t p)
 {
     const v4f v = *reinterpret_cast<__attribute__((address_space(3))) const v4f*>(p);
@@ -1864,8 +1865,12 @@ __device__ __forceinline__ void sq_consume_stage(const Ctx& c, const CmpcConsts&
             const int o = NPAN * 4 * b;
             const float x0 = pa0[o], x1 = pa1[o], x2 = pa2[o], x3 = pa3[o];
             const float y0 = pb0[o], y1 = pb1[o], y2 = pb2[o], y3 = pb3[o];   // (a diagonal tile loads the same four again: no branch in the load stream)
-            a = -(wa0 * x0 + wa1 * x1 + wa2 * x2 + pl.wa3 * x3);   // (the A operand negated: the accumulator then holds  assembled - Z^T Z  itself)
-            bv = wb0 * y0 + wb1 * y1 + wb2 * y2 + pl.wb3 * y3;
+            // (the A operand negated: the accumulator then holds  assembled - Z^T Z  itself; both operands in one packed multiply-add chain)
+            v2f ab = v2f{-wa0, wb0} * v2f{x0, y0};
+            ab = __builtin_elementwise_fma(v2f{-wa1, wb1}, v2f{x1, y1}, ab);
+            ab = __builtin_elementwise_fma(v2f{-wa2, wb2}, v2f{x2, y2}, ab);
+            ab = __builtin_elementwise_fma(v2f{-pl.wa3, pl.wb3}, v2f{x3, y3}, ab);
+            a = ab[0]; bv = ab[1];
         };
         // The gradient column (row 45 of M) has a wave of its own (no tile: with one it left the stage ~450 cycles after the others, every stage): v = W^T z_g a pair
         // of pivot blocks at a time -- see the plan (ri[5..12]) --, and at the end M[45][j] -= sum_a w_a(j) v[r_a(j)], the same sparse combination as a row of Z^T.
@@ -2234,13 +2239,14 @@ __device__ __forceinline__ void forward_sweep(const Ctx& c, const CmpcConsts& pr
         //  per stage, +0.6 % at B = 256.  The 168-register variants keep the pairwise form: as chains the sweep spills two more registers inside the loop, -2.9 % on config 3.)
         float ya, yc;
         if (!G) {
-            ya = ym[0] * xv[0].x; yc = ym[1] * xv[0].y;
-            ya = fmaf(ym[2], xv[0].z, ya); yc = fmaf(ym[3], xv[0].w, yc);
+            v2f yp = v2f{ym[0], ym[1]} * v2f{xv[0].x, xv[0].y}, yq = v2f{ym[2], ym[3]} * v2f{xv[0].z, xv[0].w};
 #pragma unroll
             for (int t = 1; t < 5; ++t) {
-                ya = fmaf(ym[4 * t], xv[t].x, ya); yc = fmaf(ym[4 * t + 1], xv[t].y, yc);
-                ya = fmaf(ym[4 * t + 2], xv[t].z, ya); yc = fmaf(ym[4 * t + 3], xv[t].w, yc);
+                yp = __builtin_elementwise_fma(v2f{ym[4 * t], ym[4 * t + 1]}, v2f{xv[t].x, xv[t].y}, yp);
+                yq = __builtin_elementwise_fma(v2f{ym[4 * t + 2], ym[4 * t + 3]}, v2f{xv[t].z, xv[t].w}, yq);
             }
+            yp += yq;
+            ya = yp[0]; yc = yp[1];
         } else {
             ya = 0.f; yc = 0.f;
 #pragma unroll
@@ -2258,15 +2264,15 @@ __device__ __forceinline__ void forward_sweep(const Ctx& c, const CmpcConsts& pr
         for (int q = 0; q < 4; ++q) yv[q] = lds_ld4(yvp + 4 * q);
         float wsum;
         if (!G) {
-            float wa = um[0].x * yv[0].x, wc = um[2].x * yv[2].x;
-            wa = fmaf(um[0].y, yv[0].y, wa); wc = fmaf(um[2].y, yv[2].y, wc);
-            wa = fmaf(um[0].z, yv[0].z, wa); wc = fmaf(um[2].z, yv[2].z, wc);
-            wa = fmaf(um[0].w, yv[0].w, wa); wc = fmaf(um[2].w, yv[2].w, wc);
-            wa = fmaf(um[1].x, yv[1].x, wa); wc = fmaf(um[3].x, yv[3].x, wc);
-            wa = fmaf(um[1].y, yv[1].y, wa); wc = fmaf(um[3].y, yv[3].y, wc);
-            wa = fmaf(um[1].z, yv[1].z, wa); wc = fmaf(um[3].z, yv[3].z, wc);
-            wa = fmaf(um[1].w, yv[1].w, wa); wc = fmaf(um[3].w, yv[3].w, wc);
-            wsum = wa + wc;
+            // two packed multiply-add chains (v_pk_fma_f32: two lanes' worth per instruction; both operands come in register pairs out of 16-byte loads)
+            v2f wp = v2f{um[0].x, um[0].y} * v2f{yv[0].x, yv[0].y}, wq = v2f{um[0].z, um[0].w} * v2f{yv[0].z, yv[0].w};
+#pragma unroll
+            for (int q = 1; q < 4; ++q) {
+                wp = __builtin_elementwise_fma(v2f{um[q].x, um[q].y}, v2f{yv[q].x, yv[q].y}, wp);
+                wq = __builtin_elementwise_fma(v2f{um[q].z, um[q].w}, v2f{yv[q].z, yv[q].w}, wq);
+            }
+            wp += wq;
+            wsum = wp[0] + wp[1];
         } else {
             wsum = (dot4(um[0], yv[0]) + dot4(um[1], yv[1])) + (dot4(um[2], yv[2]) + dot4(um[3], yv[3]));
         }
@@ -2463,11 +2469,24 @@ __device__ __forceinline__ void delta_sweep(const Ctx& c, const CmpcConsts& prm,
         float4 gv[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) gv[t] = lds_ld4(gbp + 4 * t);
-        float la = 0.f, lc = 0.f;
+        float la, lc;
+        if (!G) {
+            // (packed multiply-add chains, as in forward_sweep)
+            v2f lp = v2f{lm[0], lm[1]} * v2f{gv[0].x, gv[0].y}, lq = v2f{lm[2], lm[3]} * v2f{gv[0].z, gv[0].w};
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            la += lm[4 * t] * gv[t].x + lm[4 * t + 2] * gv[t].z;
-            lc += lm[4 * t + 1] * gv[t].y + lm[4 * t + 3] * gv[t].w;
+            for (int t = 1; t < 4; ++t) {
+                lp = __builtin_elementwise_fma(v2f{lm[4 * t], lm[4 * t + 1]}, v2f{gv[t].x, gv[t].y}, lp);
+                lq = __builtin_elementwise_fma(v2f{lm[4 * t + 2], lm[4 * t + 3]}, v2f{gv[t].z, gv[t].w}, lq);
+            }
+            lp += lq;
+            la = lp[0]; lc = lp[1];
+        } else {
+            la = 0.f; lc = 0.f;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                la += lm[4 * t] * gv[t].x + lm[4 * t + 2] * gv[t].z;
+                lc += lm[4 * t + 1] * gv[t].y + lm[4 * t + 3] * gv[t].w;
+            }
         }
         const float dl = half_sum(la + lc);
         *lbs = dl;                      // (both halves hold the same dl)
@@ -2483,8 +2502,20 @@ __device__ __forceinline__ void delta_sweep(const Ctx& c, const CmpcConsts& prm,
         float4 dv[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) dv[q] = lds_ld4(lbp + 4 * q);
-        const float sm = ((dot4(fm[0], dv[0]) + dot4(fm[1], dv[1])) + (dot4(fm[2], dv[2]) + dot4(fm[3], dv[3])))
-                         + ((dot4(fm[4], dv[4]) + dot4(fm[5], dv[5])) + (dot4(fm[6], dv[6]) + dot4(fm[7], dv[7])));
+        float sm;
+        if (!G) {
+            v2f sp = v2f{fm[0].x, fm[0].y} * v2f{dv[0].x, dv[0].y}, sq = v2f{fm[0].z, fm[0].w} * v2f{dv[0].z, dv[0].w};
+#pragma unroll
+            for (int q = 1; q < 8; ++q) {
+                sp = __builtin_elementwise_fma(v2f{fm[q].x, fm[q].y}, v2f{dv[q].x, dv[q].y}, sp);
+                sq = __builtin_elementwise_fma(v2f{fm[q].z, fm[q].w}, v2f{dv[q].z, dv[q].w}, sq);
+            }
+            sp += sq;
+            sm = sp[0] + sp[1];
+        } else {
+            sm = ((dot4(fm[0], dv[0]) + dot4(fm[1], dv[1])) + (dot4(fm[2], dv[2]) + dot4(fm[3], dv[3])))
+                 + ((dot4(fm[4], dv[4]) + dot4(fm[5], dv[5])) + (dot4(fm[6], dv[6]) + dot4(fm[7], dv[7])));
+        }
         const float gamj = fmaf(hjsel, dgam, gam0);
         const float sj = fmaf(hposm, gamj - 1.f, 1.f);
         const float cg = fmaf(hcg1, gamj, hcg0);
