@@ -2235,10 +2235,11 @@ __device__ __forceinline__ void forward_sweep(const Ctx& c, const CmpcConsts& pr
         float4 xv[5];
 #pragma unroll
         for (int t = 0; t < 5; ++t) xv[t] = lds_ld4(xvp + 4 * t);
-        // (resident variants: two multiply-add chains, written as chains -- "ya += a b + c d" compiles to a multiply, a multiply-add and an add: eight instructions
-        //  per stage, +0.6 % at B = 256.  The 168-register variants keep the pairwise form: as chains the sweep spills two more registers inside the loop, -2.9 % on config 3.)
+        // (packed multiply-add chains -- v_pk_fma_f32: two multiply-adds per instruction, and instructions are what a single-wave phase pays for; the operands
+        //  arrive in register pairs: 16-byte loads, or two 4-byte loads the allocator places side by side.  20 scalar multiply-adds -> 10 packed + 3 adds here, 16 -> 8 in
+        //  the du-step; the forward sweep 1 117 -> 1 019 instructions per four stages, the corrector sweep 1 078 -> 984 per two: +3.5 % at B = 256, +1.7 % on configs 3 / 5)
         float ya, yc;
-        if (!G) {
+        {
             v2f yp = v2f{ym[0], ym[1]} * v2f{xv[0].x, xv[0].y}, yq = v2f{ym[2], ym[3]} * v2f{xv[0].z, xv[0].w};
 #pragma unroll
             for (int t = 1; t < 5; ++t) {
@@ -2247,13 +2248,6 @@ __device__ __forceinline__ void forward_sweep(const Ctx& c, const CmpcConsts& pr
             }
             yp += yq;
             ya = yp[0]; yc = yp[1];
-        } else {
-            ya = 0.f; yc = 0.f;
-#pragma unroll
-            for (int t = 0; t < 5; ++t) {
-                ya += ym[4 * t] * xv[t].x + ym[4 * t + 2] * xv[t].z;
-                yc += ym[4 * t + 1] * xv[t].y + ym[4 * t + 3] * xv[t].w;
-            }
         }
         const float y = half_sum(ya + yc);
         *ybs = y;                       // (both halves hold the same y: the same value to the same word)
@@ -2263,7 +2257,7 @@ __device__ __forceinline__ void forward_sweep(const Ctx& c, const CmpcConsts& pr
 #pragma unroll
         for (int q = 0; q < 4; ++q) yv[q] = lds_ld4(yvp + 4 * q);
         float wsum;
-        if (!G) {
+        {
             // two packed multiply-add chains (v_pk_fma_f32: two lanes' worth per instruction; both operands come in register pairs out of 16-byte loads)
             v2f wp = v2f{um[0].x, um[0].y} * v2f{yv[0].x, yv[0].y}, wq = v2f{um[0].z, um[0].w} * v2f{yv[0].z, yv[0].w};
 #pragma unroll
@@ -2273,8 +2267,6 @@ __device__ __forceinline__ void forward_sweep(const Ctx& c, const CmpcConsts& pr
             }
             wp += wq;
             wsum = wp[0] + wp[1];
-        } else {
-            wsum = (dot4(um[0], yv[0]) + dot4(um[1], yv[1])) + (dot4(um[2], yv[2]) + dot4(um[3], yv[3]));
         }
         const float du = -half_sum(wsum);
         *dUs = du;
@@ -2470,7 +2462,7 @@ __device__ __forceinline__ void delta_sweep(const Ctx& c, const CmpcConsts& prm,
 #pragma unroll
         for (int t = 0; t < 4; ++t) gv[t] = lds_ld4(gbp + 4 * t);
         float la, lc;
-        if (!G) {
+        {
             // (packed multiply-add chains, as in forward_sweep)
             v2f lp = v2f{lm[0], lm[1]} * v2f{gv[0].x, gv[0].y}, lq = v2f{lm[2], lm[3]} * v2f{gv[0].z, gv[0].w};
 #pragma unroll
@@ -2480,13 +2472,6 @@ __device__ __forceinline__ void delta_sweep(const Ctx& c, const CmpcConsts& prm,
             }
             lp += lq;
             la = lp[0]; lc = lp[1];
-        } else {
-            la = 0.f; lc = 0.f;
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                la += lm[4 * t] * gv[t].x + lm[4 * t + 2] * gv[t].z;
-                lc += lm[4 * t + 1] * gv[t].y + lm[4 * t + 3] * gv[t].w;
-            }
         }
         const float dl = half_sum(la + lc);
         *lbs = dl;                      // (both halves hold the same dl)
@@ -2503,7 +2488,7 @@ __device__ __forceinline__ void delta_sweep(const Ctx& c, const CmpcConsts& prm,
 #pragma unroll
         for (int q = 0; q < 8; ++q) dv[q] = lds_ld4(lbp + 4 * q);
         float sm;
-        if (!G) {
+        {
             v2f sp = v2f{fm[0].x, fm[0].y} * v2f{dv[0].x, dv[0].y}, sq = v2f{fm[0].z, fm[0].w} * v2f{dv[0].z, dv[0].w};
 #pragma unroll
             for (int q = 1; q < 8; ++q) {
@@ -2512,9 +2497,6 @@ __device__ __forceinline__ void delta_sweep(const Ctx& c, const CmpcConsts& prm,
             }
             sp += sq;
             sm = sp[0] + sp[1];
-        } else {
-            sm = ((dot4(fm[0], dv[0]) + dot4(fm[1], dv[1])) + (dot4(fm[2], dv[2]) + dot4(fm[3], dv[3])))
-                 + ((dot4(fm[4], dv[4]) + dot4(fm[5], dv[5])) + (dot4(fm[6], dv[6]) + dot4(fm[7], dv[7])));
         }
         const float gamj = fmaf(hjsel, dgam, gam0);
         const float sj = fmaf(hposm, gamj - 1.f, 1.f);
