@@ -1680,10 +1680,10 @@ __device__ inline void cons_plan_build(ConsPlan& pl, const Ctx& c, const CmpcCon
 }
 // One stage of the consumers.  S: the set stage kb is assembled in (kb & 1); k: stage being factorised meanwhile (N: none -- the terminal call: only stage N-1 is
 // assembled, no previous-force block: havep false); kd: stage whose descriptors wave 4 builds (-1: none); ord: ordinal of the stage within the pass.  All uniform.
-template <int S>
 __device__ __forceinline__ void sq_consume_stage(const Ctx& c, const CmpcConsts& prm, const ConsPlan& pl, int tid, int N, int k, int kb, int kd, int ord, bool havep,
                                                  bool use_exact, float reg, float cmu)
 {
+    const int S = kb & 1;   // (a runtime value: one copy of the body for both sets, the set offsets in scalar registers -- see sq_consume_loop)
     const int w7 = tid >> 6, ln = tid & 63;
     const int wv = w7 < 4 ? w7 - 1 : w7 - 2;
     if (w7 == 4) {
@@ -2009,17 +2009,17 @@ __device__ __attribute__((noinline)) void sq_consume_loop(lds_t lds, int Nrt, fl
     const bool use_exact = __builtin_amdgcn_readfirstlane((int)exact_in) != 0;
     ConsPlan pl;
     cons_plan_build(pl, c, prm, tid >> 6, tid & 63, c.Brow + ((N - 1) & 1) * DSET_I);   // (the rows of set (N-1) & 1: built by sq_init whatever k0 is)
-    if ((N - 1) & 1) sq_consume_stage<1>(c, prm, pl, tid, N, N, N - 1, -1, 0, false, use_exact, reg, cmu);
-    else sq_consume_stage<0>(c, prm, pl, tid, N, N, N - 1, -1, 0, false, use_exact, reg, cmu);
+    // ONE copy of the stage body serves both sets (the set offsets in scalar registers): the consumers wait for the factorisation, so the few scalar instructions a runtime
+    // set costs them are free, and a body per set was 12 KB more code in a 64 KB instruction cache that an iteration's ~80 KB cycle through: +0.6 % at B = 256.
+    // (The terminal assembly -- stage N-1 from the terminal cost, no value function yet -- stays a call of its own: with `havep` a runtime value as well the stage
+    //  body lost what the single copy had gained, 341.9 k -> 335.6 k solves/s.)
+    sq_consume_stage(c, prm, pl, tid, N, N, N - 1, -1, 0, false, use_exact, reg, cmu);
     __syncthreads();
     int ord = 0;
 #pragma unroll 1
     SQ_STAGE_LOOP(k, N, k0) {                          // (sq_pass_barriers: one barrier per trip, no early exit)
         ++ord;
-        if (k > k0) {
-            if ((k - 1) & 1) sq_consume_stage<1>(c, prm, pl, tid, N, k, k - 1, k - 2 >= k0 ? k - 2 : -1, ord, true, use_exact, reg, cmu);
-            else sq_consume_stage<0>(c, prm, pl, tid, N, k, k - 1, k - 2 >= k0 ? k - 2 : -1, ord, true, use_exact, reg, cmu);
-        }
+        if (k > k0) sq_consume_stage(c, prm, pl, tid, N, k, k - 1, k - 2 >= k0 ? k - 2 : -1, ord, true, use_exact, reg, cmu);
         __syncthreads();
     }
 }
@@ -2558,12 +2558,12 @@ __device__ void step_lengths(const Ctx& c, int tid, float tau, float& ap, float&
 
 // new costates (backward, wave 0), blended into LAM with step ap:
 //   lam_k = gs_k + Q_k ds_k + S_k^T du_k + A_k^T lam_{k+1}
-__device__ void costate_update(const Ctx& c, const CmpcConsts& prm, int tid, float ap, bool use_exact)
+// gam-weighted sums of the force step per foot and in total (the defect array is free until the next
+// iteration's residual pass): d[NS k + 3 ct + a], d[NS k + 6 + a]; nth threads share the 9 N entries
+__device__ inline void costate_force_sums(const Ctx& c, int tid, int nth)
 {
     const int N = c.N;
-    // gam-weighted sums of the force step per foot and in total (the defect array is free until the next
-    // iteration's residual pass): d[NS k + 3 ct + a], d[NS k + 6 + a]
-    for (int e = tid; e < 9 * N; e += blockDim.x) {
+    for (int e = tid; e < 9 * N; e += nth) {
         const int k = e / 9, t = e - 9 * k;
         const float* du = c.dU + NU * k;
         const int a = t % 3;
@@ -2571,8 +2571,117 @@ __device__ void costate_update(const Ctx& c, const CmpcConsts& prm, int tid, flo
         const float s1 = gam_of(c, 1, k) * (du[12 + a] + du[15 + a] + du[18 + a] + du[21 + a]);
         c.d[NS * k + t] = t < 3 ? s0 : (t < 6 ? s1 : s0 + s1);
     }
-    __syncthreads();
-    if (tid < 64) {
+}
+// ---- The costates by scans over the stages (one wave, lane <-> stage k = 0 .. N; N <= CMPC_NMAX < 64).  The recursion
+//   lam_k = base_k + sj lam_{k+1} + (terms in lam_{k+1} of OTHER components)
+// is triangular in the components: the angular-momentum rows depend on nothing else (A_hh = I: a suffix sum of terms known in advance), the CoM rows and the foot rows
+// take lam_h of the next stage through the cross products with the forces (a suffix sum, and one weighted by gam), the CoM-velocity rows take dt lam_com of the next stage.
+// Four dependent levels of scans (DPP row shifts + one read of each row's leader) instead of N serial stages of ~45 instructions with two broadcasts each: ~500
+// instructions against ~900 on a dependent chain.  Same terms as costate_recursion (which stays as the statement of the recursion and serves horizons beyond 63);
+// sums are taken in scan order, so the float32 costates differ from the serial ones in the last bits. ----
+template <int CTRL>
+__device__ inline float dpp_keep(float old, float v) { return __uint_as_float(__builtin_amdgcn_update_dpp(__float_as_uint(old), __float_as_uint(v), CTRL, 0xF, 0xF, false)); }
+__device__ inline float lane_next(float v, int lane) { return __int_as_float(__builtin_amdgcn_ds_bpermute(4 * (lane + 1), __float_as_int(v))); }
+// v_k = sum_{m >= k} b_m over the lanes of the wave (lanes beyond the last stage hold zeros)
+__device__ inline float suffix_sum(float v, int lane)
+{
+    v += dpp_f<0x101>(v);   // row_shl:1  (lane i takes lane i + 1 of its row of 16; zero beyond the row)
+    v += dpp_f<0x102>(v);
+    v += dpp_f<0x104>(v);
+    v += dpp_f<0x108>(v);
+    const float t1 = readlane_f(v, 16), t2 = readlane_f(v, 32), t3 = readlane_f(v, 48);
+    const int row = lane >> 4;
+    return v + (row == 0 ? t1 + (t2 + t3) : (row == 1 ? t2 + t3 : (row == 2 ? t3 : 0.f)));
+}
+// v_k = b_k + g_k v_{k+1}  (lanes beyond the last stage: b = 0, g = 1)
+__device__ inline float suffix_lin(float g, float b, int lane)
+{
+#define CMPC_LIN_STEP(CT) { const float gn = dpp_keep<CT>(1.f, g), bn = dpp_f<CT>(b); b = fmaf(g, bn, b); g *= gn; }
+    CMPC_LIN_STEP(0x101) CMPC_LIN_STEP(0x102) CMPC_LIN_STEP(0x104) CMPC_LIN_STEP(0x108)
+#undef CMPC_LIN_STEP
+    const int row = lane >> 4;
+    const float v48 = readlane_f(b, 48);
+    if (row == 2) b = fmaf(g, v48, b);
+    const float v32 = readlane_f(b, 32);
+    if (row == 1) b = fmaf(g, v32, b);
+    const float v16 = readlane_f(b, 16);
+    if (row == 0) b = fmaf(g, v16, b);
+    return b;
+}
+template <bool DEFER>
+__device__ inline void costate_scan(const Ctx& c, const CmpcConsts& prm, int lane, float ap, bool use_exact, float* vout)
+{
+    const int N = c.N;
+    const bool valid = lane <= N, dyn = lane < N;   // dyn: a stage with dynamics (the terminal lane N carries the terminal cost only)
+    const int k = valid ? lane : N, kd = dyn ? lane : N - 1;
+    const float* S = c.S + NS * k;
+    const float* dS = c.dS + NS * k;
+    const float* geo = c.geoA + GEO * kd;
+    const float* dF = c.d + NS * kd;
+    const float dtm = dyn ? prm.dt : 0.f;           // (every coupling term carries dt: zero on the terminal lane and beyond)
+    const float egm = use_exact ? dtm : 0.f;
+    const float on = valid ? 1.f : 0.f;
+    float lo[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) lo[a] = c.LAM[NS * (kd + 1) + 6 + a];   // lam_h of the next stage as the Hessian used it
+    float lold[NS];
+    if (!DEFER) {
+#pragma unroll
+        for (int j = 0; j < NS; ++j) lold[j] = c.LAM[NS * k + j];
+    }
+    float v[NS];
+    // level 1: angular momentum
+    float vh1[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float b = on * (2.f * prm.w_h) * ((S[6 + a] - c.sp[c.L.pHref() + a + 3 * k]) + dS[6 + a]);
+        v[6 + a] = suffix_sum(b, lane);
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) vh1[a] = lane_next(v[6 + a], lane);
+    // level 2: CoM rows (total force) and foot rows (the foot's force, weighted by gam)
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const int a1 = (a + 1) % 3, a2 = (a + 2) % 3;
+        const float w = a == 0 ? 2.f * prm.w_com0 : (a == 1 ? 2.f * prm.w_com1 : prm.wz2[k]);
+        float b = w * ((S[a] - c.sp[c.L.pComref() + a + 3 * k]) + dS[a]);
+        b += egm * (dF[6 + a2] * lo[a1] - dF[6 + a1] * lo[a2]);               // eg = -dt:  -dt (dF_a1 lamh_a2 - dF_a2 lamh_a1)
+        b += dtm * (vh1[a1] * geo[30 + a2] - vh1[a2] * geo[30 + a1]);
+        v[a] = suffix_sum(on * b, lane);
+    }
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+        const float gam = c.sp[c.L.pGam(ct) + kd];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const int a1 = (a + 1) % 3, a2 = (a + 2) % 3, j = 9 + 3 * ct + a;
+            float b = (2.f * prm.w_pos) * ((S[j] - c.sp[c.L.pNom(ct) + a + 3 * k]) + dS[j]);
+            b += egm * (dF[3 * ct + a1] * lo[a2] - dF[3 * ct + a2] * lo[a1]);   // eg = +dt
+            b -= dtm * gam * (vh1[a1] * geo[24 + 3 * ct + a2] - vh1[a2] * geo[24 + 3 * ct + a1]);
+            v[j] = suffix_lin(dyn ? gam : 1.f, on * b, lane);
+        }
+    }
+    // level 3: CoM velocity (no cost of its own: dt lam_com of the next stage, summed)
+#pragma unroll
+    for (int a = 0; a < 3; ++a) v[3 + a] = suffix_sum(dtm * lane_next(v[a], lane), lane);
+    if (valid && lane > 0) {   // (stage 0 has no costate anybody reads: the recursion never wrote it)
+#pragma unroll
+        for (int j = 0; j < NS; ++j) {
+            if (DEFER) vout[NS * k + j] = v[j];
+            else c.LAM[NS * k + j] = lold[j] + ap * (v[j] - lold[j]);
+        }
+    }
+}
+
+#ifdef CMPC_COSTATE_SERIAL
+// The serial recursion the scans replace -- the statement of what they compute (oracle/ipm_ref.c states the same), compiled only into -DCMPC_COSTATE_SERIAL builds
+// (the A/B and the trace of profiles/r04_experiments_not_kept.txt, item 24).  One wave (tid < 64).  DEFER: the full-step costates go to vout (NS (N + 1) floats) and LAM is left alone -- the caller blends them in once
+// the step length is known (phase_final_post: the recursion runs beside the slack steps the step length comes from)
+template <bool DEFER>
+__device__ inline void costate_recursion(const Ctx& c, const CmpcConsts& prm, int tid, float ap, bool use_exact, float* vout)
+{
+    const int N = c.N;
+    {
         // lane j < 15 owns costate component j.  Everything below is one formula with per-lane coefficients:
         //   lam_j = w (s_j - ref_j + ds_j) + sj pv_j + ce pv_je + cg (pv_{6+a1} F_a2 - pv_{6+a2} F_a1)
         //           + eg (dF_a1 lamh_a2 - dF_a2 lamh_a1)                       (exact Hessian only)
@@ -2627,10 +2736,16 @@ __device__ void costate_update(const Ctx& c, const CmpcConsts& prm, int tid, flo
             v += sj * pvj + ce * pe + readlane_f(pvj, 6) * c0 + readlane_f(pvj, 7) * c1 + readlane_f(pvj, 8) * c2;
             lold = o.lold;
             pvj = v;
-            if (own) c.LAM[NS * k + j] = lold + ap * (v - lold);
+            if (own) {
+                if (DEFER) vout[NS * k + j] = v;
+                else c.LAM[NS * k + j] = lold + ap * (v - lold);
+            }
         };
         Ops oa = fetch(N > 1 ? N - 1 : 0), ob;
-        if (own) c.LAM[NS * N + j] = lold + ap * (pvj - lold);
+        if (own) {
+            if (DEFER) vout[NS * N + j] = pvj;
+            else c.LAM[NS * N + j] = lold + ap * (pvj - lold);
+        }
         int k = N - 1;
 #pragma unroll 1   // (left alone the compiler unrolls all N / 2 trips: 10 KB of straight-line code for a phase that runs once per iteration)
         for (; k >= 2; k -= 2) {
@@ -2641,6 +2756,17 @@ __device__ void costate_update(const Ctx& c, const CmpcConsts& prm, int tid, flo
         }
         if (k == 1) step(1, oa);
     }
+}
+#endif
+__device__ void costate_update(const Ctx& c, const CmpcConsts& prm, int tid, float ap, bool use_exact)
+{
+    costate_force_sums(c, tid, blockDim.x);
+    __syncthreads();
+#ifdef CMPC_COSTATE_SERIAL
+    if (tid < 64) costate_recursion<false>(c, prm, tid, ap, use_exact, nullptr);
+#else
+    if (tid < 64) costate_scan<false>(c, prm, tid, ap, use_exact, nullptr);
+#endif
     __syncthreads();
 }
 
@@ -2664,13 +2790,15 @@ __device__ __attribute__((noinline)) void phase_forward_part(lds_t lds, int Nrt,
     const bool affine = __builtin_amdgcn_readfirstlane((int)affine_in) != 0;
     riccati_forward<NT, NC == 0 ? 1 : (FG ? 2 : CMPC_SWEEP_UNROLL), FG, PART>(c, prm, PART == 1 ? tid - 64 * CMPC_SWEEP_WAVE : tid, affine, 0);
 }
+// the sweep alone, on its wave; what follows it -- a barrier and the slack steps -- is phase_forward_part<.., 2>, or fused with the passes behind it (phase_affine_post,
+// phase_final_post)
+#ifndef CMPC_FUSED_POST
+#define CMPC_FUSED_POST(NC) ((NC) > 0)
+#endif
 template <int NT, int NC, bool FG>
-__device__ __forceinline__ void phase_forward(lds_t lds, int Nrt, float* fg_base, bool affine_in)
+__device__ __forceinline__ void phase_forward_sweep(lds_t lds, int Nrt, float* fg_base, bool affine_in)
 {
-    if constexpr (CMPC_SWEEP_WAVE0_ONLY(FG)) {
-        if ((threadIdx.x >> 6) == CMPC_SWEEP_WAVE) phase_forward_part<NT, NC, FG, 1>(lds, Nrt, fg_base, affine_in);
-        phase_forward_part<NT, NC, FG, 2>(lds, Nrt, fg_base, affine_in);
-    } else phase_forward_part<NT, NC, FG, 0>(lds, Nrt, fg_base, affine_in);
+    if ((threadIdx.x >> 6) == CMPC_SWEEP_WAVE) phase_forward_part<NT, NC, FG, 1>(lds, Nrt, fg_base, affine_in);
 }
 template <int NT, int NC, bool FG>
 __device__ __attribute__((noinline)) void phase_forward_tail(lds_t lds, int Nrt, float* fg_base, bool affine_in, int k0_in)
@@ -2765,9 +2893,33 @@ __device__ __attribute__((noinline)) Resid phase_residuals(lds_t lds, int Nrt, f
     float l_ep = 0.f, l_ec = 0.f, l_chk = 0.f;   // l_chk: a plain sum over everything the maxima see -- fmaxf drops a NaN operand, a sum keeps it
     double l_mu = 0.0;
     all_geo<NT>(c, prm, tid);
-    for (int e = tid; e < NS * N; e += NT) {
-        const double dv = defect(c, prm, e / NS, e % NS);
-        c.d[e] = (float)dv;
+    // The angular-momentum defects are the heavy ones (eight corner torques in float64 each) and only 3 of a stage's 15: left inside defect() every wave walks through
+    // that branch for a fifth of its lanes.  Here a corner per lane -- eight consecutive lanes form one (stage, axis) and meet through three DPP steps -- and the twelve
+    // light components of a stage in a loop of their own.
+    for (int e = tid; e < 24 * N; e += NT) {
+        const int k = e / 24, r = e - 24 * k, a = r >> 3, cj = r & 7, ct = cj >> 2;
+        const int a1 = (a + 1) % 3, a2 = (a + 2) % 3;
+        const float* s = c.S + NS * k;
+        const float* f = c.U + NU * k + 3 * cj;
+        const float* R = c.sp + c.L.pR(ct) + 9 * k;
+        const float* cn = prm.corners + 3 * cj;
+        const double r1 = (double)Rm(R, a1, 0) * cn[0] + (double)Rm(R, a1, 1) * cn[1] + (double)Rm(R, a1, 2) * cn[2] + (double)s[9 + 3 * ct + a1] - (double)s[a1];
+        const double r2 = (double)Rm(R, a2, 0) * cn[0] + (double)Rm(R, a2, 1) * cn[1] + (double)Rm(R, a2, 2) * cn[2] + (double)s[9 + 3 * ct + a2] - (double)s[a2];
+        double t = (double)gam_of(c, ct, k) * (r1 * (double)f[a2] - r2 * (double)f[a1]);
+        t += dpp_d<0xB1>(t);    // quad_perm [1,0,3,2]
+        t += dpp_d<0x4E>(t);    // quad_perm [2,3,0,1]
+        t += dpp_d<0x141>(t);   // row_half_mirror: the eight corners
+        if (cj == 0) {
+            const double dv = (double)s[6 + a] + (double)prm.dt * ((double)c.sp[c.L.pText() + 3 * k + a] + t) - (double)c.S[NS * (k + 1) + 6 + a];
+            c.d[NS * k + 6 + a] = (float)dv;
+            l_ep = fmaxf(l_ep, fabsf((float)dv));
+            l_chk += (float)dv;
+        }
+    }
+    for (int e = tid; e < 12 * N; e += NT) {
+        const int k = e / 12, ii = e - 12 * k, i = ii < 6 ? ii : ii + 3;
+        const double dv = defect(c, prm, k, i);
+        c.d[NS * k + i] = (float)dv;
         l_ep = fmaxf(l_ep, fabsf((float)dv));
         l_chk += (float)dv;
     }
@@ -3041,6 +3193,153 @@ __device__ __attribute__((noinline)) Centre phase_corrector_targets(lds_t lds, i
     return r;
 }
 
+// ---- The element-wise passes between the sweeps, fused (compile-time horizons; the runtime-N variants keep the separate passes above).  Each of the small passes was a
+// call, a rebuilt LDS map, one or two block reductions (two barriers each) and a round trip of its operands through LDS: 4.6 k cycles for the step lengths and the
+// centring parameter of a 20-stage problem, 15 k for slack steps + step lengths + costates + update, of a 244 k-cycle iteration.  Here a thread keeps the rows it owns
+// (t, z, dt, dz) in registers from the slack step to the last use.
+// phase_affine_post: behind the affine forward sweep -- slack and multiplier steps, step lengths to the boundary, Mehrotra's centring parameter, the corrector's per-row
+// targets (dZ) and row coefficient changes (dT): what riccati_forward's element-wise part, phase_step_lengths(1) and phase_corrector_targets did, same arithmetic. ----
+template <int NT, int NC, bool FG>
+__device__ __attribute__((noinline)) Centre phase_affine_post(lds_t lds, int Nrt, float* fg_base, float mu_in, int nrow_in)
+{
+    CMPC_PHASE_PROLOGUE;
+    constexpr int RPT = (NI * (NC > 0 ? NC : 1) + NT - 1) / NT;
+    const float mu_cur = uniform_f(mu_in);
+    const int nrow = __builtin_amdgcn_readfirstlane(nrow_in);
+    __syncthreads();   // (the sweep, one wave, is complete)
+    float t[RPT], z[RPT], dt[RPT], dz[RPT];
+    bool act[RPT];
+    float a_p = 1.f, a_d = 1.f;
+#pragma unroll
+    for (int q = 0; q < RPT; ++q) {
+        const int e = tid + NT * q;
+        t[q] = 1.f; z[q] = 0.f; dt[q] = 0.f; dz[q] = 0.f; act[q] = false;
+        if (e < NI * N) {
+            const int k = e / NI, i = e % NI;
+            if (row_active(c, k, i)) {
+                act[q] = true;
+                t[q] = c.T[e]; z[q] = c.Z[e];
+                const float r = row_val(c, prm, k, i, c.U + NU * k) + t[q];
+                dt[q] = -r - row_dot(c, prm, k, i, c.dU + NU * k);
+                dz[q] = (0.f - z[q] * t[q]) / t[q] - (z[q] / t[q]) * dt[q];
+                if (dt[q] < 0.f) a_p = fminf(a_p, -t[q] / dt[q]);
+                if (dz[q] < 0.f) a_d = fminf(a_d, -z[q] / dz[q]);
+            }
+        }
+    }
+    float m[2] = {-a_p, -a_d};
+    block_maxn<NT, 2>(m, c.red, tid);
+    const float ap = -m[0], ad = -m[1];
+    double l_aff = 0.0;
+#pragma unroll
+    for (int q = 0; q < RPT; ++q)
+        if (act[q]) l_aff += (double)(t[q] + ap * dt[q]) * (double)(z[q] + ad * dz[q]);
+    const float mu_aff = (float)(block_sum<NT>(l_aff, c.redd, tid) / (double)nrow);
+    Centre r;
+    r.sigma = mu_aff / mu_cur;
+    r.sigma = r.sigma * r.sigma * r.sigma;
+    r.mu_t = fmaxf(fmaxf(r.sigma, prm.sigma_min) * mu_cur, prm.mu_min);
+#pragma unroll
+    for (int q = 0; q < RPT; ++q) {
+        const int e = tid + NT * q;
+        if (e < NI * N) {
+            const float cmu = act[q] ? r.mu_t - dt[q] * dz[q] : 0.f;   // complementarity target
+            c.dZ[e] = cmu;
+            c.dT[e] = cmu / t[q];   // row coefficient change, read by the corrector sweep
+        }
+    }
+    __syncthreads();
+    return r;
+}
+
+// phase_final_post: behind the last forward sweep of an iteration.  The costate recursion (one wave, serial over the stages: the longest pole of these passes) runs
+// BESIDE the slack steps and step lengths of the other waves; it leaves the full-step costates in the dT array -- dead by now: the rows' steps stay in registers -- and
+// every thread blends them in once the step length is known.  Then the iterate takes its step and the step is measured (phase_update's arithmetic and thread mapping).
+struct FinalStep { float ap, ad, step; };
+template <int NT, int NC, bool FG>
+__device__ __attribute__((noinline)) FinalStep phase_final_post(lds_t lds, int Nrt, float* fg_base, float tau_in, bool exact_in)
+{
+    CMPC_PHASE_PROLOGUE;
+    constexpr int NTR = NT - 64;   // threads on the rows
+    constexpr int RPT = (NI * (NC > 0 ? NC : 1) + NTR - 1) / NTR;
+    const float tau = uniform_f(tau_in);
+    const bool use_exact = __builtin_amdgcn_readfirstlane((int)exact_in) != 0;
+    float* vbuf = c.dT;
+    __syncthreads();   // (the sweep, one wave, is complete)
+    float t[RPT], z[RPT], dt[RPT], dz[RPT];
+    bool act[RPT];
+    float a_p = 1.f, a_d = 1.f;
+    if (tid < 64) {
+        costate_force_sums(c, tid, 64);
+        wave_lds_sync();
+#ifdef CMPC_COSTATE_SERIAL
+        costate_recursion<true>(c, prm, tid, 0.f, use_exact, vbuf);
+#else
+        costate_scan<true>(c, prm, tid, 0.f, use_exact, vbuf);
+#endif
+#pragma unroll
+        for (int q = 0; q < RPT; ++q) { t[q] = 1.f; z[q] = 0.f; dt[q] = 0.f; dz[q] = 0.f; act[q] = false; }
+    } else {
+#pragma unroll
+        for (int q = 0; q < RPT; ++q) {
+            const int e = tid - 64 + NTR * q;
+            t[q] = 1.f; z[q] = 0.f; dt[q] = 0.f; dz[q] = 0.f; act[q] = false;
+            if (e < NI * N) {
+                const int k = e / NI, i = e % NI;
+                if (row_active(c, k, i)) {
+                    act[q] = true;
+                    t[q] = c.T[e]; z[q] = c.Z[e];
+                    const float cmu = c.dZ[e];
+                    const float r = row_val(c, prm, k, i, c.U + NU * k) + t[q];
+                    dt[q] = -r - row_dot(c, prm, k, i, c.dU + NU * k);
+                    dz[q] = (cmu - z[q] * t[q]) / t[q] - (z[q] / t[q]) * dt[q];
+                    if (dt[q] < 0.f) a_p = fminf(a_p, -tau * t[q] / dt[q]);
+                    if (dz[q] < 0.f) a_d = fminf(a_d, -tau * z[q] / dz[q]);
+                }
+            }
+        }
+    }
+    float m[2] = {-a_p, -a_d};
+    block_maxn<NT, 2>(m, c.red, tid);   // (its barriers are also what makes the costates in vbuf visible)
+    const float ap = -m[0], ad = -m[1];
+    if (tid >= 64) {
+#pragma unroll
+        for (int q = 0; q < RPT; ++q)
+            if (act[q]) {
+                const int e = tid - 64 + NTR * q;
+                c.T[e] = t[q] + ap * dt[q];
+                c.Z[e] = z[q] + ad * dz[q];
+            }
+    }
+    for (int e = tid; e < NS * (N + 1); e += NT) {
+        const float lold = c.LAM[e];
+        c.LAM[e] = lold + ap * (vbuf[e] - lold);
+        c.S[e] += ap * c.dS[e];
+    }
+    for (int e = tid; e < NU * N; e += NT) c.U[e] += ap * c.dU[e];
+    // the step norm of the termination test: see phase_update
+    float l_st = 0.f, l_sf = 0.f, l_fm = 1.f, l_chk2 = 0.f;
+    for (int e = tid; e < NS * (N + 1); e += NT) { const float ds = c.dS[e]; l_st = fmaxf(l_st, fabsf(ds)); l_chk2 += ds; }
+    for (int e = tid; e < NU * N; e += NT) {
+        const int k = e / NU, mm = e % NU;
+        const float du = c.dU[e];
+        l_chk2 += du;
+        if (mm < NF) {
+            const float* f = c.dU + NU * k + 12 * (mm / 12) + mm % 3;
+            const float mean = 0.25f * (f[0] + f[3] + f[6] + f[9]);
+            l_sf = fmaxf(l_sf, fabsf(du - gam_of(c, mm / 12, k) * mean));
+            if (k > 0) l_sf = fmaxf(l_sf, fabsf(du - c.dU[e - NU]));
+            l_fm = fmaxf(l_fm, fabsf(c.U[e]));
+        } else l_st = fmaxf(l_st, fabsf(du));
+    }
+    if (!(fabsf(l_chk2) < INFINITY)) l_st = INFINITY;
+    float m3[3] = {l_st, l_sf, l_fm};
+    block_maxn<NT, 3>(m3, c.red, tid);
+    FinalStep r;
+    r.ap = ap; r.ad = ad; r.step = ap * fmaxf(m3[0], m3[1] / m3[2]);
+    return r;
+}
+
 // x in the reference layout (and, warm starts with duals, the costates, slacks and multipliers)
 template <int NT, int NC, bool FG>
 __device__ __attribute__((noinline)) void phase_export(lds_t lds, int Nrt, float* fg_base, float* x, float* dq)
@@ -3202,29 +3501,43 @@ __global__ __launch_bounds__(NT, FG ? 3 : 1) void cmpc_solve_kernel(CmpcParams k
             if (centring) {
                 phase_multipliers<NT, NC, FG>(lds, N, fg_base, 2, prm.mu_min, nrow);
             } else {
-                phase_forward<NT, NC, FG>(lds, N, fg_base, true);
+                phase_forward_sweep<NT, NC, FG>(lds, N, fg_base, true);
                 PROF(12);
                 if (finishing) {
                     // last step: affine-scaling extrapolation of the central path to mu = 0 (primal only), and the tail polish behind it
+                    phase_forward_part<NT, NC, FG, 2>(lds, N, fg_base, true);
                     if (phase_finish<NT, NC, FG>(lds, N, fg_base)) sg += 100000;
                     ++it;
                     break;
                 }
-                const StepLen sa = phase_step_lengths<NT, NC, FG>(lds, N, fg_base, 1.f);
-                const Centre ce = phase_corrector_targets<NT, NC, FG>(lds, N, fg_base, sa.ap, sa.ad, mu_cur, nrow);
+                Centre ce;
+                if constexpr (CMPC_FUSED_POST(NC)) ce = phase_affine_post<NT, NC, FG>(lds, N, fg_base, mu_cur, nrow);
+                else {
+                    phase_forward_part<NT, NC, FG, 2>(lds, N, fg_base, true);
+                    const StepLen sa = phase_step_lengths<NT, NC, FG>(lds, N, fg_base, 1.f);
+                    ce = phase_corrector_targets<NT, NC, FG>(lds, N, fg_base, sa.ap, sa.ad, mu_cur, nrow);
+                }
                 sigma = ce.sigma; mu_t = ce.mu_t;
                 PROF(13);
                 phase_delta<NT, NC, FG>(lds, N, fg_base);
                 PROF(14);
             }
-            phase_forward<NT, NC, FG>(lds, N, fg_base, false);   // (one call site for both branches: the sweep may be inlined here)
+            phase_forward_sweep<NT, NC, FG>(lds, N, fg_base, false);   // (one call site for both branches: the sweep may be inlined here)
             PROF(15);
-            const StepLen sl = phase_step_lengths<NT, NC, FG>(lds, N, fg_base, fmaxf(0.99f, 1.f - mu_t));
-            const float ap = sl.ap, ad = sl.ad;
-            // ---- costates, then the iterate ----
-            phase_costate<NT, NC, FG>(lds, N, fg_base, ap, exact);
-            PROF(16);
-            const float step = phase_update<NT, NC, FG>(lds, N, fg_base, ap, ad);
+            // ---- slack steps, step lengths, costates, then the iterate ----
+            float ap, ad, step;
+            if constexpr (CMPC_FUSED_POST(NC)) {
+                const FinalStep fs = phase_final_post<NT, NC, FG>(lds, N, fg_base, fmaxf(0.99f, 1.f - mu_t), exact);
+                ap = fs.ap; ad = fs.ad; step = fs.step;
+                PROF(16);
+            } else {
+                phase_forward_part<NT, NC, FG, 2>(lds, N, fg_base, false);
+                const StepLen sl = phase_step_lengths<NT, NC, FG>(lds, N, fg_base, fmaxf(0.99f, 1.f - mu_t));
+                ap = sl.ap; ad = sl.ad;
+                phase_costate<NT, NC, FG>(lds, N, fg_base, ap, exact);
+                PROF(16);
+                step = phase_update<NT, NC, FG>(lds, N, fg_base, ap, ad);
+            }
             step_prev = step_out;
             step_out = step;
             err = fmaxf(ep, ec);
