@@ -524,26 +524,21 @@ __device__ inline void block_max2_sum(float& m0, float& m1, double& sm, float* r
 template <int NT>
 __device__ inline void all_geo(const Ctx& c, const CmpcConsts& prm, int tid)
 {
-    for (int e = tid; e < c.N * 33; e += NT) {
-        const int k = e / 33, t = e % 33;
+    // (a loop per kind: with the 33 entries of a stage in one index space every wave walked through all three formulas on both of its trips)
+    for (int e = tid; e < c.N * 24; e += NT) {
+        const int k = e / 24, t = e - 24 * k;
         const float* s = c.S + NS * k;
+        const int ct = t / 12, j = (t % 12) / 3, i = t % 3;
+        const float* R = c.sp + c.L.pR(ct) + 9 * k;
+        const float* cn = prm.corners + 12 * ct + 3 * j;
+        c.geoA[GEO * k + t] = Rm(R, i, 0) * cn[0] + Rm(R, i, 1) * cn[1] + Rm(R, i, 2) * cn[2] + s[9 + 3 * ct + i] - s[i];
+    }
+    for (int e = tid; e < c.N * 9; e += NT) {
+        const int k = e / 9, t = e - 9 * k, i = t % 3;
         const float* u = c.U + NU * k;
-        float v;
-        if (t < 24) {
-            const int ct = t / 12, j = (t % 12) / 3, i = t % 3;
-            const float* R = c.sp + c.L.pR(ct) + 9 * k;
-            const float* cn = prm.corners + 12 * ct + 3 * j;
-            v = Rm(R, i, 0) * cn[0] + Rm(R, i, 1) * cn[1] + Rm(R, i, 2) * cn[2] + s[9 + 3 * ct + i] - s[i];
-        } else if (t < 30) {
-            const int ct = (t - 24) / 3, i = (t - 24) % 3;
-            const float* f = u + 12 * ct;
-            v = f[i] + f[3 + i] + f[6 + i] + f[9 + i];
-        } else {
-            const int i = t - 30;
-            v = gam_of(c, 0, k) * (u[i] + u[3 + i] + u[6 + i] + u[9 + i])
-                + gam_of(c, 1, k) * (u[12 + i] + u[15 + i] + u[18 + i] + u[21 + i]);
-        }
-        c.geoA[GEO * k + t] = v;
+        const float f0 = u[i] + u[3 + i] + u[6 + i] + u[9 + i], f1 = u[12 + i] + u[15 + i] + u[18 + i] + u[21 + i];
+        // t = 0..2: Fc of foot 0, 3..5: Fc of foot 1 (plain corner sums), 6..8: Fsum (gam-weighted)
+        c.geoA[GEO * k + 24 + t] = t < 3 ? f0 : (t < 6 ? f1 : gam_of(c, 0, k) * f0 + gam_of(c, 1, k) * f1);
     }
 }
 
@@ -2360,12 +2355,22 @@ __device__ __forceinline__ void delta_sweep(const Ctx& c, const CmpcConsts& prm,
     unsigned loff[16], foff[8];
 #pragma unroll
     for (int t = 0; t < 16; ++t) {
-        const int m = 16 * half + t;
-        loff[t] = blk >= (m >> 2) ? ub_row(m) + r - 4 * (m >> 2) : REC_ZERO;
+        // (row m = 16 half + t: both halves' constants at compile time and one select each, instead of ub_row's arithmetic on a runtime m)
+        const int mq = half ? (16 + t) >> 2 : t >> 2;
+        const int cm = half ? ub_row(16 + t) - 4 * ((16 + t) >> 2) : ub_row(t) - 4 * (t >> 2);
+        loff[t] = blk >= mq ? cm + r : REC_ZERO;
     }
+    {
+        // (both halves' offsets and a bitwise blend: written as a conditional expression the eight selects became eight branchy regions of the set-up)
+        const unsigned ubr = ub_row(r) - 4 * blk, wtr = REC_WT + 32 * (r & 15), r7 = r & 7;
+        const unsigned hm = 0u - (unsigned)half, w16 = 0u - (unsigned)(r < 16);   // all ones: upper half / a Ws row
 #pragma unroll
-    for (int q = 0; q < 8; ++q)
-        foff[q] = half == 0 ? (q >= blk ? ub_row(r) + 4 * (q - blk) : REC_ZERO) : (r < 16 ? REC_WT + 32 * r + 4 * (q ^ (r & 7)) : REC_ZERO);
+        for (int q = 0; q < 8; ++q) {
+            const unsigned lo = q >= blk ? ubr + 4 * q : REC_ZERO;
+            const unsigned hq = ((wtr + 4 * (q ^ r7)) & w16) | (REC_ZERO & ~w16);
+            foff[q] = (lo & ~hm) | (hq & hm);
+        }
+    }
     // A^T row roles of lanes 32..46 (state index j = r): out = s v[j] + ce v[je] + cg (v[6+a1] F[a2] - v[6+a2] F[a1]) - W^T dl
     const bool hi = half == 1 && r < NS;
     const int j = hi ? r : 0;
@@ -2442,17 +2447,19 @@ __device__ __forceinline__ void delta_sweep(const Ctx& c, const CmpcConsts& prm,
         const float dgam = gam1 - gam0;
         PROF2(24);
         // ---- g = C^T w + fp_p + B^T fp_s: a force component (lanes 0..23) or a landing offset (24..29) ----
+        // (both forms on every lane, on clamped indices, and a select: the wave walks through both anyway, and a branch on the lane's role costs the exec-mask
+        //  bookkeeping of two regions per stage)
         float g;
-        if (isF) {
+        {
             const float w0 = wp[NI * o], w1 = wp[NI * o + 1], w2 = wp[NI * o + 2], w3 = wp[NI * o + 3];
             // sum_f w_f R (sx_f, sy_f, -mu)^T,  (sx, sy) = (+,+), (-,+), (-,-), (+,-)
             const float wx = w0 - w1 - w2 + w3, wy = w0 + w1 - w2 - w3, ws = w0 + w1 + w2 + w3;
-            g = rfp[9 * o] * wx + rfp[9 * o + 3] * wy - mu * rfp[9 * o + 6] * ws;
-            g += vN[0] + dtc * fmaf(fsel, dgam, gam0) * (v3[0] + v6a[0] * rr2[GEO * o] - v6b[0] * rr1[GEO * o]);
-        } else {
+            float gF = rfp[9 * o] * wx + rfp[9 * o + 3] * wy - mu * rfp[9 * o + 6] * ws;
+            gF += vN[0] + dtc * fmaf(fsel, dgam, gam0) * (v3[0] + v6a[0] * rr2[GEO * o] - v6b[0] * rr1[GEO * o]);
             const float fr = (float)((qmp[o] >> qq) & 1);
-            g = wqp[NI * o] - wqp[NI * o + 6];
-            g += fr * (1.f - fmaf(qsel, dgam, gam0)) * (rqp[9 * o] * vq[0] + rqp[9 * o + 1] * vq[1] + rqp[9 * o + 2] * vq[2]);
+            float gQ = wqp[NI * o] - wqp[NI * o + 6];
+            gQ += fr * (1.f - fmaf(qsel, dgam, gam0)) * (rqp[9 * o] * vq[0] + rqp[9 * o + 1] * vq[1] + rqp[9 * o + 2] * vq[2]);
+            g = isF ? gF : gQ;
         }
         *gbs = g;
         wave_lds_sync();
