@@ -42,6 +42,7 @@
 #include "cmpc_device.h"
 
 #include <cstdlib>
+#include <type_traits>
 #include <map>
 #include <mutex>
 
@@ -388,6 +389,60 @@ __device__ inline float row_dot(const Ctx& c, const CmpcConsts& prm, int k, int 
     }
     if (i < 38) return du[24 + i - 32];
     return -du[24 + i - 38];
+}
+
+// ---- The inequality rows of all stages as per-thread SLOTS, a kind at a time (compile-time horizons): slots 0 .. RF-1 are friction rows (32 per stage: stage and row are a
+// shift and a mask, always in use), slots RF .. RF+RB-1 box rows of the landing offsets (12 per stage, in use where the offset is free).  With the 44 rows of a stage in one
+// index space (e / NI, e % NI, row_val's three-way branch) every wave of the row passes walked through all three row formulas on every trip.  Branch-free on clamped
+// indices: a slot beyond the last row computes row 0 of its kind and is masked by `in`.  Same arithmetic as row_val / row_dot (explicit fused multiply-adds: see fric_row).
+//   e: index of the row in T, Z, dT, dZ;  val = a^T u - b;  dot = a^T du (DOT);  returns in | 2 * in-use ----
+template <int NTR, int NC>
+struct RowSlots {
+    static constexpr int RF = (32 * (NC > 0 ? NC : 1) + NTR - 1) / NTR, RB = (12 * (NC > 0 ? NC : 1) + NTR - 1) / NTR, R = RF + RB;
+};
+template <int NTR, int NC, int Q, bool DOT>
+__device__ __forceinline__ int row_slot(const Ctx& c, const CmpcConsts& prm, int tr, int& e, float& val, float& dot)
+{
+    constexpr int RF = RowSlots<NTR, NC>::RF;
+    if constexpr (Q < RF) {
+        const int ef = tr + NTR * Q;
+        const bool in = ef < 32 * NC;
+        const int efc = in ? ef : 0;
+        const int k = efc >> 5, i = efc & 31;
+        e = NI * k + i;
+        float a0, a1, a2;
+        fric_row(c, prm, k, i, a0, a1, a2);
+        const float* f = c.U + NU * k + 3 * (i >> 2);
+        val = __builtin_fmaf(a2, f[2], __builtin_fmaf(a1, f[1], a0 * f[0]));
+        if (DOT) {
+            const float* g = c.dU + NU * k + 3 * (i >> 2);
+            dot = __builtin_fmaf(a2, g[2], __builtin_fmaf(a1, g[1], a0 * g[0]));
+        }
+        return in ? 3 : 0;
+    } else {
+        const int eb = tr + NTR * (Q - RF);
+        const bool in = eb < 12 * NC;
+        const int ebc = in ? eb : 0;
+        const int k = ebc / 12, ib = ebc - 12 * k;
+        const bool upper = ib < 6;
+        const int m = upper ? ib : ib - 6;
+        e = NI * k + 32 + ib;
+        const int ct = m >= 3 ? 1 : 0;
+        const float bound = c.sp[(upper ? c.L.pUp(ct) : c.L.pLo(ct)) + 3 * k + m - 3 * ct];
+        const float u = c.U[NU * k + 24 + m];
+        val = upper ? u - bound : bound - u;
+        if (DOT) { const float du = c.dU[NU * k + 24 + m]; dot = upper ? du : -du; }
+        return in ? (qfree(c, k, m) ? 3 : 1) : 0;
+    }
+}
+// (a compile-time loop over the slots: F(integral_constant<int, Q>) for Q = 0 .. R-1)
+template <int Q0, int Q1, typename F>
+__device__ __forceinline__ void for_slots(F&& f)
+{
+    if constexpr (Q0 < Q1) {
+        f(std::integral_constant<int, Q0>{});
+        for_slots<Q0 + 1, Q1>(f);
+    }
 }
 
 __device__ inline float qdiag(const CmpcConsts& prm, int k, int i)
@@ -965,6 +1020,13 @@ __device__ inline int desc_role_t(int role, int lane)
     const int n = role == 0 ? NU : (role == 1 ? NS : (role == 2 ? NI : 9));
     return lane < n ? base + lane : 127;   // (127: no role)
 }
+// the roles of 128 threads (two waves) packed so that each formula is walked through by ONE wave: B columns, A columns and the exact-Hessian block on the first
+// (30 + 15 + 9 lanes), the 44 inequality rows on the second.  (With t = the thread's number the rows straddled both waves -- t = 48..91 -- and both executed the
+// row formulas, float64 divisions included.)
+__device__ inline int desc_pack_t(int tl)
+{
+    return tl < NU ? tl : (tl < NU + NS ? 32 + tl - NU : (tl < NU + NS + 9 ? 96 + tl - (NU + NS) : ((tl >= 64 && tl < 64 + NI) ? 48 + tl - 64 : 127)));
+}
 __device__ inline void stage_desc_body(const Ctx& c, const CmpcConsts& prm, int t, int k, bool use_exact, float cmu)
 {
     const float* u = c.U + NU * k;
@@ -1375,7 +1437,7 @@ __device__ __attribute__((noinline)) void stage_desc(lds_t lds, int Nrt, float* 
     const int k = __builtin_amdgcn_readfirstlane(k_in);   // (arguments arrive in VGPRs: a uniform copy keeps the stage's address arithmetic on the SALU)
     const bool use_exact = __builtin_amdgcn_readfirstlane((int)exact_in) != 0;
     use_desc_set(c, k & 1);
-    stage_desc_body(c, prm, tid - 128, k, use_exact, cmu);
+    stage_desc_body(c, prm, desc_pack_t(tid - 128), k, use_exact, cmu);
 }
 
 
@@ -1398,7 +1460,7 @@ __device__ __attribute__((noinline)) void stage_mid(lds_t lds, int Nrt, float* f
         stage_qss_body<NT>(c, prm, tid, k, c.P0, c.Qb, tqp);
         if (k > 0) {
             use_desc_set(c, ((k - 1) & 1) - (k & 1));
-            stage_desc_body(c, prm, tid - 128, k - 1, use_exact, cmu);
+            stage_desc_body(c, prm, desc_pack_t(tid - 128), k - 1, use_exact, cmu);
         }
     }
     __syncthreads();
@@ -2042,7 +2104,7 @@ __device__ __attribute__((noinline)) void sq_init(lds_t lds, int Nrt, float* fg_
         const int kd = tid >= 384 ? N - 1 : N - 2;
         if (kd >= k0) {
             use_desc_set(c, kd & 1);
-            stage_desc_body(c, prm, tid & 127, kd, use_exact, cmu);
+            stage_desc_body(c, prm, desc_pack_t(tid & 127), kd, use_exact, cmu);
         }
     }
     __syncthreads();
@@ -2930,15 +2992,33 @@ __device__ __attribute__((noinline)) Resid phase_residuals(lds_t lds, int Nrt, f
         l_ep = fmaxf(l_ep, fabsf((float)dv));
         l_chk += (float)dv;
     }
-    for (int e = tid; e < NI * N; e += NT) {
-        const int k = e / NI, i = e % NI;
-        if (row_active(c, k, i)) {
+    if constexpr (NC > 0) {
+        // (the rows a kind at a time: see row_slot)
+        for_slots<0, RowSlots<NT, NC>::R>([&](auto qc) {
+            constexpr int q = decltype(qc)::value;
+            int e;
+            float val, dot;
+            const int st = row_slot<NT, NC, q, false>(c, prm, tid, e, val, dot);
             const float t = c.T[e], z = c.Z[e];
-            const float rv = row_val(c, prm, k, i, c.U + NU * k) + t;
-            l_ep = fmaxf(l_ep, fabsf(rv));
-            l_ec = fmaxf(l_ec, t * z);
-            l_chk += rv + t * z;
-            l_mu += (double)t * z;
+            if (st & 2) {
+                const float rv = val + t;
+                l_ep = fmaxf(l_ep, fabsf(rv));
+                l_ec = fmaxf(l_ec, t * z);
+                l_chk += rv + t * z;
+                l_mu += (double)t * z;
+            }
+        });
+    } else {
+        for (int e = tid; e < NI * N; e += NT) {
+            const int k = e / NI, i = e % NI;
+            if (row_active(c, k, i)) {
+                const float t = c.T[e], z = c.Z[e];
+                const float rv = row_val(c, prm, k, i, c.U + NU * k) + t;
+                l_ep = fmaxf(l_ep, fabsf(rv));
+                l_ec = fmaxf(l_ec, t * z);
+                l_chk += rv + t * z;
+                l_mu += (double)t * z;
+            }
         }
     }
     if (!(fabsf(l_chk) < INFINITY)) l_ep = INFINITY;   // (one test per thread, not per element: NaN, inf, inf - inf all end here)
@@ -3210,49 +3290,45 @@ template <int NT, int NC, bool FG>
 __device__ __attribute__((noinline)) Centre phase_affine_post(lds_t lds, int Nrt, float* fg_base, float mu_in, int nrow_in)
 {
     CMPC_PHASE_PROLOGUE;
-    constexpr int RPT = (NI * (NC > 0 ? NC : 1) + NT - 1) / NT;
+    typedef RowSlots<NT, NC> RS;
+    constexpr int R = RS::R;
     const float mu_cur = uniform_f(mu_in);
     const int nrow = __builtin_amdgcn_readfirstlane(nrow_in);
     __syncthreads();   // (the sweep, one wave, is complete)
-    float t[RPT], z[RPT], dt[RPT], dz[RPT];
-    bool act[RPT];
+    float t[R], z[R], dt[R], dz[R];
+    int ei[R], st[R];
     float a_p = 1.f, a_d = 1.f;
-#pragma unroll
-    for (int q = 0; q < RPT; ++q) {
-        const int e = tid + NT * q;
-        t[q] = 1.f; z[q] = 0.f; dt[q] = 0.f; dz[q] = 0.f; act[q] = false;
-        if (e < NI * N) {
-            const int k = e / NI, i = e % NI;
-            if (row_active(c, k, i)) {
-                act[q] = true;
-                t[q] = c.T[e]; z[q] = c.Z[e];
-                const float r = row_val(c, prm, k, i, c.U + NU * k) + t[q];
-                dt[q] = -r - row_dot(c, prm, k, i, c.dU + NU * k);
-                dz[q] = (0.f - z[q] * t[q]) / t[q] - (z[q] / t[q]) * dt[q];
-                if (dt[q] < 0.f) a_p = fminf(a_p, -t[q] / dt[q]);
-                if (dz[q] < 0.f) a_d = fminf(a_d, -z[q] / dz[q]);
-            }
+    for_slots<0, R>([&](auto qc) {
+        constexpr int q = decltype(qc)::value;
+        float val, dot;
+        st[q] = row_slot<NT, NC, q, true>(c, prm, tid, ei[q], val, dot);
+        t[q] = c.T[ei[q]]; z[q] = c.Z[ei[q]];
+        const float r = val + t[q];
+        dt[q] = -r - dot;
+        dz[q] = (0.f - z[q] * t[q]) / t[q] - (z[q] / t[q]) * dt[q];
+        if (st[q] & 2) {
+            if (dt[q] < 0.f) a_p = fminf(a_p, -t[q] / dt[q]);
+            if (dz[q] < 0.f) a_d = fminf(a_d, -z[q] / dz[q]);
         }
-    }
+    });
     float m[2] = {-a_p, -a_d};
     block_maxn<NT, 2>(m, c.red, tid);
     const float ap = -m[0], ad = -m[1];
     double l_aff = 0.0;
 #pragma unroll
-    for (int q = 0; q < RPT; ++q)
-        if (act[q]) l_aff += (double)(t[q] + ap * dt[q]) * (double)(z[q] + ad * dz[q]);
+    for (int q = 0; q < R; ++q)
+        if (st[q] & 2) l_aff += (double)(t[q] + ap * dt[q]) * (double)(z[q] + ad * dz[q]);
     const float mu_aff = (float)(block_sum<NT>(l_aff, c.redd, tid) / (double)nrow);
     Centre r;
     r.sigma = mu_aff / mu_cur;
     r.sigma = r.sigma * r.sigma * r.sigma;
     r.mu_t = fmaxf(fmaxf(r.sigma, prm.sigma_min) * mu_cur, prm.mu_min);
 #pragma unroll
-    for (int q = 0; q < RPT; ++q) {
-        const int e = tid + NT * q;
-        if (e < NI * N) {
-            const float cmu = act[q] ? r.mu_t - dt[q] * dz[q] : 0.f;   // complementarity target
-            c.dZ[e] = cmu;
-            c.dT[e] = cmu / t[q];   // row coefficient change, read by the corrector sweep
+    for (int q = 0; q < R; ++q) {
+        if (st[q] & 1) {
+            const float cmu = (st[q] & 2) ? r.mu_t - dt[q] * dz[q] : 0.f;   // complementarity target
+            c.dZ[ei[q]] = cmu;
+            c.dT[ei[q]] = (st[q] & 2) ? cmu / t[q] : 0.f;   // row coefficient change, read by the corrector sweep
         }
     }
     __syncthreads();
@@ -3268,13 +3344,14 @@ __device__ __attribute__((noinline)) FinalStep phase_final_post(lds_t lds, int N
 {
     CMPC_PHASE_PROLOGUE;
     constexpr int NTR = NT - 64;   // threads on the rows
-    constexpr int RPT = (NI * (NC > 0 ? NC : 1) + NTR - 1) / NTR;
+    typedef RowSlots<NTR, NC> RS;
+    constexpr int R = RS::R;
     const float tau = uniform_f(tau_in);
     const bool use_exact = __builtin_amdgcn_readfirstlane((int)exact_in) != 0;
     float* vbuf = c.dT;
     __syncthreads();   // (the sweep, one wave, is complete)
-    float t[RPT], z[RPT], dt[RPT], dz[RPT];
-    bool act[RPT];
+    float t[R], z[R], dt[R], dz[R];
+    int ei[R], st[R];
     float a_p = 1.f, a_d = 1.f;
     if (tid < 64) {
         costate_force_sums(c, tid, 64);
@@ -3285,39 +3362,32 @@ __device__ __attribute__((noinline)) FinalStep phase_final_post(lds_t lds, int N
         costate_scan<true>(c, prm, tid, 0.f, use_exact, vbuf);
 #endif
 #pragma unroll
-        for (int q = 0; q < RPT; ++q) { t[q] = 1.f; z[q] = 0.f; dt[q] = 0.f; dz[q] = 0.f; act[q] = false; }
+        for (int q = 0; q < R; ++q) { t[q] = 1.f; z[q] = 0.f; dt[q] = 0.f; dz[q] = 0.f; ei[q] = 0; st[q] = 0; }
     } else {
-#pragma unroll
-        for (int q = 0; q < RPT; ++q) {
-            const int e = tid - 64 + NTR * q;
-            t[q] = 1.f; z[q] = 0.f; dt[q] = 0.f; dz[q] = 0.f; act[q] = false;
-            if (e < NI * N) {
-                const int k = e / NI, i = e % NI;
-                if (row_active(c, k, i)) {
-                    act[q] = true;
-                    t[q] = c.T[e]; z[q] = c.Z[e];
-                    const float cmu = c.dZ[e];
-                    const float r = row_val(c, prm, k, i, c.U + NU * k) + t[q];
-                    dt[q] = -r - row_dot(c, prm, k, i, c.dU + NU * k);
-                    dz[q] = (cmu - z[q] * t[q]) / t[q] - (z[q] / t[q]) * dt[q];
-                    if (dt[q] < 0.f) a_p = fminf(a_p, -tau * t[q] / dt[q]);
-                    if (dz[q] < 0.f) a_d = fminf(a_d, -tau * z[q] / dz[q]);
-                }
+        for_slots<0, R>([&](auto qc) {
+            constexpr int q = decltype(qc)::value;
+            float val, dot;
+            st[q] = row_slot<NTR, NC, q, true>(c, prm, tid - 64, ei[q], val, dot);
+            t[q] = c.T[ei[q]]; z[q] = c.Z[ei[q]];
+            const float cmu = c.dZ[ei[q]];
+            const float r = val + t[q];
+            dt[q] = -r - dot;
+            dz[q] = (cmu - z[q] * t[q]) / t[q] - (z[q] / t[q]) * dt[q];
+            if (st[q] & 2) {
+                if (dt[q] < 0.f) a_p = fminf(a_p, -tau * t[q] / dt[q]);
+                if (dz[q] < 0.f) a_d = fminf(a_d, -tau * z[q] / dz[q]);
             }
-        }
+        });
     }
     float m[2] = {-a_p, -a_d};
     block_maxn<NT, 2>(m, c.red, tid);   // (its barriers are also what makes the costates in vbuf visible)
     const float ap = -m[0], ad = -m[1];
-    if (tid >= 64) {
 #pragma unroll
-        for (int q = 0; q < RPT; ++q)
-            if (act[q]) {
-                const int e = tid - 64 + NTR * q;
-                c.T[e] = t[q] + ap * dt[q];
-                c.Z[e] = z[q] + ad * dz[q];
-            }
-    }
+    for (int q = 0; q < R; ++q)
+        if (st[q] & 2) {
+            c.T[ei[q]] = t[q] + ap * dt[q];
+            c.Z[ei[q]] = z[q] + ad * dz[q];
+        }
     for (int e = tid; e < NS * (N + 1); e += NT) {
         const float lold = c.LAM[e];
         c.LAM[e] = lold + ap * (vbuf[e] - lold);
