@@ -1323,7 +1323,7 @@ __device__ inline void stage_qss_body(const Ctx& c, const CmpcConsts& prm, int t
             if (t < NS) c.qs[t] = grad_track(c, prm, k, t) + At_vec<double>(c, prm, k, t, c.Pd);
 }
 
-template <int NT, bool LEAN>
+template <int NT, bool PACKED>
 __device__ inline void stage_post_body(const Ctx& c, const CmpcConsts& prm, int tid, int k, float* Pnew, const float* Qb, int tqp)
 {
     const bool pk = k > 0;
@@ -1348,8 +1348,31 @@ __device__ inline void stage_post_body(const Ctx& c, const CmpcConsts& prm, int 
                     return i < NS ? qb : (i == j ? prm.D[(i - NS) % 3] : 0.f);
                 };
                 const float b00 = base_of(i0, j0), b01 = base_of(i0, j0 + 1), b10 = base_of(i0 + 1, j0), b11 = base_of(i0 + 1, j0 + 1);
-                float a00 = 0.f, a01 = 0.f, a10 = 0.f, a11 = 0.f;
-                {
+                float a00, a01, a10, a11;
+                if constexpr (PACKED) {
+                    // Packed multiply-add chains over the pairs (x, y), (z, w) of the 16-byte operands, the two halves added once at the end: 2 instructions per four
+                    // products and accumulator, where the sum written as (xx + yy) + (zz + ww) added to the accumulator costs 4 (config 3 456.4 k -> 464.5 k solves/s).
+                    // Horizons up to 20 only: a 16-term chain rounds worse than eight 4-term trees, and at N = 30 (tolerance 3e-7) the value function's rounding
+                    // shows in the tail -- soak of 40 960 config-5 problems: 57 instead of 34 need 14 iterations or more, and one straggler of the bench batch (29
+                    // iterations against 18) cost that batch 5 % (profiles/r04_experiments_not_kept.txt, item 28).
+                    v2f p00 = {0.f, 0.f}, p01 = {0.f, 0.f}, p10 = {0.f, 0.f}, p11 = {0.f, 0.f};
+#pragma unroll 1
+                    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int q4 = 4 * h + q;
+                            const float4 x0 = ri0[q4], x1 = ri1[q4], y0 = rj0[q4], y1 = rj1[q4];
+                            const v2f x0a = {x0.x, x0.y}, x0b = {x0.z, x0.w}, x1a = {x1.x, x1.y}, x1b = {x1.z, x1.w};
+                            const v2f y0a = {y0.x, y0.y}, y0b = {y0.z, y0.w}, y1a = {y1.x, y1.y}, y1b = {y1.z, y1.w};
+                            p00 = __builtin_elementwise_fma(x0b, y0b, __builtin_elementwise_fma(x0a, y0a, p00));
+                            p01 = __builtin_elementwise_fma(x0b, y1b, __builtin_elementwise_fma(x0a, y1a, p01));
+                            p10 = __builtin_elementwise_fma(x1b, y0b, __builtin_elementwise_fma(x1a, y0a, p10));
+                            p11 = __builtin_elementwise_fma(x1b, y1b, __builtin_elementwise_fma(x1a, y1a, p11));
+                        }
+                    }
+                    a00 = p00[0] + p00[1]; a01 = p01[0] + p01[1]; a10 = p10[0] + p10[1]; a11 = p11[0] + p11[1];
+                } else {
+                    a00 = a01 = a10 = a11 = 0.f;
                     // The 168-register variants (three workgroups per CU) take the 32 row loads in two rounds: hoisted all
                     // at once they need the callee-saved registers, and saving those at every call of this function was
                     // 18 GB of scratch traffic per 4096-problem batch (columns 30, 31 of the panel are stored as zeros).
@@ -1472,7 +1495,7 @@ __device__ __attribute__((noinline)) void stage_post_pre(lds_t lds, int Nrt, flo
     CMPC_PHASE_PROLOGUE;
     const int k = __builtin_amdgcn_readfirstlane(k_in);
     const bool use_exact = __builtin_amdgcn_readfirstlane((int)exact_in) != 0;
-    stage_post_body<NT, FG>(c, prm, tid, k, c.P0, c.Qb, tqp);
+    stage_post_body<NT, (NC > 0 && NC <= 20)>(c, prm, tid, k, c.P0, c.Qb, tqp);
     if (k > 0) {
         use_desc_set(c, (k - 1) & 1);
         stage_pre_body<NT, NC, FG>(c, prm, tid, k - 1, c.P0, true, use_exact, reg, cmu, tpk);
