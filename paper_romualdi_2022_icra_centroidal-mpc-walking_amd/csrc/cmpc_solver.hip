@@ -1585,8 +1585,9 @@ __device__ __attribute__((noinline)) void sq_factor_loop(lds_t lds, int Nrt, flo
 // instructions per wave and stage, two thirds of them index decoding, clamping and divergent control flow that does not depend on the stage.
 // Here everything that is fixed over a backward pass -- which entries a lane owns, the rows its sparse columns point at, where results go -- is
 // decoded ONCE per pass into a per-lane plan of indices and 0/1 float masks (ConsPlan), the stage body is straight-line code on clamped indices
-// (results of lanes without a task go to words nobody reads), and the set a stage is assembled in is a template parameter, so that every set offset
-// folds into the immediate field of the LDS instruction (that is why Qss lives inside the set: QuuF | Pan | Qb, one stride).
+// (results of lanes without a task go to words nobody reads), and a set is ONE stride (QuuF | Pan | Qb: that is why Qss lives inside the set) -- first with the
+// set as a template parameter, every set offset an immediate of the LDS instruction; since the consumers wait for the factorising wave anyway, now as a runtime value:
+// one copy of the stage body, the set offsets in scalar registers (see sq_consume_loop).
 // =====================================================================================================================
 struct ConsPlan {
     // the thread's float32 triple: out_c = w . Y[:, col + c] + ew E[3 c] + m_c (qd - symw)
