@@ -90,6 +90,9 @@
 #define REC_WT 576
 #define REC_ZERO 572
 #define REC_N CMPC_REC_N
+#ifndef CMPC_DELTA_UNROLL
+#define CMPC_DELTA_UNROLL 4   // the same for the corrector sweep of the resident variants (2 -> 4: 354.9 k -> 356.2 k solves/s at B = 256, three rounds)
+#endif
 #ifndef CMPC_SWEEP_UNROLL
 #define CMPC_SWEEP_UNROLL 4   // stages per trip of the sweep loops in the resident variants (A/B: 1 / 2 / 4 / 10 -> 184.4 / 186.1 / 189.8 / 188.0 k solves/s)
 #endif
@@ -2905,7 +2908,7 @@ template <int NT, int NC, bool FG, int PART>
 __device__ __attribute__((noinline)) void phase_delta_part(lds_t lds, int Nrt, float* fg_base)
 {
     CMPC_PHASE_PROLOGUE;
-    riccati_delta<NC == 0 ? 1 : 2, FG, PART>(c, prm, PART == 1 ? tid - 64 * CMPC_SWEEP_WAVE : tid);
+    riccati_delta<NC == 0 ? 1 : (FG ? 2 : CMPC_DELTA_UNROLL), FG, PART>(c, prm, PART == 1 ? tid - 64 * CMPC_SWEEP_WAVE : tid);
 }
 template <int NT, int NC, bool FG>
 __device__ __forceinline__ void phase_delta(lds_t lds, int Nrt, float* fg_base)
