@@ -101,7 +101,13 @@ class WalkingRollout:
         state = torch.from_numpy(np.concatenate([com0, dcom0, h0], 1).astype(np.float32)).to(dev)
         wrench = torch.zeros((B, N, 6), dtype=torch.float32, device=dev)
         dpush = torch.from_numpy(np.asarray(push, np.float32)).to(dev) if push is not None else None
-        kk = torch.arange(N + 1, dtype=torch.float32, device=dev)
+        # references at the knots (CentroidalMPCBlock.cpp:525-577 resamples the planner's; here a straight line at the plan's mean speed): y and z never
+        # change and no kernel of the tick writes those entries of dP, so they are written once; x is ONE launch per tick (ref_x0 + speed * now)
+        ref = dP[:, L.p_comref:L.p_comref + 3 * (N + 1)].view(B, N + 1, 3)
+        ref[:, :, 1] = 0.0
+        ref[:, :, 2] = 0.7
+        ref_x = ref[:, :, 0]
+        ref_x0 = (self.com_speed * dt * torch.arange(N + 1, dtype=torch.float32, device=dev))[None, :].expand(B, N + 1)
         import time
         rec = dict(iterations_mean=[], iterations_max=[], converged=[], merge_ok=[], com=[], land=[], landing_offset=[], solve_ms=[], zmp=[],
                    tick_ms=[], retried=[], unconverged=[])
@@ -118,27 +124,20 @@ class WalkingRollout:
                 lists = tuple(a.clone() for a in self.plan)
                 ok = torch.ones((B,), dtype=torch.int32, device=dev)
             else:
+                # (whether every merge succeeded is read by the host at the END of the tick, with the status words: a read here would drain the stream in the
+                #  middle of the tick and leave the GPU idle while the host queues the six launches in front of the solve -- 0.17 ms of a 0.83 ms tick at
+                #  B <= 256, tools/gpu_rollout_tick_overhead.py.  Until then a failed problem is harmless: its merged list is empty, the sampling kernel leaves
+                #  its blocks of dP as they were and writes land = -2, the adjustment kernel skips it -- include/cmpc.h)
                 lists, ok = s.contacts_merge_device(now, self.plan, mpc_prev)
-                if not bool(ok.all().item()):
-                    # the reference aborts the tick when updateContactPhaseList returns false (CentroidalMPCBlock.cpp:603-607): so does
-                    # the roll-out -- the merged lists of the failing problems are empty and must not be sampled or solved
-                    # (every per-tick list gets its entry, so that the records stay aligned; bench.py fails the roll-out when it sees 'aborted_tick')
-                    rec["merge_ok"].append(False)
-                    rec["aborted_tick"] = i
-                    rec["tick_ms"].append(float("nan")); rec["retried"].append(0); rec["unconverged"].append(B)
-                    rec["iterations_mean"].append(float("nan")); rec["iterations_max"].append(0); rec["converged"].append(False)
-                    rec["solve_ms"].append(float("nan"))
-                    break
             land = s.contacts_sample_device(now, lists, dP)
-            # references at the knots (CentroidalMPCBlock.cpp:525-577 resamples the planner's; here a straight line)
-            ref = dP[:, L.p_comref:L.p_comref + 3 * (N + 1)].view(B, N + 1, 3)
-            ref[:, :, 0] = self.com_speed * (now + kk * dt)[None, :]
-            ref[:, :, 1] = 0.0
-            ref[:, :, 2] = 0.7
-            wrench.zero_()
-            if dpush is not None and i < push_ticks:
-                wrench[:, :max(push_ticks - i, 1), :3] = dpush[:, None, :]
-            s.write_state_device(state, dP, wrench)
+            torch.add(ref_x0, self.com_speed * now, out=ref_x)
+            if dpush is not None and i <= push_ticks:      # (the wrench rows of dP change while the push lasts and once more when it ends; zero from the start otherwise)
+                wrench.zero_()
+                if i < push_ticks:
+                    wrench[:, :max(push_ticks - i, 1), :3] = dpush[:, None, :]
+                s.write_state_device(state, dP, wrench)
+            else:
+                s.write_state_device(state, dP, None)
             shifted = not (mpc_prev is None or not warm)
             if not shifted:
                 # cold start: CoM at com0, feet at nominal, f_z = g/8 per corner
@@ -176,7 +175,18 @@ class WalkingRollout:
             mpc_prev = lists
             state, zmp = s.plant_step_device(dX, dP, state, step=dt / self.substeps, substeps=self.substeps)
             torch.cuda.synchronize()
-            rec["tick_ms"].append((time.perf_counter() - t_tick) * 1e3)
+            tick_ms = (time.perf_counter() - t_tick) * 1e3
+            if not bool(ok.cpu().numpy().all()):
+                # the reference aborts the tick when updateContactPhaseList returns false (CentroidalMPCBlock.cpp:603-607): so does the roll-out -- what
+                # the tick computed is discarded (every per-tick list gets its entry, so that the records stay aligned; bench.py fails the roll-out
+                # when it sees 'aborted_tick')
+                rec["merge_ok"].append(False)
+                rec["aborted_tick"] = i
+                rec["tick_ms"].append(float("nan")); rec["retried"].append(0); rec["unconverged"].append(B)
+                rec["iterations_mean"].append(float("nan")); rec["iterations_max"].append(0); rec["converged"].append(False)
+                rec["solve_ms"].append(float("nan"))
+                break
+            rec["tick_ms"].append(tick_ms)
             rec["retried"].append(nretry)
             info = dInfo.cpu().numpy()
             rec["unconverged"].append(int((info[:, 5] != 0).sum()))
@@ -187,7 +197,7 @@ class WalkingRollout:
             rec["iterations_max"].append(int(info[:, 0].max()))
             rec["converged"].append(bool((info[:, 5] == 0).all()))
             rec.setdefault("failed_info", []).append(info[info[:, 5] != 0])
-            rec["merge_ok"].append(bool(ok.cpu().numpy().all()))
+            rec["merge_ok"].append(True)
             rec["solve_ms"].append(s.last_solve_ms())
             if record != "full":
                 continue
