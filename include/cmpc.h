@@ -260,6 +260,38 @@ int cmpc_contacts_adjust_device(cmpc_handle h, int max_contacts, double now, con
 
 /* setState on the device: dState[B][9] (com, dcom, h) and dWrench[B][N][6] (or NULL: left alone) into the rows of dP */
 int cmpc_write_state_device(cmpc_handle h, const float* dState, const float* dWrench, float* dP, void* stream);
+
+/* ONE receding-horizon tick of the whole batch as ONE call: what CentroidalMPCBlock::advance does between two solves
+ * (CentroidalMPCBlock.cpp:594-626) and WholeBodyQPBlock::advance after it (WholeBodyQPBlock.cpp:1083-1150), chained on
+ * `stream` (NULL: the handle's) without returning to the host in between:
+ *   cmpc_contacts_merge_device (updateContactPhaseList :594-607) -> cmpc_contacts_sample_device (setContactPhaseList :609)
+ *   -> cmpc_write_state_device (setState :407) -> cmpc_shift_solution_device (is_warm_start_enabled; warm != 0)
+ *   -> cmpc_solve_device[_warm] (advance :615) -> cmpc_contacts_adjust_device (getOutput :626) -> cmpc_plant_step_device.
+ * Every step is what the entry point of that name computes, with the same argument checks; the steps in front of the solve are ONE launch and so are the
+ * two behind it (they touch disjoint entries; same per-problem device functions: results identical to the last bit), so that a tick is three dispatches instead of ten.  It saves the
+ * caller six trips through its FFI and the idle GPU time between them (a seventh of a tick at B <= 256,
+ * tools/gpu_rollout_tick_overhead.py).  The reference rows of dP (comRef, hRef) are the caller's: write them before the call.
+ * All pointers are device pointers except box_upper / box_lower (host, [2][3]). */
+typedef struct cmpc_tick_io {
+    const double* dPlanT; const float* dPlanPose; const int* dPlanN; /* the planner's lists (layout above) */
+    const double* dPrevT; const float* dPrevPose; const int* dPrevN; /* the MPC's lists of the previous tick.  All NULL (first tick):
+                                                                        no merge, dList* is taken as the caller filled it, dOk is left alone */
+    double* dListT; float* dListPose; int* dListN;                   /* this tick's lists: merged here, sampled, and step-adjusted after
+                                                                        the solve (the next tick's dPrev*); must not alias dPrev* */
+    int* dOk;               /* [B] merge status (0: the tick of that problem must be discarded, :603-607), or NULL */
+    int* dLand;             /* [B][2] landing knots */
+    const float* box_upper; const float* box_lower;
+    const float* dState;    /* [B][9] measured com, dcom, h */
+    const float* dWrench;   /* [B][N][6] or NULL (rows of dP left alone) */
+    float* dP;              /* [B][n_p] */
+    float* dX0;             /* [B][n_x] starting point: written (dX shifted by one knot) when warm != 0, read when warm == 0 */
+    float* dX;              /* [B][n_x] previous solution in (warm != 0), this tick's solution out */
+    float* dInfo;           /* [B][CMPC_INFO] */
+    float* dStateOut;       /* [B][9] state at the next tick (may alias dState) */
+    float* dZmp;            /* [B][2] or NULL */
+    double plant_step; int plant_substeps; double zmp_half_x, zmp_half_y; /* as cmpc_plant_step_device */
+} cmpc_tick_io;
+int cmpc_rollout_tick_device(cmpc_handle h, int max_contacts, double now, int warm, const cmpc_tick_io* io, void* stream);
 /* is_warm_start_enabled on the device: dX0 = dXprev shifted by one knot; solve from it with cmpc_solve_device_warm
  * (cmpc_set_initial_guess(NULL, 1) + cmpc_advance do the same for the handle's own buffers) */
 int cmpc_shift_solution_device(cmpc_handle h, const float* dXprev, float* dX0, void* stream);

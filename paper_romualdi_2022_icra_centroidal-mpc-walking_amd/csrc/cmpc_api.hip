@@ -30,6 +30,13 @@ extern "C" int cmpc_launch_contacts_adjust(int B, int N, int M, double now, cons
                                            const int* n, hipStream_t stream);
 extern "C" int cmpc_launch_write_state(int B, int N, const float* state, const float* wrench, float* P, hipStream_t stream);
 extern "C" int cmpc_launch_compact(int N, int B, const float* dX, const float* dInfo, float* dOut, hipStream_t stream);
+extern "C" int cmpc_launch_tick_pre(int B, int N, int M, double dt, double now, int merge, const double* plan_t, const float* plan_pose, const int* plan_n,
+                                    const double* prev_t, const float* prev_pose, const int* prev_n, double* list_t, float* list_pose, int* list_n, int* ok,
+                                    int* land, const float* box, const float* state, const float* wrench, float* P, const float* Xprev, float* X0,
+                                    hipStream_t stream);
+extern "C" int cmpc_launch_tick_post(int B, int N, int M, double now, float grav, const float* dCorners, const float* dX, const float* dP,
+                                     const float* dStateIn, float* dStateOut, float* dZmp, float h, int nsub, float zx, float zy, const int* land,
+                                     const double* t, float* pose, const int* n, hipStream_t stream);
 extern "C" int cmpc_launch_plant_step(int N, int B, float grav, const float* dCorners, const float* dX, const float* dP,
                                       const float* dStateIn, float* dStateOut, float* dZmp, float h, int nsub, float zx, float zy,
                                       hipStream_t stream);
@@ -800,12 +807,9 @@ int cmpc_contacts_merge_device(cmpc_handle h, int max_contacts, double now, cons
     return CMPC_OK;
 }
 
-int cmpc_contacts_sample_device(cmpc_handle h, int max_contacts, double now, const double* dT, const float* dPose, const int* dN,
-                                const float* box_upper, const float* box_lower, float* dP, int* dLand, void* stream)
+// the bounding boxes of the two contacts on the device (uploaded when they change)
+static int upload_box(cmpc_handle h, const float* box_upper, const float* box_lower, hipStream_t st)
 {
-    if (!h || max_contacts < 1 || !dT || !dPose || !dN || !box_upper || !box_lower || !dP) return fail(h, CMPC_ERR_ARG, "cmpc_contacts_sample_device: bad argument");
-    HIPCHK(h, hipSetDevice(h->device));
-    hipStream_t st = stream ? (hipStream_t)stream : h->stream;
     float box[12];
     std::memcpy(box, box_upper, sizeof(float) * 6);
     std::memcpy(box + 6, box_lower, sizeof(float) * 6);
@@ -814,7 +818,18 @@ int cmpc_contacts_sample_device(cmpc_handle h, int max_contacts, double now, con
         HIPCHK(h, hipMemcpyAsync(h->dBox, h->hBox, sizeof(box), hipMemcpyHostToDevice, st));
         h->box_set = true;
     }
-    int rc = cmpc_launch_contacts_sample(h->B, h->cfg.horizon, max_contacts, h->cfg.sampling_time, now, dT, dPose, dN, h->dBox, dP, dLand, st);
+    return CMPC_OK;
+}
+
+int cmpc_contacts_sample_device(cmpc_handle h, int max_contacts, double now, const double* dT, const float* dPose, const int* dN,
+                                const float* box_upper, const float* box_lower, float* dP, int* dLand, void* stream)
+{
+    if (!h || max_contacts < 1 || !dT || !dPose || !dN || !box_upper || !box_lower || !dP) return fail(h, CMPC_ERR_ARG, "cmpc_contacts_sample_device: bad argument");
+    HIPCHK(h, hipSetDevice(h->device));
+    hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+    int rc = upload_box(h, box_upper, box_lower, st);
+    if (rc != CMPC_OK) return rc;
+    rc = cmpc_launch_contacts_sample(h->B, h->cfg.horizon, max_contacts, h->cfg.sampling_time, now, dT, dPose, dN, h->dBox, dP, dLand, st);
     if (rc != 0) return fail(h, CMPC_ERR_HIP, std::string("contact sampling launch: ") + hipGetErrorString((hipError_t)rc));
     return CMPC_OK;
 }
@@ -847,6 +862,38 @@ int cmpc_shift_solution_device(cmpc_handle h, const float* dXprev, float* dX0, v
     int rc = cmpc_launch_warm_shift(&p, dXprev, dX0, stream ? (hipStream_t)stream : h->stream);
     if (rc != 0) return fail(h, CMPC_ERR_HIP, "warm-start shift launch failed");
     return CMPC_OK;   // (no state on the handle: the caller solves from dX0 with cmpc_solve_device_warm)
+}
+
+// ---- 8f-1 .. 8f-4 chained: one tick of the receding-horizon loop in one call (include/cmpc.h): the steps of the entry points above in the reference's order, with the
+// same argument checks, as THREE launches -- everything in front of the solve, the solve, everything behind it (cmpc_tick_pre_kernel / cmpc_tick_post_kernel call the same
+// per-problem functions as the single kernels; results identical to the last bit). ----
+int cmpc_rollout_tick_device(cmpc_handle h, int max_contacts, double now, int warm, const cmpc_tick_io* io, void* stream)
+{
+    if (!h || !io) return fail(h, CMPC_ERR_ARG, "cmpc_rollout_tick_device: null argument");
+    if (!io->dLand || !io->dInfo) return fail(h, CMPC_ERR_ARG, "cmpc_rollout_tick_device: dLand and dInfo are needed");
+    const bool merge = io->dPrevT || io->dPrevPose || io->dPrevN;
+    if (merge && (io->dPrevT == io->dListT || io->dPrevPose == io->dListPose || io->dPrevN == io->dListN))
+        return fail(h, CMPC_ERR_ARG, "cmpc_rollout_tick_device: the merged lists must not alias the previous tick's");
+    if (merge && (!io->dPlanT || !io->dPlanPose || !io->dPlanN || !io->dPrevT || !io->dPrevPose || !io->dPrevN))
+        return fail(h, CMPC_ERR_ARG, "cmpc_rollout_tick_device: the merge needs the planner's and the previous tick's lists");
+    if (max_contacts < 1 || !io->dListT || !io->dListPose || !io->dListN || !io->box_upper || !io->box_lower || !io->dState || !io->dP || !io->dX0 || !io->dX ||
+        !io->dStateOut || !(io->plant_step > 0) || io->plant_substeps < 1)
+        return fail(h, CMPC_ERR_ARG, "cmpc_rollout_tick_device: bad argument");
+    HIPCHK(h, hipSetDevice(h->device));
+    hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+    int rc = upload_box(h, io->box_upper, io->box_lower, st);
+    if (rc != CMPC_OK) return rc;
+    int lrc = cmpc_launch_tick_pre(h->B, h->cfg.horizon, max_contacts, h->cfg.sampling_time, now, merge ? 1 : 0, io->dPlanT, io->dPlanPose, io->dPlanN, io->dPrevT,
+                                   io->dPrevPose, io->dPrevN, io->dListT, io->dListPose, io->dListN, io->dOk, io->dLand, h->dBox, io->dState, io->dWrench, io->dP,
+                                   warm ? io->dX : nullptr, io->dX0, st);
+    if (lrc != 0) return fail(h, CMPC_ERR_HIP, std::string("tick (front) launch: ") + hipGetErrorString((hipError_t)lrc));
+    rc = solve_device_impl(h, io->dP, io->dX0, io->dX, io->dInfo, stream, warm != 0);
+    if (rc != CMPC_OK) return rc;
+    lrc = cmpc_launch_tick_post(h->B, h->cfg.horizon, max_contacts, now, (float)h->cfg.gravity, h->dConsts->corners, io->dX, io->dP, io->dState, io->dStateOut, io->dZmp,
+                                (float)io->plant_step, io->plant_substeps, (float)io->zmp_half_x, (float)io->zmp_half_y, io->dLand, io->dListT, io->dListPose,
+                                io->dListN, st);
+    if (lrc != 0) return fail(h, CMPC_ERR_HIP, std::string("tick (back) launch: ") + hipGetErrorString((hipError_t)lrc));
+    return CMPC_OK;
 }
 
 // the handle's own contact blocks from contact lists (what the class facade's setContactPhaseList calls)

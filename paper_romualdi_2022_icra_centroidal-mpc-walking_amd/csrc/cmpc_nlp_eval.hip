@@ -9,6 +9,7 @@
 // One workgroup per problem: x, p and lam_g are staged in LDS (12 KB at N=20), every output
 // element is one thread's closed-form expression, output rows are written coalesced.  The path is
 // HBM-write bound (~45 KB out per problem when the Hessian is requested).
+#include "cmpc_contacts.h"
 #include "cmpc_device.h"
 
 #include <algorithm>
@@ -458,14 +459,12 @@ __global__ __launch_bounds__(256) void cmpc_nlp_grad_kernel(CmpcParams kp, const
 
 // warm start: previous solution shifted by one knot (last knot repeated); is_warm_start_enabled of
 // the reference (ergoCubGazeboV1/centroidal_mpc.ini:9)
-__global__ __launch_bounds__(256) void cmpc_warm_shift_kernel(int N, int B, const float* __restrict__ Xp, float* __restrict__ X0)
+// (one problem: xp -> x0, thread tid of nt)
+__device__ inline void warm_shift_problem(int N, const float* __restrict__ xp, float* __restrict__ x0, int tid, int nt)
 {
     CmpcLayout L;
     cmpc_layout_init(L, N);
-    const int b = blockIdx.x;
-    const float* xp = Xp + (size_t)b * L.nx;
-    float* x0 = X0 + (size_t)b * L.nx;
-    for (int e = threadIdx.x; e < L.nx; e += 256) {
+    for (int e = tid; e < L.nx; e += nt) {
         // every block of x is 3 x (N+1) or 3 x N, column = knot: find block start and length
         int start, len;
         if (e < L.o_pos[0]) { start = (e / (3 * (N + 1))) * 3 * (N + 1); len = 3 * (N + 1); }
@@ -478,6 +477,13 @@ __global__ __launch_bounds__(256) void cmpc_warm_shift_kernel(int N, int B, cons
         const int src = off + 3 < len ? e + 3 : e;  // shift by one knot, repeat the last
         x0[e] = xp[src];
     }
+}
+__global__ __launch_bounds__(256) void cmpc_warm_shift_kernel(int N, int B, const float* __restrict__ Xp, float* __restrict__ X0)
+{
+    CmpcLayout L;
+    cmpc_layout_init(L, N);
+    const int b = blockIdx.x;
+    warm_shift_problem(N, Xp + (size_t)b * L.nx, X0 + (size_t)b * L.nx, threadIdx.x, 256);
 }
 
 void build_sparsity(int N, std::vector<Trip>& J, std::vector<Trip>& H)
@@ -642,13 +648,11 @@ extern "C" int cmpc_launch_warm_shift(const CmpcParams* prm, const float* dXprev
 // flops): the kernel is HBM/launch bound and exists so that Monte-Carlo roll-outs never leave HBM.
 namespace {
 
-__global__ __launch_bounds__(256) void cmpc_plant_step_kernel(int N, int B, float grav, const float* __restrict__ corners,
-                                                              const float* __restrict__ X, const float* __restrict__ P,
-                                                              const float* __restrict__ state_in, float* __restrict__ state_out,
-                                                              float* __restrict__ zmp, float h, int nsub, float zx, float zy)
+// (problem b, one thread.  state_in / state_out may alias: everything is read before anything is written)
+__device__ inline void plant_step_problem(int N, int b, float grav, const float* __restrict__ corners, const float* __restrict__ X,
+                                          const float* __restrict__ P, const float* state_in, float* state_out, float* __restrict__ zmp, float h,
+                                          int nsub, float zx, float zy)
 {
-    const int b = blockIdx.x * 256 + threadIdx.x;
-    if (b >= B) return;
     CmpcIdx L{N};
     const float* x = X + (size_t)b * L.nx();
     const float* p = P + (size_t)b * L.np();
@@ -719,7 +723,102 @@ __global__ __launch_bounds__(256) void cmpc_plant_step_kernel(int N, int B, floa
     }
 }
 
+__global__ __launch_bounds__(256) void cmpc_plant_step_kernel(int N, int B, float grav, const float* __restrict__ corners,
+                                                              const float* __restrict__ X, const float* __restrict__ P,
+                                                              const float* state_in, float* state_out,
+                                                              float* __restrict__ zmp, float h, int nsub, float zx, float zy)
+{
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= B) return;
+    plant_step_problem(N, b, grav, corners, X, P, state_in, state_out, zmp, h, nsub, zx, zy);
+}
+
+// ---- the two ends of a roll-out tick as ONE launch each (cmpc_rollout_tick_device).  At B <= 256 a tick is a 0.66 ms solve between nine launches of a
+// few microseconds of work each, and the dispatch of a kernel behind another costs as much as they do (tools/gpu_rollout_tick_overhead.py): the steps in
+// front of the solve touch disjoint entries of P and X0 (contact blocks / state rows / the shifted solution) and so do the two behind it (the lists' poses /
+// the state), so each group is one grid whose threads call the SAME per-problem functions as the single kernels -- results identical to the last bit
+// (tests/test_gpu_rollout.py).
+// pre: one workgroup per problem.  Threads 0, 1: merge (updateContactPhaseList) and sampling (setContactPhaseList) of foot 0 / 1 -- the sampling reads the
+// list its own thread just merged --; all threads: setState and the warm-start shift.
+__global__ __launch_bounds__(256) void cmpc_tick_pre_kernel(int B, int N, int M, double dt, double now, int merge, const double* plan_t, const float* plan_pose,
+                                                            const int* plan_n, const double* prev_t, const float* prev_pose, const int* prev_n, double* list_t,
+                                                            float* list_pose, int* list_n, int* ok, int* land, const float* __restrict__ box,
+                                                            const float* __restrict__ state, const float* __restrict__ wrench, float* P,
+                                                            const float* __restrict__ Xprev, float* __restrict__ X0)
+{
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const CmpcIdx L{N};
+    float* p = P + (size_t)b * L.np();
+    __shared__ int okw;
+    if (tid == 0) okw = 1;
+    __syncthreads();
+    if (tid < 2) {
+        const int e = 2 * b + tid;
+        const size_t o = (size_t)e * M;
+        if (merge) {
+            const bool sane = plan_n[e] >= 0 && plan_n[e] <= M && prev_n[e] >= 0 && prev_n[e] <= M;
+            if (!sane) list_n[e] = 0;
+            const bool good = sane && cmpc_merge_foot(now, plan_t + 2 * o, plan_pose + 7 * o, plan_n[e], prev_t + 2 * o, prev_pose + 7 * o, prev_n[e], M,
+                                                      list_t + 2 * o, list_pose + 7 * o, list_n + e);
+            if (!good) atomicAnd(&okw, 0);
+        }
+        const int n = list_n[e];
+        if (n < 1 || n > M) land[e] = -2;
+        else land[e] = cmpc_sample_foot(N, dt, now, tid, list_t + 2 * o, list_pose + 7 * o, n, box, box + 6, p);
+    }
+    for (int e = tid; e < 9; e += 256) p[L.pCom0() + e] = state[9 * (size_t)b + e];
+    if (wrench)
+        for (int e = tid; e < 3 * N; e += 256) {
+            const int k = e / 3, i = e % 3;
+            p[L.pFext() + e] = wrench[((size_t)b * N + k) * 6 + i];
+            p[L.pText() + e] = wrench[((size_t)b * N + k) * 6 + 3 + i];
+        }
+    if (Xprev) warm_shift_problem(N, Xprev + (size_t)b * L.nx(), X0 + (size_t)b * L.nx(), tid, 256);
+    __syncthreads();
+    if (merge && ok && tid == 0) ok[b] = okw;
+}
+
+// post: one thread per problem -- the plant step, then the step adjustment of its two feet (getOutput().contactPhaseList)
+__global__ __launch_bounds__(256) void cmpc_tick_post_kernel(int B, int N, int M, double now, float grav, const float* __restrict__ corners,
+                                                             const float* __restrict__ X, const float* __restrict__ P, const float* state_in, float* state_out,
+                                                             float* __restrict__ zmp, float h, int nsub, float zx, float zy, const int* __restrict__ land,
+                                                             const double* __restrict__ t, float* __restrict__ pose, const int* __restrict__ n)
+{
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= B) return;
+    plant_step_problem(N, b, grav, corners, X, P, state_in, state_out, zmp, h, nsub, zx, zy);
+    const CmpcIdx L{N};
+    for (int c = 0; c < 2; ++c) {
+        const int e = 2 * b + c, lk = land[e];
+        if (lk < 0 || lk > N || n[e] < 1 || n[e] > M) continue;
+        const size_t o = (size_t)e * M;
+        const int nx = cmpc_next_contact(t + 2 * o, n[e], now);
+        if (nx < 0) continue;
+        const float* x = X + (size_t)b * L.nx() + L.oPos(c) + 3 * lk;
+        for (int i = 0; i < 3; ++i) pose[7 * (o + nx) + i] = x[i];
+    }
+}
+
 }  // namespace
+
+extern "C" int cmpc_launch_tick_pre(int B, int N, int M, double dt, double now, int merge, const double* plan_t, const float* plan_pose, const int* plan_n,
+                                    const double* prev_t, const float* prev_pose, const int* prev_n, double* list_t, float* list_pose, int* list_n, int* ok,
+                                    int* land, const float* box, const float* state, const float* wrench, float* P, const float* Xprev, float* X0,
+                                    hipStream_t stream)
+{
+    hipLaunchKernelGGL(cmpc_tick_pre_kernel, dim3(B), dim3(256), 0, stream, B, N, M, dt, now, merge, plan_t, plan_pose, plan_n, prev_t, prev_pose, prev_n,
+                       list_t, list_pose, list_n, ok, land, box, state, wrench, P, Xprev, X0);
+    return (int)hipGetLastError();
+}
+
+extern "C" int cmpc_launch_tick_post(int B, int N, int M, double now, float grav, const float* dCorners, const float* dX, const float* dP,
+                                     const float* dStateIn, float* dStateOut, float* dZmp, float h, int nsub, float zx, float zy, const int* land,
+                                     const double* t, float* pose, const int* n, hipStream_t stream)
+{
+    hipLaunchKernelGGL(cmpc_tick_post_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, B, N, M, now, grav, dCorners, dX, dP, dStateIn, dStateOut, dZmp,
+                       h, nsub, zx, zy, land, t, pose, n);
+    return (int)hipGetLastError();
+}
 
 extern "C" int cmpc_launch_plant_step(int N, int B, float grav, const float* dCorners, const float* dX, const float* dP,
                                       const float* dStateIn, float* dStateOut, float* dZmp, float h, int nsub, float zx, float zy,

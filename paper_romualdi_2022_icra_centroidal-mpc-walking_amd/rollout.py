@@ -42,7 +42,7 @@ class WalkingRollout:
     stragglers are solved again from the cold start in a small launch of their own (a CU each); None: they stay unconverged -- which is all
     the reference can do: its advance() returns false and the tick is aborted (CentroidalMPCBlock.cpp:615-619)."""
 
-    def __init__(self, cfg, batch, plan=None, device=0, substeps=6, com_speed=None, warm_budget=14, retry="kernel", retry_batch=256, **solver_opts):
+    def __init__(self, cfg, batch, plan=None, device=0, substeps=6, com_speed=None, warm_budget=14, retry="kernel", retry_batch=256, native_tick=True, **solver_opts):
         import torch
         self.torch = torch
         self.cfg, self.B = cfg, batch
@@ -51,6 +51,9 @@ class WalkingRollout:
         self.solver = BatchSolver(cfg, batch, device=device, **solver_opts)
         assert retry in ("kernel", "launch", None)
         self.retry, self.retry_batch = retry, min(retry_batch, batch)
+        # native_tick: a warm-started tick is ONE call of the C ABI (cmpc_rollout_tick_device: the same seven entry points chained inside the library, bit-identical
+        # results) instead of seven; ticks that need the host between the steps (cold starts, retry="launch", the dump hook) take the step-by-step path
+        self.native_tick = native_tick and retry != "launch"
         self.solver.set_warm_policy(warm_budget, restart_in_kernel=(retry == "kernel"))
         self.solver2 = BatchSolver(cfg, self.retry_batch, device=device, **solver_opts) if retry == "launch" else None
         plan = plan or walking_plan(cfg)
@@ -83,12 +86,72 @@ class WalkingRollout:
         finally:
             cur.wait_stream(ls)
 
-    def _run(self, ticks, com0, dcom0, h0, push=None, push_ticks=0, warm=True, dump=None, replan=None, slow=None, record="full"):
+    def _tick_by_steps(self, i, now, mpc_prev, warm, dump, dP, dX0, dX, dInfo, state, wrench, dpush, push_ticks, ref_x0, ref_x):
+        """one tick as seven calls of the C ABI with the host between them (cold starts, retry="launch", the dump hook; native_tick=False)"""
+        torch, L, cfg, B, N = self.torch, self.L, self.cfg, self.B, self.cfg.N
+        dt, dev, s = cfg.sampling_time, self.dev, self.solver
+        if mpc_prev is None:
+            lists = tuple(a.clone() for a in self.plan)
+            ok = torch.ones((B,), dtype=torch.int32, device=dev)
+        else:
+            # (whether every merge succeeded is read by the host at the END of the tick, with the status words: a read here would drain the stream in the
+            #  middle of the tick and leave the GPU idle while the host queues the six launches in front of the solve -- 0.17 ms of a 0.83 ms tick at
+            #  B <= 256, tools/gpu_rollout_tick_overhead.py.  Until then a failed problem is harmless: its merged list is empty, the sampling kernel leaves
+            #  its blocks of dP as they were and writes land = -2, the adjustment kernel skips it -- include/cmpc.h)
+            lists, ok = s.contacts_merge_device(now, self.plan, mpc_prev)
+        land = s.contacts_sample_device(now, lists, dP)
+        torch.add(ref_x0, self.com_speed * now, out=ref_x)
+        if dpush is not None and i <= push_ticks:      # (the wrench rows of dP change while the push lasts and once more when it ends; zero from the start otherwise)
+            wrench.zero_()
+            if i < push_ticks:
+                wrench[:, :max(push_ticks - i, 1), :3] = dpush[:, None, :]
+            s.write_state_device(state, dP, wrench)
+        else:
+            s.write_state_device(state, dP, None)
+        shifted = not (mpc_prev is None or not warm)
+        if not shifted:
+            # cold start (SURVEY 8d): CoM at com0, feet at nominal, f_z = g/8 per corner
+            dX0.zero_()
+            dX0[:, L.com:L.com + 3 * (N + 1)] = state[:, 0:3].repeat(1, N + 1)
+            for c in range(2):
+                dX0[:, L.pos[c]:L.pos[c] + 3 * (N + 1)] = dP[:, L.p_nom[c]:L.p_nom[c] + 3 * (N + 1)]
+                for j in range(4):
+                    dX0[:, L.f[c][j] + 2:L.f[c][j] + 3 * N:3] = GRAVITY / 8.0   # (the library's cold start: cmpc_config.gravity / 8, which this package always sets to GRAVITY)
+        else:
+            s.shift_solution_device(dX, dX0)
+        if dump is not None and i == dump[0]:   # developer hook: (tick, path) -> the tick's P and X0
+            np.savez(dump[1], P=dP.cpu().numpy(), X0=dX0.cpu().numpy())
+        s.solve_device(dP, dX0, dX, dInfo, warm=shifted)
+        nretry = 0
+        if self.retry == "launch" and shifted:
+            bad = (dInfo[:, 5] != 0).nonzero().flatten()        # (one scalar comes to the host: the count)
+            nretry = int(bad.numel())
+            for lo in range(0, nretry, self.retry_batch):
+                chunk = bad[lo:lo + self.retry_batch]
+                idx = torch.cat([chunk, chunk[:1].expand(self.retry_batch - chunk.numel())]) if chunk.numel() < self.retry_batch else chunk
+                P2 = dP.index_select(0, idx)
+                X02 = torch.zeros((self.retry_batch, L.nx), dtype=torch.float32, device=dev)       # the cold start of SURVEY 8d
+                X02[:, L.com:L.com + 3 * (N + 1)] = P2[:, L.p_com0:L.p_com0 + 3].repeat(1, N + 1)
+                for c in range(2):
+                    X02[:, L.pos[c]:L.pos[c] + 3 * (N + 1)] = P2[:, L.p_nom[c]:L.p_nom[c] + 3 * (N + 1)]
+                    for j in range(4):
+                        X02[:, L.f[c][j] + 2:L.f[c][j] + 3 * N:3] = GRAVITY / 8.0
+                X2, I2 = self.solver2.solve_device(P2, X02)
+                I2[:, 0] += dInfo.index_select(0, idx)[:, 0]     # iterations of both attempts
+                I2[:, 3] += 10000.0                              # safeguard word: solved again from the cold start
+                dX.index_copy_(0, chunk, X2[:chunk.numel()])
+                dInfo.index_copy_(0, chunk, I2[:chunk.numel()])
+        s.contacts_adjust_device(now, dX, land, lists)
+        state, zmp = s.plant_step_device(dX, dP, state, step=dt / self.substeps, substeps=self.substeps)
+        return ok, lists, land, nretry, state, zmp
+
+    def _run(self, ticks, com0, dcom0, h0, push=None, push_ticks=0, warm=True, dump=None, replan=None, slow=None, record="full", timing=True):
         """com0/dcom0/h0 [B,3] numpy; push [B,3] (mass-normalised force held for the first `push_ticks` ticks);
         replan {tick: (t, pose, n)}: the planner's lists from that tick on (the reference's generator re-plans while walking);
         slow (threshold, list): developer hook -- (tick, problem, P row, X0 row, info row) of every solve with more iterations;
         record "full": per-tick CoM, ZMP, landing offsets (host loops over the batch); "light": iteration statistics and the tick's
-        wall-clock latency only (what bench.py times).
+        wall-clock latency only (what bench.py times).  timing=False: without the library's event pair around every solve (cmpc_set_timing: an event record
+        is a barrier packet on the stream, ~10 us of a tick each); rec["solve_ms"] is then NaN.
         Returns a dict of per-tick numpy records."""
         torch, L, cfg, B, N = self.torch, self.L, self.cfg, self.B, self.cfg.N
         dt = cfg.sampling_time
@@ -111,7 +174,8 @@ class WalkingRollout:
         import time
         rec = dict(iterations_mean=[], iterations_max=[], converged=[], merge_ok=[], com=[], land=[], landing_offset=[], solve_ms=[], zmp=[],
                    tick_ms=[], retried=[], unconverged=[])
-        mpc_prev = None
+        mpc_prev, tick_bufs = None, None
+        s.set_timing(timing)
         box_up = np.array([c.bounding_box_upper_limit for c in cfg.contacts])
         box_lo = np.array([c.bounding_box_lower_limit for c in cfg.contacts])
         for i in range(ticks):
@@ -120,60 +184,27 @@ class WalkingRollout:
             t_tick = time.perf_counter()
             if replan and i in replan:
                 self.plan = replan[i]
-            if mpc_prev is None:
-                lists = tuple(a.clone() for a in self.plan)
-                ok = torch.ones((B,), dtype=torch.int32, device=dev)
+            if self.native_tick and warm and mpc_prev is not None and not (dump is not None and i == dump[0]):
+                if tick_bufs is None:
+                    tick_bufs = ([tuple(torch.zeros_like(a) for a in self.plan) for _ in range(2)], torch.empty((B, 2), dtype=torch.int32, device=dev),
+                                 torch.empty((B, 2), dtype=torch.float32, device=dev))
+                lists = tick_bufs[0][i & 1] if mpc_prev[0] is not tick_bufs[0][i & 1][0] else tick_bufs[0][1 - (i & 1)]
+                ok = torch.empty((B,), dtype=torch.int32, device=dev)
+                land, zmp = tick_bufs[1], tick_bufs[2]
+                torch.add(ref_x0, self.com_speed * now, out=ref_x)
+                wr = None
+                if dpush is not None and i <= push_ticks:
+                    wrench.zero_()
+                    if i < push_ticks:
+                        wrench[:, :max(push_ticks - i, 1), :3] = dpush[:, None, :]
+                    wr = wrench
+                s.rollout_tick_device(now, self.plan, mpc_prev, lists, ok, land, state, wr, dP, dX0, dX, dInfo, state, zmp, True,
+                                      step=dt / self.substeps, substeps=self.substeps)
+                mpc_prev = lists
+                nretry = 0
             else:
-                # (whether every merge succeeded is read by the host at the END of the tick, with the status words: a read here would drain the stream in the
-                #  middle of the tick and leave the GPU idle while the host queues the six launches in front of the solve -- 0.17 ms of a 0.83 ms tick at
-                #  B <= 256, tools/gpu_rollout_tick_overhead.py.  Until then a failed problem is harmless: its merged list is empty, the sampling kernel leaves
-                #  its blocks of dP as they were and writes land = -2, the adjustment kernel skips it -- include/cmpc.h)
-                lists, ok = s.contacts_merge_device(now, self.plan, mpc_prev)
-            land = s.contacts_sample_device(now, lists, dP)
-            torch.add(ref_x0, self.com_speed * now, out=ref_x)
-            if dpush is not None and i <= push_ticks:      # (the wrench rows of dP change while the push lasts and once more when it ends; zero from the start otherwise)
-                wrench.zero_()
-                if i < push_ticks:
-                    wrench[:, :max(push_ticks - i, 1), :3] = dpush[:, None, :]
-                s.write_state_device(state, dP, wrench)
-            else:
-                s.write_state_device(state, dP, None)
-            shifted = not (mpc_prev is None or not warm)
-            if not shifted:
-                # cold start: CoM at com0, feet at nominal, f_z = g/8 per corner
-                dX0.zero_()
-                dX0[:, L.com:L.com + 3 * (N + 1)] = state[:, 0:3].repeat(1, N + 1)
-                for c in range(2):
-                    dX0[:, L.pos[c]:L.pos[c] + 3 * (N + 1)] = dP[:, L.p_nom[c]:L.p_nom[c] + 3 * (N + 1)]
-                    for j in range(4):
-                        dX0[:, L.f[c][j] + 2:L.f[c][j] + 3 * N:3] = GRAVITY / 8.0   # (the library's cold start: cmpc_config.gravity / 8, which this package always sets to GRAVITY)
-            else:
-                s.shift_solution_device(dX, dX0)
-            if dump is not None and i == dump[0]:   # developer hook: (tick, path) -> the tick's P and X0
-                np.savez(dump[1], P=dP.cpu().numpy(), X0=dX0.cpu().numpy())
-            s.solve_device(dP, dX0, dX, dInfo, warm=shifted)
-            nretry = 0
-            if self.retry == "launch" and shifted:
-                bad = (dInfo[:, 5] != 0).nonzero().flatten()        # (one scalar comes to the host: the count)
-                nretry = int(bad.numel())
-                for lo in range(0, nretry, self.retry_batch):
-                    chunk = bad[lo:lo + self.retry_batch]
-                    idx = torch.cat([chunk, chunk[:1].expand(self.retry_batch - chunk.numel())]) if chunk.numel() < self.retry_batch else chunk
-                    P2 = dP.index_select(0, idx)
-                    X02 = torch.zeros((self.retry_batch, L.nx), dtype=torch.float32, device=dev)       # the cold start of SURVEY 8d
-                    X02[:, L.com:L.com + 3 * (N + 1)] = P2[:, L.p_com0:L.p_com0 + 3].repeat(1, N + 1)
-                    for c in range(2):
-                        X02[:, L.pos[c]:L.pos[c] + 3 * (N + 1)] = P2[:, L.p_nom[c]:L.p_nom[c] + 3 * (N + 1)]
-                        for j in range(4):
-                            X02[:, L.f[c][j] + 2:L.f[c][j] + 3 * N:3] = GRAVITY / 8.0
-                    X2, I2 = self.solver2.solve_device(P2, X02)
-                    I2[:, 0] += dInfo.index_select(0, idx)[:, 0]     # iterations of both attempts
-                    I2[:, 3] += 10000.0                              # safeguard word: solved again from the cold start
-                    dX.index_copy_(0, chunk, X2[:chunk.numel()])
-                    dInfo.index_copy_(0, chunk, I2[:chunk.numel()])
-            s.contacts_adjust_device(now, dX, land, lists)
-            mpc_prev = lists
-            state, zmp = s.plant_step_device(dX, dP, state, step=dt / self.substeps, substeps=self.substeps)
+                ok, lists, land, nretry, state, zmp = self._tick_by_steps(i, now, mpc_prev, warm, dump, dP, dX0, dX, dInfo, state, wrench, dpush, push_ticks, ref_x0, ref_x)
+                mpc_prev = lists
             torch.cuda.synchronize()
             tick_ms = (time.perf_counter() - t_tick) * 1e3
             if not bool(ok.cpu().numpy().all()):
@@ -198,7 +229,7 @@ class WalkingRollout:
             rec["converged"].append(bool((info[:, 5] == 0).all()))
             rec.setdefault("failed_info", []).append(info[info[:, 5] != 0])
             rec["merge_ok"].append(True)
-            rec["solve_ms"].append(s.last_solve_ms())
+            rec["solve_ms"].append(s.last_solve_ms() if timing else float("nan"))
             if record != "full":
                 continue
             rec["com"].append(state[:, 0:3].cpu().numpy())
@@ -216,5 +247,6 @@ class WalkingRollout:
                         d = Xh[b, L.pos[c] + 3 * k:L.pos[c] + 3 * k + 3] - Ph[b, L.p_nom[c] + 3 * k:L.p_nom[c] + 3 * k + 3]
                         off[b, c] = R.T @ d
             rec["landing_offset"].append(off)
+        s.set_timing(True)
         rec["box_upper"], rec["box_lower"] = box_up, box_lo
         return rec

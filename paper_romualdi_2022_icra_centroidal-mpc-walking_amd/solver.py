@@ -236,6 +236,22 @@ class BatchSolver:
         self._launch(dP.device, lambda st: self._lib.cmpc_write_state_device(
             self._h, dState.data_ptr(), dWrench.data_ptr() if dWrench is not None else None, dP.data_ptr(), st))
 
+    def rollout_tick_device(self, now, plan, prev, lists, ok, land, dState, dWrench, dP, dX0, dX, dInfo, dStateOut, dZmp, warm,
+                            step=0.01, substeps=6, zmp_half_x=0.08, zmp_half_y=0.03):
+        """cmpc_rollout_tick_device: merge -> sample -> setState -> shift -> solve -> step adjustment -> plant as ONE call (include/cmpc.h); plan / prev /
+        lists = (t, pose, n) CUDA tensors, prev None on the first tick (lists is then taken as filled by the caller); dWrench may be None."""
+        from ._capi import CmpcTickIO
+        if getattr(self, "_box", None) is None:
+            self._box = (np.ascontiguousarray([c.bounding_box_upper_limit for c in self.cfg.contacts], np.float32),
+                         np.ascontiguousarray([c.bounding_box_lower_limit for c in self.cfg.contacts], np.float32))
+        ptr = lambda a: a.data_ptr() if a is not None else None
+        io = CmpcTickIO(ptr(plan[0]), ptr(plan[1]), ptr(plan[2]),
+                        *(tuple(ptr(a) for a in prev) if prev is not None else (None, None, None)),
+                        ptr(lists[0]), ptr(lists[1]), ptr(lists[2]), ptr(ok), ptr(land), self._box[0].ctypes.data, self._box[1].ctypes.data,
+                        ptr(dState), ptr(dWrench), ptr(dP), ptr(dX0), ptr(dX), ptr(dInfo), ptr(dStateOut), ptr(dZmp),
+                        float(step), int(substeps), float(zmp_half_x), float(zmp_half_y))
+        self._launch(dP.device, lambda st: self._lib.cmpc_rollout_tick_device(self._h, lists[0].shape[2], float(now), 1 if warm else 0, io, st))
+
     def shift_solution_device(self, dXprev, dX0):
         """is_warm_start_enabled: dX0 = dXprev shifted by one knot; solve from it with solve_device(..., warm=True)."""
         self._launch(dX0.device, lambda st: self._lib.cmpc_shift_solution_device(self._h, dXprev.data_ptr(), dX0.data_ptr(), st))

@@ -175,3 +175,45 @@ def test_warm_policy_budget_restart_and_launch_level_retry():
     ro2 = cm.rollout.WalkingRollout(cfg, B, warm_budget=3, retry=None)
     rec2 = ro2.run(3, com0, z, z, record="light")
     assert sum(rec2["unconverged"]) > 0 and not all(rec2["converged"])
+
+
+def test_native_tick_is_the_seven_entry_points_chained_bit_for_bit():
+    """cmpc_rollout_tick_device (one call per tick) against the same tick as seven calls of the C ABI: the same kernels in the same order on the same
+    buffers, so every record of the roll-out -- CoM, ZMP, landing knots, landing offsets, iteration counts -- is identical to the last bit, across the
+    push, a lift-off and a landing."""
+    cfg = cm.config.ergocub_gazebo_v1(20, 0.06)
+    B, ticks = 24, 18
+    rng = np.random.default_rng(11)
+    com0 = np.array([0.0, 0.0, 0.7]) + rng.uniform(-0.01, 0.01, (B, 3))
+    dcom0 = rng.uniform(-0.05, 0.05, (B, 3))
+    h0 = rng.uniform(-0.02, 0.02, (B, 3))
+    push = np.zeros((B, 3))
+    push[:, :2] = rng.uniform(-20.0, 20.0, (B, 2)) / cm.synthetic.ROBOT_MASS
+    recs = []
+    for native in (True, False):
+        ro = cm.rollout.WalkingRollout(cfg, B, native_tick=native)
+        assert ro.native_tick == native
+        recs.append(ro.run(ticks, com0, dcom0, h0, push=push, push_ticks=3))
+    a, b = recs
+    assert all(a["converged"]) and all(a["merge_ok"]) and len(a["com"]) == ticks
+    for key in ("com", "zmp", "land", "landing_offset"):
+        assert np.array_equal(np.stack(a[key]), np.stack(b[key])), key
+    assert a["iterations_max"] == b["iterations_max"] and a["iterations_mean"] == b["iterations_mean"]
+    lands = np.stack(a["land"])
+    assert len(np.unique(lands)) > 3                        # the window crossed swing and double-support phases: the landing knots moved through the horizon
+
+
+def test_native_tick_rejects_aliased_lists_and_null_buffers():
+    import ctypes
+    import torch
+    CmpcTickIO = cm._capi.CmpcTickIO
+    cfg = cm.config.ergocub_gazebo_v1(20, 0.06)
+    s = cm.BatchSolver(cfg, 4)
+    io = CmpcTickIO()
+    assert s._lib.cmpc_rollout_tick_device(s._h, 3, 0.0, 1, ctypes.byref(io), None) != 0 and "dLand" in s.last_error
+    t = torch.zeros((4, 2, 3, 2), dtype=torch.float64, device="cuda")
+    scratch = torch.zeros((4, 8), dtype=torch.float32, device="cuda")
+    io.dLand = io.dInfo = scratch.data_ptr()
+    io.dPrevT = io.dListT = t.data_ptr()
+    assert s._lib.cmpc_rollout_tick_device(s._h, 3, 0.0, 1, ctypes.byref(io), None) != 0 and "alias" in s.last_error
+    assert s._lib.cmpc_rollout_tick_device(s._h, 3, 0.0, 1, None, None) != 0

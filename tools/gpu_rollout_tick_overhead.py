@@ -22,3 +22,6 @@ for B in (1, 16, 256, 2048):
     print(f"B={B:5d} ticks={ticks} converged {all(rec['converged'])} | tick ms p50 {np.median(tick):.3f} p99 {np.percentile(tick, 99):.3f} | solve kernel ms p50 "
           f"{np.median(solve):.3f} | tick - solve p50 {np.median(gap):.3f} ms ({100 * np.median(gap) / np.median(tick):.1f} % of the tick) | iterations mean "
           f"{np.mean(rec['iterations_mean']):.2f}", flush=True)
+    rec = ro.run(ticks, com0, dcom0, h0, push=push, push_ticks=3, record="light", timing=False)
+    tick = np.array(rec["tick_ms"][1:])
+    print(f"        without the library's event pair around the solve: tick ms p50 {np.median(tick):.3f} p99 {np.percentile(tick, 99):.3f}", flush=True)
