@@ -63,6 +63,11 @@ struct cmpc_handle_s {
     long long scratch_stride = 0;
     std::vector<float> hP, hX0;  // host staging for the class-shaped setters
     bool have_solution = false, x0_set = false;
+    // pinned host mirror of the handle's solution and status words, filled by cmpc_advance in the same synchronisation as the solve (the class surface's
+    // getOutput / cmpc_get_solution then cost no GPU call: a pageable device-to-host copy of their own was 25 us of a 0.83 ms tick at B = 1)
+    float* hXpin = nullptr;
+    float* hInfoPin = nullptr;
+    bool hX_valid = false;
     bool warm = false;           // class path only (cmpc_set_initial_guess(.., 1) -> cmpc_advance): the handle's own dX0 is a shifted previous solution
     double mu_warm = 1e-2, floor_warm = 1e-2;  // measured: 1e-2 saves 35 % (standing) / 15 % (walking) of the iterations; 1e-4 can stall
     int warm_budget = 14, warm_no_restart = 0;  // cmpc_set_warm_policy (CmpcParams); 14: measured on the walking roll-out (profiles/r03_walking_rollout.txt)
@@ -243,6 +248,8 @@ int cmpc_destroy(cmpc_handle h)
     if (!h) return CMPC_OK;
     hipSetDevice(h->device);
     if (h->stream) hipStreamSynchronize(h->stream);
+    if (h->hXpin) hipHostFree(h->hXpin);
+    if (h->hInfoPin) hipHostFree(h->hInfoPin);
     hipFree(h->dP); hipFree(h->dX0); hipFree(h->dX); hipFree(h->dInfo); hipFree(h->dConsts); hipFree(h->dScratch); hipFree(h->dBox); hipFree(h->dDuals);
     if (h->ev0) hipEventDestroy(h->ev0);
     if (h->ev1) hipEventDestroy(h->ev1);
@@ -418,6 +425,7 @@ int cmpc_solve(cmpc_handle h, const float* P, const float* X0, float* X, float* 
     const size_t nP = (size_t)h->B * h->L.np, nX = (size_t)h->B * h->L.nx;
     HIPCHK(h, hipMemcpyAsync(h->dP, P, sizeof(float) * nP, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemcpyAsync(h->dX0, X0, sizeof(float) * nX, hipMemcpyHostToDevice, h->stream));
+    h->hX_valid = false;   // (dX is about to change behind the pinned mirror of cmpc_advance)
     rc = cmpc_solve_device(h, h->dP, h->dX0, h->dX, h->dInfo, nullptr);
     if (rc) return rc;
     std::vector<float> hinfo((size_t)h->B * CMPC_INFO_N);
@@ -558,11 +566,17 @@ int cmpc_advance(cmpc_handle h)
         h->timed = h->timing;
         h->warm = false;
     }
-    std::vector<float> hinfo((size_t)h->B * CMPC_INFO_N);
-    HIPCHK(h, hipMemcpyAsync(hinfo.data(), h->dInfo, sizeof(float) * hinfo.size(), hipMemcpyDeviceToHost, h->stream));
+    const size_t nXo = (size_t)h->B * h->L.nx, nIo = (size_t)h->B * CMPC_INFO_N;
+    h->hX_valid = false;
+    if (!h->hXpin) HIPCHK(h, hipHostMalloc((void**)&h->hXpin, sizeof(float) * nXo, hipHostMallocDefault));
+    if (!h->hInfoPin) HIPCHK(h, hipHostMalloc((void**)&h->hInfoPin, sizeof(float) * nIo, hipHostMallocDefault));
+    HIPCHK(h, hipMemcpyAsync(h->hXpin, h->dX, sizeof(float) * nXo, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->hInfoPin, h->dInfo, sizeof(float) * nIo, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     h->have_solution = true;
+    h->hX_valid = true;
     h->x0_set = false;  // the next tick picks its own start unless told otherwise
+    const std::vector<float> hinfo(h->hInfoPin, h->hInfoPin + nIo);
     return check_status(h, hinfo);
 }
 
@@ -590,6 +604,11 @@ int cmpc_get_parameters_device(cmpc_handle h, const float** dP)
 int cmpc_get_solution(cmpc_handle h, float* X, float* info)
 {
     if (!h || !h->have_solution) return fail(h, CMPC_ERR_ARG, "cmpc_get_solution: no solution yet");
+    if (h->hX_valid) {   // (the last writer of dX was cmpc_advance: its pinned mirror is the solution)
+        if (X) std::memcpy(X, h->hXpin, sizeof(float) * (size_t)h->B * h->L.nx);
+        if (info) std::memcpy(info, h->hInfoPin, sizeof(float) * (size_t)h->B * CMPC_INFO_N);
+        return CMPC_OK;
+    }
     HIPCHK(h, hipSetDevice(h->device));
     if (X) HIPCHK(h, hipMemcpyAsync(X, h->dX, sizeof(float) * (size_t)h->B * h->L.nx, hipMemcpyDeviceToHost, h->stream));
     if (info) HIPCHK(h, hipMemcpyAsync(info, h->dInfo, sizeof(float) * (size_t)h->B * CMPC_INFO_N, hipMemcpyDeviceToHost, h->stream));
@@ -600,12 +619,17 @@ int cmpc_get_solution(cmpc_handle h, float* X, float* info)
 int cmpc_get_output(cmpc_handle h, float* forces0, float* pos0, float* next_pos, int* next_knot)
 {
     if (!h || !h->have_solution) return fail(h, CMPC_ERR_ARG, "cmpc_get_output: no solution yet");
-    std::vector<float> X((size_t)h->B * h->L.nx);
-    int rc = cmpc_get_solution(h, X.data(), nullptr);
-    if (rc) return rc;
+    std::vector<float> Xcopy;
+    const float* Xh = h->hXpin;
+    if (!h->hX_valid) {
+        Xcopy.resize((size_t)h->B * h->L.nx);
+        int rc = cmpc_get_solution(h, Xcopy.data(), nullptr);
+        if (rc) return rc;
+        Xh = Xcopy.data();
+    }
     const int N = h->cfg.horizon;
     for (int b = 0; b < h->B; ++b) {
-        const float* x = X.data() + (size_t)b * h->L.nx;
+        const float* x = Xh + (size_t)b * h->L.nx;
         const float* p = h->hP.data() + (size_t)b * h->L.np;
         for (int ct = 0; ct < 2; ++ct) {
             for (int j = 0; j < 4; ++j)
