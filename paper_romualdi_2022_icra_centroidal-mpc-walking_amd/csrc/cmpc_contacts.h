@@ -79,29 +79,43 @@ __host__ __device__ inline void cmpc_quat_to_R(const float* q /* w x y z */, flo
 // in the air at the end of the horizon, -1 if it never leaves the ground).  Rule (contacts.py): stage k starts at
 // now + k dt; Gamma_k = 1 iff a contact is active then; R_k, the limits of row k and nominal_{k+1} come from the
 // stage's owner; nominal_0 and currentPos from the owner of stage 0.
-__host__ __device__ inline int cmpc_sample_foot(int N, double dt, double now, int c, const double* t, const float* pose, int n,
-                                                const float* box_upper, const float* box_lower, float* p)
+// stage k of foot c (the body of cmpc_sample_foot's loop): writes the stage's entries of p, returns whether the foot is in contact at the stage's start
+__host__ __device__ inline bool cmpc_sample_stage(int N, double dt, double now, int c, int k, const double* t, const float* pose, int n,
+                                                  const float* box_upper, const float* box_lower, float* p)
 {
     const CmpcIdx L{N};
+    bool act;
+    const int o = cmpc_stage_owner(t, n, now + k * dt, &act);
+    float R[9];
+    cmpc_quat_to_R(pose + 7 * o + 3, R);
+    for (int r = 0; r < 3; ++r)
+        for (int cc = 0; cc < 3; ++cc) p[L.pR(c) + 9 * k + 3 * cc + r] = R[3 * r + cc];   // vec(R) column-major
+    p[L.pGam(c) + k] = act ? 1.f : 0.f;
+    for (int i = 0; i < 3; ++i) {
+        p[L.pUp(c) + 3 * k + i] = box_upper[3 * c + i];
+        p[L.pLo(c) + 3 * k + i] = box_lower[3 * c + i];
+        p[L.pNom(c) + 3 * (k + 1) + i] = pose[7 * o + i];
+        if (k == 0) { p[L.pNom(c) + i] = pose[7 * o + i]; p[L.pCur(c) + i] = pose[7 * o + i]; }
+    }
+    return act;
+}
+// the landing knot from the stages' contact flags (first knot in contact after a swing stage, N if still in the air at the end, -1 if the foot never lifts);
+// act(k) is called once per stage, in order
+template <class ActOf>
+__host__ __device__ inline int cmpc_landing_knot(int N, ActOf act)
+{
     int land = -1;
     bool prev_act = true;
     for (int k = 0; k < N; ++k) {
-        bool act;
-        const int o = cmpc_stage_owner(t, n, now + k * dt, &act);
-        float R[9];
-        cmpc_quat_to_R(pose + 7 * o + 3, R);
-        for (int r = 0; r < 3; ++r)
-            for (int cc = 0; cc < 3; ++cc) p[L.pR(c) + 9 * k + 3 * cc + r] = R[3 * r + cc];   // vec(R) column-major
-        p[L.pGam(c) + k] = act ? 1.f : 0.f;
-        for (int i = 0; i < 3; ++i) {
-            p[L.pUp(c) + 3 * k + i] = box_upper[3 * c + i];
-            p[L.pLo(c) + 3 * k + i] = box_lower[3 * c + i];
-            p[L.pNom(c) + 3 * (k + 1) + i] = pose[7 * o + i];
-            if (k == 0) { p[L.pNom(c) + i] = pose[7 * o + i]; p[L.pCur(c) + i] = pose[7 * o + i]; }
-        }
-        if (act && !prev_act && land < 0) land = k;
-        prev_act = act;
+        const bool a = act(k);
+        if (a && !prev_act && land < 0) land = k;
+        prev_act = a;
     }
     if (!prev_act && land < 0) land = N;
     return land;
+}
+__host__ __device__ inline int cmpc_sample_foot(int N, double dt, double now, int c, const double* t, const float* pose, int n,
+                                                const float* box_upper, const float* box_lower, float* p)
+{
+    return cmpc_landing_knot(N, [&](int k) { return cmpc_sample_stage(N, dt, now, c, k, t, pose, n, box_upper, box_lower, p); });
 }

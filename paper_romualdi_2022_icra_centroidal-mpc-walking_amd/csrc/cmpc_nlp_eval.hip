@@ -738,8 +738,8 @@ __global__ __launch_bounds__(256) void cmpc_plant_step_kernel(int N, int B, floa
 // front of the solve touch disjoint entries of P and X0 (contact blocks / state rows / the shifted solution) and so do the two behind it (the lists' poses /
 // the state), so each group is one grid whose threads call the SAME per-problem functions as the single kernels -- results identical to the last bit
 // (tests/test_gpu_rollout.py).
-// pre: one workgroup per problem.  Threads 0, 1: merge (updateContactPhaseList) and sampling (setContactPhaseList) of foot 0 / 1 -- the sampling reads the
-// list its own thread just merged --; all threads: setState and the warm-start shift.
+// pre: one workgroup per problem.  All threads: setState and the warm-start shift; threads 0, 1: merge (updateContactPhaseList) of foot 0 / 1; then one thread per
+// (foot, stage): sampling (setContactPhaseList) of the merged lists; threads 0, 1: the landing knots.
 __global__ __launch_bounds__(256) void cmpc_tick_pre_kernel(int B, int N, int M, double dt, double now, int merge, const double* plan_t, const float* plan_pose,
                                                             const int* plan_n, const double* prev_t, const float* prev_pose, const int* prev_n, double* list_t,
                                                             float* list_pose, int* list_n, int* ok, int* land, const float* __restrict__ box,
@@ -752,6 +752,15 @@ __global__ __launch_bounds__(256) void cmpc_tick_pre_kernel(int B, int N, int M,
     __shared__ int okw;
     if (tid == 0) okw = 1;
     __syncthreads();
+    // setState and the warm-start shift first (they depend on nothing the kernel computes: their memory traffic runs under the merge of threads 0, 1)
+    for (int e = tid; e < 9; e += 256) p[L.pCom0() + e] = state[9 * (size_t)b + e];
+    if (wrench)
+        for (int e = tid; e < 3 * N; e += 256) {
+            const int k = e / 3, i = e % 3;
+            p[L.pFext() + e] = wrench[((size_t)b * N + k) * 6 + i];
+            p[L.pText() + e] = wrench[((size_t)b * N + k) * 6 + 3 + i];
+        }
+    if (Xprev) warm_shift_problem(N, Xprev + (size_t)b * L.nx(), X0 + (size_t)b * L.nx(), tid, 256);
     if (tid < 2) {
         const int e = 2 * b + tid;
         const size_t o = (size_t)e * M;
@@ -762,19 +771,22 @@ __global__ __launch_bounds__(256) void cmpc_tick_pre_kernel(int B, int N, int M,
                                                       list_t + 2 * o, list_pose + 7 * o, list_n + e);
             if (!good) atomicAnd(&okw, 0);
         }
-        const int n = list_n[e];
-        if (n < 1 || n > M) land[e] = -2;
-        else land[e] = cmpc_sample_foot(N, dt, now, tid, list_t + 2 * o, list_pose + 7 * o, n, box, box + 6, p);
     }
-    for (int e = tid; e < 9; e += 256) p[L.pCom0() + e] = state[9 * (size_t)b + e];
-    if (wrench)
-        for (int e = tid; e < 3 * N; e += 256) {
-            const int k = e / 3, i = e % 3;
-            p[L.pFext() + e] = wrench[((size_t)b * N + k) * 6 + i];
-            p[L.pText() + e] = wrench[((size_t)b * N + k) * 6 + 3 + i];
-        }
-    if (Xprev) warm_shift_problem(N, Xprev + (size_t)b * L.nx(), X0 + (size_t)b * L.nx(), tid, 256);
+    __syncthreads();   // (the merged lists of the two feet are in global memory, visible to the workgroup)
+    // sampling: one thread per (foot, stage) -- a single thread walking the N stages of a foot one global-memory round trip at a time was 33 of this kernel's
+    // 39 us (rocprofv3, profiles/r04_rollout_tick_overhead.txt); the landing knot then comes from the stages' contact flags in LDS
+    __shared__ unsigned char acts[2][CMPC_NMAX];
+    for (int e2 = tid; e2 < 2 * N; e2 += 256) {
+        const int cft = e2 / N, k = e2 - cft * N, e = 2 * b + cft;
+        const size_t o = (size_t)e * M;
+        const int n = list_n[e];
+        if (n >= 1 && n <= M) acts[cft][k] = cmpc_sample_stage(N, dt, now, cft, k, list_t + 2 * o, list_pose + 7 * o, n, box, box + 6, p) ? 1 : 0;
+    }
     __syncthreads();
+    if (tid < 2) {
+        const int e = 2 * b + tid, n = list_n[e];
+        land[e] = (n < 1 || n > M) ? -2 : cmpc_landing_knot(N, [&](int k) { return acts[tid][k] != 0; });
+    }
     if (merge && ok && tid == 0) ok[b] = okw;
 }
 
