@@ -690,14 +690,21 @@ __device__ inline void plant_step_problem(int N, int b, float grav, const float*
             zw[1] += F[2] * ((double)x[L.oPos(c) + 1] + (double)R[1] * lx + (double)R[4] * ly);
         }
     }
+    // The forces are held over the step, so the torque about the CoM, sum_q (p_q - c) x f_q, is tau0 - c x fsum with tau0 = sum_q p_q x f_q formed once: one cross
+    // product per Runge-Kutta stage instead of eight (this one-thread-per-problem kernel is a dependent chain of float64 operations: 18 us of a tick before,
+    // profiles/r04_rollout_tick_overhead.txt).
+    double tau0[3] = {ext_t[0], ext_t[1], ext_t[2]}, acc[3];
+    for (int q = 0; q < 8; ++q) {
+        tau0[0] += cp[q][1] * cf[q][2] - cp[q][2] * cf[q][1];
+        tau0[1] += cp[q][2] * cf[q][0] - cp[q][0] * cf[q][2];
+        tau0[2] += cp[q][0] * cf[q][1] - cp[q][1] * cf[q][0];
+    }
+    for (int i = 0; i < 3; ++i) acc[i] = fsum[i] + (double)p[L.pFext() + i] - (i == 2 ? (double)grav : 0.0);
     auto deriv = [&](const double* cm, const double* vv, double* dcm, double* dv, double* dh) {
-        for (int i = 0; i < 3; ++i) { dcm[i] = vv[i]; dv[i] = fsum[i] + (double)p[L.pFext() + i] - (i == 2 ? (double)grav : 0.0); dh[i] = ext_t[i]; }
-        for (int q = 0; q < 8; ++q) {
-            const double r0 = cp[q][0] - cm[0], r1 = cp[q][1] - cm[1], r2 = cp[q][2] - cm[2];
-            dh[0] += r1 * cf[q][2] - r2 * cf[q][1];
-            dh[1] += r2 * cf[q][0] - r0 * cf[q][2];
-            dh[2] += r0 * cf[q][1] - r1 * cf[q][0];
-        }
+        for (int i = 0; i < 3; ++i) { dcm[i] = vv[i]; dv[i] = acc[i]; }
+        dh[0] = tau0[0] - (cm[1] * fsum[2] - cm[2] * fsum[1]);
+        dh[1] = tau0[1] - (cm[2] * fsum[0] - cm[0] * fsum[2]);
+        dh[2] = tau0[2] - (cm[0] * fsum[1] - cm[1] * fsum[0]);
     };
     for (int s = 0; s < nsub; ++s) {
         double k1c[3], k1v[3], k1h[3], k2c[3], k2v[3], k2h[3], k3c[3], k3v[3], k3h[3], k4c[3], k4v[3], k4h[3], tc[3], tv[3];
