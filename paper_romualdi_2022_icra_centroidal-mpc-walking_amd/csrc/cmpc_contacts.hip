@@ -29,25 +29,30 @@ __global__ __launch_bounds__(128) void cmpc_fill_int_kernel(int n, int v, int* _
     if (e < n) dst[e] = v;
 }
 
-__global__ __launch_bounds__(128) void cmpc_contacts_sample_kernel(int B, int N, int M, double dt, double now, const double* __restrict__ t,
-                                                                   const float* __restrict__ pose, const int* __restrict__ n,
-                                                                   const float* __restrict__ box /* upper[6] | lower[6] */,
-                                                                   float* __restrict__ P, int* __restrict__ land)
+// one workgroup (one wave) per problem, one thread per (foot, stage); the landing knots from the stages' contact flags in LDS.  (One thread per foot walking its N
+// stages through global-memory latency took 33 us per launch whatever the batch: profiles/r04_rollout_tick_overhead.txt.)
+__global__ __launch_bounds__(64) void cmpc_contacts_sample_kernel(int B, int N, int M, double dt, double now, const double* __restrict__ t,
+                                                                  const float* __restrict__ pose, const int* __restrict__ n,
+                                                                  const float* __restrict__ box /* upper[6] | lower[6] */,
+                                                                  float* __restrict__ P, int* __restrict__ land)
 {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= 2 * B) return;
-    const int b = e >> 1, c = e & 1;
+    const int b = blockIdx.x, tid = threadIdx.x;
     const CmpcIdx L{N};
-    const size_t o = (size_t)e * M;
+    __shared__ unsigned char acts[2][CMPC_NMAX];
     // An empty list (cmpc_merge_foot leaves one where the reference's updateContactPhaseList returns false, CentroidalMPCBlock.cpp:70-77,
     // and the reference then aborts the tick, :603-607) or a length beyond M has no owner to sample: the foot's blocks of P are left
     // as they are and the landing knot reads -2 (the host entry point returns CMPC_ERR_ARG for the same input).
-    if (n[e] < 1 || n[e] > M) {
-        if (land) land[e] = -2;
-        return;
+    for (int e2 = tid; e2 < 2 * N; e2 += 64) {
+        const int c = e2 / N, k = e2 - c * N, e = 2 * b + c;
+        const size_t o = (size_t)e * M;
+        if (n[e] >= 1 && n[e] <= M)
+            acts[c][k] = cmpc_sample_stage(N, dt, now, c, k, t + 2 * o, pose + 7 * o, n[e], box, box + 6, P + (size_t)b * L.np()) ? 1 : 0;
     }
-    const int lk = cmpc_sample_foot(N, dt, now, c, t + 2 * o, pose + 7 * o, n[e], box, box + 6, P + (size_t)b * L.np());
-    if (land) land[e] = lk;
+    __syncthreads();
+    if (tid < 2 && land) {
+        const int e = 2 * b + tid;
+        land[e] = (n[e] < 1 || n[e] > M) ? -2 : cmpc_landing_knot(N, [&](int k) { return acts[tid][k] != 0; });
+    }
 }
 
 // step adjustment: the next contact of every foot that lands inside the horizon takes the optimised landing position
@@ -99,7 +104,7 @@ extern "C" int cmpc_launch_contacts_merge(int B, int M, double now, const double
 extern "C" int cmpc_launch_contacts_sample(int B, int N, int M, double dt, double now, const double* t, const float* pose, const int* n,
                                            const float* box, float* P, int* land, hipStream_t stream)
 {
-    hipLaunchKernelGGL(cmpc_contacts_sample_kernel, dim3((2 * B + 127) / 128), dim3(128), 0, stream, B, N, M, dt, now, t, pose, n, box, P, land);
+    hipLaunchKernelGGL(cmpc_contacts_sample_kernel, dim3(B), dim3(64), 0, stream, B, N, M, dt, now, t, pose, n, box, P, land);
     return (int)hipGetLastError();
 }
 
