@@ -191,6 +191,10 @@ int cmpc_get_output(cmpc_handle h, float* forces0, float* pos0, float* next_pos,
  * by linear interpolation; the CoM height is replaced by com_height unless it is NaN (the reference forces 0.7, :534). */
 int cmpc_set_reference_from_planner(cmpc_handle h, const float* com_in, const float* h_in, int n_in, double in_dt,
                                     double t_offset, double robot_mass, double com_height);
+/* the same on the device (one thread per problem and knot), into the reference rows of the caller's dP[B][n_p]; dComIn / dHIn [B][n_in][3] device pointers;
+ * asynchronous on `stream` (NULL: the handle's) */
+int cmpc_write_reference_from_planner_device(cmpc_handle h, const float* dComIn, const float* dHIn, int n_in, double in_dt, double t_offset,
+                                             double robot_mass, double com_height, float* dP, void* stream);
 /* 8f-4, WholeBodyQPBlock.cpp:805-873, 1083-1084, 1150, 1259-1262: between two MPC ticks the plant integrates the
  * centroidal dynamics under the first-knot corner forces of the active contacts + the external wrench of knot 0 (RK4,
  * `substeps` steps of `step` seconds, forces held) and reports the desired ZMP (local ZMP clamped to +-zmp_half_x/y:
@@ -270,7 +274,7 @@ int cmpc_write_state_device(cmpc_handle h, const float* dState, const float* dWr
  * Every step is what the entry point of that name computes, with the same argument checks; the steps in front of the solve are ONE launch and so are the
  * two behind it (they touch disjoint entries; same per-problem device functions: results identical to the last bit), so that a tick is three dispatches instead of ten.  It saves the
  * caller six trips through its FFI and the idle GPU time between them (a seventh of a tick at B <= 256,
- * tools/gpu_rollout_tick_overhead.py).  The reference rows of dP (comRef, hRef) are the caller's: write them before the call.
+ * tools/gpu_rollout_tick_overhead.py).  The reference rows of dP (comRef, hRef) are the caller's -- write them before the call -- unless dPlanCom / dPlanH are given.
  * All pointers are device pointers except box_upper / box_lower (host, [2][3]). */
 typedef struct cmpc_tick_io {
     const double* dPlanT; const float* dPlanPose; const int* dPlanN; /* the planner's lists (layout above) */
@@ -290,6 +294,10 @@ typedef struct cmpc_tick_io {
     float* dStateOut;       /* [B][9] state at the next tick (may alias dState) */
     float* dZmp;            /* [B][2] or NULL */
     double plant_step; int plant_substeps; double zmp_half_x, zmp_half_y; /* as cmpc_plant_step_device */
+    /* optional: the planner's CoM / angular-momentum trajectories (cmpc_write_reference_from_planner_device: [B][plan_knots][3] each, a knot every plan_dt seconds,
+     * the first one plan_t_offset seconds before `now`) -- the tick then writes comRef / hRef of dP itself (setReferenceTrajectory, CentroidalMPCBlock.cpp:525-579).
+     * Both NULL: the reference rows of dP are the caller's. */
+    const float* dPlanCom; const float* dPlanH; int plan_knots; double plan_dt, plan_t_offset, robot_mass, com_height;
 } cmpc_tick_io;
 int cmpc_rollout_tick_device(cmpc_handle h, int max_contacts, double now, int warm, const cmpc_tick_io* io, void* stream);
 /* is_warm_start_enabled on the device: dX0 = dXprev shifted by one knot; solve from it with cmpc_solve_device_warm

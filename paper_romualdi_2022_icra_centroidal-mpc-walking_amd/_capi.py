@@ -42,7 +42,9 @@ class CmpcTickIO(C.Structure):
     _fields_ = [(k, C.c_void_p) for k in (
         "dPlanT", "dPlanPose", "dPlanN", "dPrevT", "dPrevPose", "dPrevN", "dListT", "dListPose", "dListN", "dOk", "dLand",
         "box_upper", "box_lower", "dState", "dWrench", "dP", "dX0", "dX", "dInfo", "dStateOut", "dZmp")] + [
-        ("plant_step", C.c_double), ("plant_substeps", C.c_int), ("zmp_half_x", C.c_double), ("zmp_half_y", C.c_double)]
+        ("plant_step", C.c_double), ("plant_substeps", C.c_int), ("zmp_half_x", C.c_double), ("zmp_half_y", C.c_double),
+        ("dPlanCom", C.c_void_p), ("dPlanH", C.c_void_p), ("plan_knots", C.c_int), ("plan_dt", C.c_double), ("plan_t_offset", C.c_double),
+        ("robot_mass", C.c_double), ("com_height", C.c_double)]
 
 
 FACTORS = {None: 0, "auto": 0, "lds": 1, "hbm": 2}   # cmpc_config.factor_storage
@@ -58,7 +60,7 @@ EXPORTS = [
     "cmpc_contacts_sample_device", "cmpc_set_contact_lists", "cmpc_contacts_adjust", "cmpc_contacts_adjust_device",
     "cmpc_write_state_device", "cmpc_shift_solution_device", "cmpc_eval_nlp_grad_device", "cmpc_solve_device_warm", "cmpc_set_warm_policy",
     "cmpc_get_parameters", "cmpc_get_parameters_device", "cmpc_allgather_compact_device", "cmpc_sq_pass_barriers",
-    "cmpc_rollout_tick_device",
+    "cmpc_rollout_tick_device", "cmpc_write_reference_from_planner_device",
 ]
 
 _lib = None
@@ -130,5 +132,7 @@ def lib():
             L.cmpc_sq_pass_barriers.argtypes = [C.c_int, C.c_int, C.c_int]
         if hasattr(L, "cmpc_rollout_tick_device"):
             L.cmpc_rollout_tick_device.argtypes = [vp, i, d, i, C.POINTER(CmpcTickIO), vp]
+        if hasattr(L, "cmpc_write_reference_from_planner_device"):
+            L.cmpc_write_reference_from_planner_device.argtypes = [vp, fp, fp, i, d, d, d, d, fp, vp]
         _lib = L
     return _lib

@@ -30,10 +30,13 @@ extern "C" int cmpc_launch_contacts_adjust(int B, int N, int M, double now, cons
                                            const int* n, hipStream_t stream);
 extern "C" int cmpc_launch_write_state(int B, int N, const float* state, const float* wrench, float* P, hipStream_t stream);
 extern "C" int cmpc_launch_compact(int N, int B, const float* dX, const float* dInfo, float* dOut, hipStream_t stream);
+extern "C" int cmpc_launch_reference_from_planner(int B, int N, int n_in, double dt, double in_dt, double t_offset, double robot_mass, double com_height,
+                                                  const float* com_in, const float* h_in, float* P, hipStream_t stream);
 extern "C" int cmpc_launch_tick_pre(int B, int N, int M, double dt, double now, int merge, const double* plan_t, const float* plan_pose, const int* plan_n,
                                     const double* prev_t, const float* prev_pose, const int* prev_n, double* list_t, float* list_pose, int* list_n, int* ok,
                                     int* land, const float* box, const float* state, const float* wrench, float* P, const float* Xprev, float* X0,
-                                    hipStream_t stream);
+                                    const float* plan_com, const float* plan_h, int plan_knots, double plan_dt, double plan_t_offset, double robot_mass,
+                                    double com_height, hipStream_t stream);
 extern "C" int cmpc_launch_tick_post(int B, int N, int M, double now, float grav, const float* dCorners, const float* dX, const float* dP,
                                      const float* dStateIn, float* dStateOut, float* dZmp, float h, int nsub, float zx, float zy, const int* land,
                                      const double* t, float* pose, const int* n, hipStream_t stream);
@@ -688,21 +691,23 @@ int cmpc_set_reference_from_planner(cmpc_handle h, const float* com_in, const fl
         float* p = h->hP.data() + (size_t)b * h->L.np;
         const float* ci = com_in + (size_t)b * n_in * 3;
         const float* hi = h_in + (size_t)b * n_in * 3;
-        for (int k = 0; k <= N; ++k) {
-            double s = (t_offset + k * h->cfg.sampling_time) / in_dt;
-            if (s < 0) s = 0;
-            if (s > n_in - 1) s = n_in - 1;
-            int i0 = (int)s;
-            if (i0 > n_in - 2) i0 = n_in - 2;
-            const double w = s - i0;
-            for (int a = 0; a < 3; ++a) {
-                double cv = (1 - w) * ci[3 * i0 + a] + w * ci[3 * (i0 + 1) + a];
-                if (a == 2 && com_height == com_height) cv = com_height;  // the reference forces 0.7 (:534); NaN keeps the planner's
-                p[h->L.p_comref + 3 * k + a] = (float)cv;
-                p[h->L.p_href + 3 * k + a] = (float)(((1 - w) * hi[3 * i0 + a] + w * hi[3 * (i0 + 1) + a]) / robot_mass);
-            }
-        }
+        for (int k = 0; k <= N; ++k)
+            cmpc_resample_reference_knot(ci, hi, n_in, in_dt, t_offset, h->cfg.sampling_time, k, robot_mass, com_height, p + h->L.p_comref + 3 * k,
+                                         p + h->L.p_href + 3 * k);
     }
+    return CMPC_OK;
+}
+
+// the same on the device, into the caller's dP (one thread per problem and knot)
+int cmpc_write_reference_from_planner_device(cmpc_handle h, const float* dComIn, const float* dHIn, int n_in, double in_dt, double t_offset, double robot_mass,
+                                             double com_height, float* dP, void* stream)
+{
+    if (!h || !dComIn || !dHIn || !dP || n_in < 2 || !(in_dt > 0) || !(robot_mass > 0))
+        return fail(h, CMPC_ERR_ARG, "cmpc_write_reference_from_planner_device: bad argument");
+    HIPCHK(h, hipSetDevice(h->device));
+    int rc = cmpc_launch_reference_from_planner(h->B, h->cfg.horizon, n_in, h->cfg.sampling_time, in_dt, t_offset, robot_mass, com_height, dComIn, dHIn, dP,
+                                                stream ? (hipStream_t)stream : h->stream);
+    if (rc != 0) return fail(h, CMPC_ERR_HIP, std::string("reference resampling launch: ") + hipGetErrorString((hipError_t)rc));
     return CMPC_OK;
 }
 
@@ -903,13 +908,16 @@ int cmpc_rollout_tick_device(cmpc_handle h, int max_contacts, double now, int wa
     if (max_contacts < 1 || !io->dListT || !io->dListPose || !io->dListN || !io->box_upper || !io->box_lower || !io->dState || !io->dP || !io->dX0 || !io->dX ||
         !io->dStateOut || !(io->plant_step > 0) || io->plant_substeps < 1)
         return fail(h, CMPC_ERR_ARG, "cmpc_rollout_tick_device: bad argument");
+    if ((io->dPlanCom || io->dPlanH) && (!io->dPlanCom || !io->dPlanH || io->plan_knots < 2 || !(io->plan_dt > 0) || !(io->robot_mass > 0)))
+        return fail(h, CMPC_ERR_ARG, "cmpc_rollout_tick_device: bad planner trajectory");
     HIPCHK(h, hipSetDevice(h->device));
     hipStream_t st = stream ? (hipStream_t)stream : h->stream;
     int rc = upload_box(h, io->box_upper, io->box_lower, st);
     if (rc != CMPC_OK) return rc;
     int lrc = cmpc_launch_tick_pre(h->B, h->cfg.horizon, max_contacts, h->cfg.sampling_time, now, merge ? 1 : 0, io->dPlanT, io->dPlanPose, io->dPlanN, io->dPrevT,
                                    io->dPrevPose, io->dPrevN, io->dListT, io->dListPose, io->dListN, io->dOk, io->dLand, h->dBox, io->dState, io->dWrench, io->dP,
-                                   warm ? io->dX : nullptr, io->dX0, st);
+                                   warm ? io->dX : nullptr, io->dX0, io->dPlanCom, io->dPlanH, io->plan_knots, io->plan_dt, io->plan_t_offset, io->robot_mass,
+                                   io->com_height, st);
     if (lrc != 0) return fail(h, CMPC_ERR_HIP, std::string("tick (front) launch: ") + hipGetErrorString((hipError_t)lrc));
     rc = solve_device_impl(h, io->dP, io->dX0, io->dX, io->dInfo, stream, warm != 0);
     if (rc != CMPC_OK) return rc;

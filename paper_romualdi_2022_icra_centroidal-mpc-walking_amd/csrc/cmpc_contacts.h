@@ -119,3 +119,24 @@ __host__ __device__ inline int cmpc_sample_foot(int N, double dt, double now, in
 {
     return cmpc_landing_knot(N, [&](int k) { return cmpc_sample_stage(N, dt, now, c, k, t, pose, n, box_upper, box_lower, p); });
 }
+
+
+// 8f-3, CentroidalMPCBlock.cpp:525-577: knot k of the references from the planner's trajectories (n_in knots every in_dt seconds, the first one t_offset seconds
+// before "now"; h_in not yet divided by the mass) by linear interpolation, clamped to the trajectory's ends; the CoM height is replaced by com_height unless it is
+// NaN (the reference forces 0.7, :534).  ci / hi: the problem's [n_in][3]; com_out / h_out: the knot's three entries of comRef / hRef.
+__host__ __device__ inline void cmpc_resample_reference_knot(const float* ci, const float* hi, int n_in, double in_dt, double t_offset, double dt, int k,
+                                                             double robot_mass, double com_height, float* com_out, float* h_out)
+{
+    double s = (t_offset + k * dt) / in_dt;
+    if (s < 0) s = 0;
+    if (s > n_in - 1) s = n_in - 1;
+    int i0 = (int)s;
+    if (i0 > n_in - 2) i0 = n_in - 2;
+    const double w = s - i0;
+    for (int a = 0; a < 3; ++a) {
+        double cv = (1 - w) * ci[3 * i0 + a] + w * ci[3 * (i0 + 1) + a];
+        if (a == 2 && com_height == com_height) cv = com_height;
+        com_out[a] = (float)cv;
+        h_out[a] = (float)(((1 - w) * hi[3 * i0 + a] + w * hi[3 * (i0 + 1) + a]) / robot_mass);
+    }
+}

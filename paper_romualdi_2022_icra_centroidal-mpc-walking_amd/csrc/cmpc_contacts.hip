@@ -89,7 +89,27 @@ __global__ __launch_bounds__(128) void cmpc_write_state_kernel(int B, int N, con
         }
 }
 
+// 8f-3 on the device: comRef / hRef of every problem from the planner's trajectories, one thread per knot (cmpc_resample_reference_knot)
+__global__ __launch_bounds__(64) void cmpc_reference_from_planner_kernel(int B, int N, int n_in, double dt, double in_dt, double t_offset, double robot_mass,
+                                                                         double com_height, const float* __restrict__ com_in, const float* __restrict__ h_in,
+                                                                         float* __restrict__ P)
+{
+    const int b = blockIdx.x;
+    const CmpcIdx L{N};
+    float* p = P + (size_t)b * L.np();
+    for (int k = threadIdx.x; k <= N; k += 64)
+        cmpc_resample_reference_knot(com_in + (size_t)b * n_in * 3, h_in + (size_t)b * n_in * 3, n_in, in_dt, t_offset, dt, k, robot_mass, com_height,
+                                     p + L.pComref() + 3 * k, p + L.pHref() + 3 * k);
+}
+
 }  // namespace
+
+extern "C" int cmpc_launch_reference_from_planner(int B, int N, int n_in, double dt, double in_dt, double t_offset, double robot_mass, double com_height,
+                                                  const float* com_in, const float* h_in, float* P, hipStream_t stream)
+{
+    hipLaunchKernelGGL(cmpc_reference_from_planner_kernel, dim3(B), dim3(64), 0, stream, B, N, n_in, dt, in_dt, t_offset, robot_mass, com_height, com_in, h_in, P);
+    return (int)hipGetLastError();
+}
 
 extern "C" int cmpc_launch_contacts_merge(int B, int M, double now, const double* plan_t, const float* plan_pose, const int* plan_n,
                                           const double* mpc_t, const float* mpc_pose, const int* mpc_n, double* out_t, float* out_pose,

@@ -751,7 +751,9 @@ __global__ __launch_bounds__(256) void cmpc_tick_pre_kernel(int B, int N, int M,
                                                             const int* plan_n, const double* prev_t, const float* prev_pose, const int* prev_n, double* list_t,
                                                             float* list_pose, int* list_n, int* ok, int* land, const float* __restrict__ box,
                                                             const float* __restrict__ state, const float* __restrict__ wrench, float* P,
-                                                            const float* __restrict__ Xprev, float* __restrict__ X0)
+                                                            const float* __restrict__ Xprev, float* __restrict__ X0, const float* __restrict__ plan_com,
+                                                            const float* __restrict__ plan_h, int plan_knots, double plan_dt, double plan_t_offset,
+                                                            double robot_mass, double com_height)
 {
     const int b = blockIdx.x, tid = threadIdx.x;
     const CmpcIdx L{N};
@@ -768,6 +770,10 @@ __global__ __launch_bounds__(256) void cmpc_tick_pre_kernel(int B, int N, int M,
             p[L.pText() + e] = wrench[((size_t)b * N + k) * 6 + 3 + i];
         }
     if (Xprev) warm_shift_problem(N, Xprev + (size_t)b * L.nx(), X0 + (size_t)b * L.nx(), tid, 256);
+    if (plan_com)   // setReferenceTrajectory from the planner's trajectories (8f-3), one thread per knot, from the far end of the workgroup
+        for (int k = 255 - tid; k <= N; k += 256)
+            cmpc_resample_reference_knot(plan_com + (size_t)b * plan_knots * 3, plan_h + (size_t)b * plan_knots * 3, plan_knots, plan_dt, plan_t_offset, dt, k,
+                                         robot_mass, com_height, p + L.pComref() + 3 * k, p + L.pHref() + 3 * k);
     if (tid < 2) {
         const int e = 2 * b + tid;
         const size_t o = (size_t)e * M;
@@ -823,10 +829,12 @@ __global__ __launch_bounds__(256) void cmpc_tick_post_kernel(int B, int N, int M
 extern "C" int cmpc_launch_tick_pre(int B, int N, int M, double dt, double now, int merge, const double* plan_t, const float* plan_pose, const int* plan_n,
                                     const double* prev_t, const float* prev_pose, const int* prev_n, double* list_t, float* list_pose, int* list_n, int* ok,
                                     int* land, const float* box, const float* state, const float* wrench, float* P, const float* Xprev, float* X0,
-                                    hipStream_t stream)
+                                    const float* plan_com, const float* plan_h, int plan_knots, double plan_dt, double plan_t_offset, double robot_mass,
+                                    double com_height, hipStream_t stream)
 {
     hipLaunchKernelGGL(cmpc_tick_pre_kernel, dim3(B), dim3(256), 0, stream, B, N, M, dt, now, merge, plan_t, plan_pose, plan_n, prev_t, prev_pose, prev_n,
-                       list_t, list_pose, list_n, ok, land, box, state, wrench, P, Xprev, X0);
+                       list_t, list_pose, list_n, ok, land, box, state, wrench, P, Xprev, X0, plan_com, plan_h, plan_knots, plan_dt, plan_t_offset, robot_mass,
+                       com_height);
     return (int)hipGetLastError();
 }
 

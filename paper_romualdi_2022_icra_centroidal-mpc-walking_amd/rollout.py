@@ -86,7 +86,7 @@ class WalkingRollout:
         finally:
             cur.wait_stream(ls)
 
-    def _tick_by_steps(self, i, now, mpc_prev, warm, dump, dP, dX0, dX, dInfo, state, wrench, dpush, push_ticks, ref_x0, ref_x):
+    def _tick_by_steps(self, i, now, mpc_prev, warm, dump, dP, dX0, dX, dInfo, state, wrench, dpush, push_ticks, planner):
         """one tick as seven calls of the C ABI with the host between them (cold starts, retry="launch", the dump hook; native_tick=False)"""
         torch, L, cfg, B, N = self.torch, self.L, self.cfg, self.B, self.cfg.N
         dt, dev, s = cfg.sampling_time, self.dev, self.solver
@@ -100,7 +100,7 @@ class WalkingRollout:
             #  its blocks of dP as they were and writes land = -2, the adjustment kernel skips it -- include/cmpc.h)
             lists, ok = s.contacts_merge_device(now, self.plan, mpc_prev)
         land = s.contacts_sample_device(now, lists, dP)
-        torch.add(ref_x0, self.com_speed * now, out=ref_x)
+        s.write_reference_from_planner_device(planner[0], planner[1], planner[2], planner[3], planner[4], planner[5], dP)
         if dpush is not None and i <= push_ticks:      # (the wrench rows of dP change while the push lasts and once more when it ends; zero from the start otherwise)
             wrench.zero_()
             if i < push_ticks:
@@ -164,13 +164,14 @@ class WalkingRollout:
         state = torch.from_numpy(np.concatenate([com0, dcom0, h0], 1).astype(np.float32)).to(dev)
         wrench = torch.zeros((B, N, 6), dtype=torch.float32, device=dev)
         dpush = torch.from_numpy(np.asarray(push, np.float32)).to(dev) if push is not None else None
-        # references at the knots (CentroidalMPCBlock.cpp:525-577 resamples the planner's; here a straight line at the plan's mean speed): y and z never
-        # change and no kernel of the tick writes those entries of dP, so they are written once; x is ONE launch per tick (ref_x0 + speed * now)
-        ref = dP[:, L.p_comref:L.p_comref + 3 * (N + 1)].view(B, N + 1, 3)
-        ref[:, :, 1] = 0.0
-        ref[:, :, 2] = 0.7
-        ref_x = ref[:, :, 0]
-        ref_x0 = (self.com_speed * dt * torch.arange(N + 1, dtype=torch.float32, device=dev))[None, :].expand(B, N + 1)
+        # references (CentroidalMPCBlock.cpp:525-577 resamples the planner's trajectories at the MPC knots): the planner here is a straight line at the plan's mean
+        # speed and zero angular momentum, a knot every dt from time zero to the end of the last tick's horizon -- resampled on the device every tick
+        # (cmpc_write_reference_from_planner_device; inside cmpc_rollout_tick_device for the warm ticks), CoM height forced to 0.7 as the reference does (:534)
+        n_plan = ticks + N + 2
+        plan_com = torch.zeros((B, n_plan, 3), dtype=torch.float32, device=dev)
+        plan_com[:, :, 0] = (self.com_speed * dt * torch.arange(n_plan, dtype=torch.float64, device=dev)).to(torch.float32)[None, :]
+        plan_h = torch.zeros_like(plan_com)
+        planner = lambda now: (plan_com, plan_h, dt, now, 1.0, 0.7)
         import time
         rec = dict(iterations_mean=[], iterations_max=[], converged=[], merge_ok=[], com=[], land=[], landing_offset=[], solve_ms=[], zmp=[],
                    tick_ms=[], retried=[], unconverged=[])
@@ -191,7 +192,6 @@ class WalkingRollout:
                 lists = tick_bufs[0][i & 1] if mpc_prev[0] is not tick_bufs[0][i & 1][0] else tick_bufs[0][1 - (i & 1)]
                 ok = torch.empty((B,), dtype=torch.int32, device=dev)
                 land, zmp = tick_bufs[1], tick_bufs[2]
-                torch.add(ref_x0, self.com_speed * now, out=ref_x)
                 wr = None
                 if dpush is not None and i <= push_ticks:
                     wrench.zero_()
@@ -199,11 +199,11 @@ class WalkingRollout:
                         wrench[:, :max(push_ticks - i, 1), :3] = dpush[:, None, :]
                     wr = wrench
                 s.rollout_tick_device(now, self.plan, mpc_prev, lists, ok, land, state, wr, dP, dX0, dX, dInfo, state, zmp, True,
-                                      step=dt / self.substeps, substeps=self.substeps)
+                                      step=dt / self.substeps, substeps=self.substeps, planner=planner(now))
                 mpc_prev = lists
                 nretry = 0
             else:
-                ok, lists, land, nretry, state, zmp = self._tick_by_steps(i, now, mpc_prev, warm, dump, dP, dX0, dX, dInfo, state, wrench, dpush, push_ticks, ref_x0, ref_x)
+                ok, lists, land, nretry, state, zmp = self._tick_by_steps(i, now, mpc_prev, warm, dump, dP, dX0, dX, dInfo, state, wrench, dpush, push_ticks, planner(now))
                 mpc_prev = lists
             torch.cuda.synchronize()
             tick_ms = (time.perf_counter() - t_tick) * 1e3

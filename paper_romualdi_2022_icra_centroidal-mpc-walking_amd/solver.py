@@ -236,8 +236,15 @@ class BatchSolver:
         self._launch(dP.device, lambda st: self._lib.cmpc_write_state_device(
             self._h, dState.data_ptr(), dWrench.data_ptr() if dWrench is not None else None, dP.data_ptr(), st))
 
+    def write_reference_from_planner_device(self, dComIn, dHIn, in_dt, t_offset, robot_mass, com_height, dP):
+        """setReferenceTrajectory from the planner's trajectories (8f-3) on the device: dComIn / dHIn [B, n_in, 3] float32 CUDA tensors -> comRef / hRef rows of dP."""
+        assert dComIn.is_contiguous() and dHIn.is_contiguous() and dComIn.shape == dHIn.shape and dComIn.shape[0] == self.batch
+        self._launch(dP.device, lambda st: self._lib.cmpc_write_reference_from_planner_device(
+            self._h, dComIn.data_ptr(), dHIn.data_ptr(), int(dComIn.shape[1]), float(in_dt), float(t_offset), float(robot_mass),
+            float("nan") if com_height is None else float(com_height), dP.data_ptr(), st))
+
     def rollout_tick_device(self, now, plan, prev, lists, ok, land, dState, dWrench, dP, dX0, dX, dInfo, dStateOut, dZmp, warm,
-                            step=0.01, substeps=6, zmp_half_x=0.08, zmp_half_y=0.03):
+                            step=0.01, substeps=6, zmp_half_x=0.08, zmp_half_y=0.03, planner=None):
         """cmpc_rollout_tick_device: merge -> sample -> setState -> shift -> solve -> step adjustment -> plant as ONE call (include/cmpc.h); plan / prev /
         lists = (t, pose, n) CUDA tensors, prev None on the first tick (lists is then taken as filled by the caller); dWrench may be None."""
         from ._capi import CmpcTickIO
@@ -250,6 +257,10 @@ class BatchSolver:
                         ptr(lists[0]), ptr(lists[1]), ptr(lists[2]), ptr(ok), ptr(land), self._box[0].ctypes.data, self._box[1].ctypes.data,
                         ptr(dState), ptr(dWrench), ptr(dP), ptr(dX0), ptr(dX), ptr(dInfo), ptr(dStateOut), ptr(dZmp),
                         float(step), int(substeps), float(zmp_half_x), float(zmp_half_y))
+        if planner is not None:   # (dComIn, dHIn, in_dt, t_offset, robot_mass, com_height): the tick writes the reference rows itself
+            pc, ph, pdt, poff, mass, height = planner
+            io.dPlanCom, io.dPlanH, io.plan_knots, io.plan_dt, io.plan_t_offset = pc.data_ptr(), ph.data_ptr(), int(pc.shape[1]), float(pdt), float(poff)
+            io.robot_mass, io.com_height = float(mass), float("nan") if height is None else float(height)
         self._launch(dP.device, lambda st: self._lib.cmpc_rollout_tick_device(self._h, lists[0].shape[2], float(now), 1 if warm else 0, io, st))
 
     def shift_solution_device(self, dXprev, dX0):

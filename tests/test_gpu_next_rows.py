@@ -122,3 +122,30 @@ def test_warm_start_saves_iterations_in_receding_horizon():
     for b in range(B):  # same closed-loop trajectory either way
         e = parity.errors(cfg.N, P[b], sols["warm"][b], sols["cold"][b])
         assert e["com"] < 1e-4 and e["force0"] < 1e-4, e
+
+
+@pytest.mark.parametrize("com_height", [0.7, None])
+def test_device_reference_resampling_matches_the_oracle_tensor_for_tensor(com_height):
+    """cmpc_write_reference_from_planner_device (8f-3 on the device, CentroidalMPCBlock.cpp:525-577) against oracle/plant_ref.resample_references: the comRef / hRef rows of
+    dP themselves, 1e-6, including offsets before the trajectory's start and beyond its end (clamped) and the planner's own CoM height (NaN = None)."""
+    import torch
+    from oracle import plant_ref
+    cfg = cm.config.ergocub_gazebo_v1()
+    B, M, N = 6, 40, cfg.N
+    L = cm.Layout(N)
+    rng = np.random.default_rng(8)
+    com_in = (np.cumsum(rng.normal(scale=0.005, size=(B, M, 3)), axis=1) + [0, 0, 0.72]).astype(np.float32)
+    h_in = rng.normal(scale=2.0, size=(B, M, 3)).astype(np.float32)
+    s = cm.BatchSolver(cfg, B)
+    for t_offset in (-0.05, 0.04, 0.31, 0.9):       # 0.9 + 20 * 0.06 s runs past the 0.78 s the trajectory covers
+        dP = torch.full((B, L.np), 7.0, dtype=torch.float32, device="cuda")
+        s.write_reference_from_planner_device(torch.from_numpy(com_in).cuda(), torch.from_numpy(h_in).cuda(), 0.02, t_offset, 56.0, com_height, dP)
+        torch.cuda.synchronize()
+        P = dP.cpu().numpy()
+        for b in range(B):
+            cr, hr = plant_ref.resample_references(com_in[b].astype(np.float64), h_in[b].astype(np.float64), 0.02, t_offset, N, cfg.sampling_time, 56.0,
+                                                   com_height if com_height is not None else float("nan"))
+            np.testing.assert_allclose(P[b, L.p_comref:L.p_comref + 3 * (N + 1)], cr.reshape(-1), rtol=0, atol=1e-6)
+            np.testing.assert_allclose(P[b, L.p_href:L.p_href + 3 * (N + 1)], hr.reshape(-1), rtol=0, atol=1e-6)
+        rest = np.ones(L.np, bool); rest[L.p_comref:L.p_href + 3 * (N + 1)] = False
+        assert (P[:, rest] == 7.0).all()             # nothing else of dP is touched
