@@ -361,7 +361,7 @@ class Runner:
                 "value": round(self.world * B * ticks / elapsed, 1), "unit": "solves/s", "scaling": "weak",
                 "ticks_per_s": round(ticks / elapsed, 1), "ticks": ticks, "batch_per_gpu": B,
                 "tick_latency_ms": {"p50": round(float(np.median(pr[:, 4])), 3), "p99": round(float(pr[:, 5].max()), 3), "max": round(float(pr[:, 3].max()), 3),
-                                    "what": "wall clock of one tick on one rank: the reference write, the tick call, the wait for the stream"},
+                                    "what": "wall clock of one tick on one rank: the tick call (references from the planner trajectory inside it) and the wait for the stream"},
                 "iterations_mean_per_tick": round(float(pr[:, 2].mean()), 2), "iterations_max": int(pr[:, 1].max()),
                 "iterations_mean_first_ticks": [round(v, 2) for v in rec["iterations_mean"][:20]],
                 "iterations_max_by_tick": rec["iterations_max"],
