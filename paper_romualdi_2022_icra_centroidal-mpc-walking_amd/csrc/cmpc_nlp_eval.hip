@@ -673,7 +673,8 @@ __device__ inline void plant_step_problem(int N, int b, float grav, const float*
             double fl[3];
             for (int i = 0; i < 3; ++i) {
                 cp[4 * c + j][i] = (double)x[L.oPos(c) + i] + (double)R[i] * cn[0] + (double)R[3 + i] * cn[1] + (double)R[6 + i] * cn[2];
-                cf[4 * c + j][i] = on ? (double)x[L.oF(c, j) + i] : 0.0;
+                const float fv = x[L.oF(c, j) + i];   // (loaded whatever `on` is: a load behind the contact flag is a second global-memory round trip on this one-thread chain)
+                cf[4 * c + j][i] = on ? (double)fv : 0.0;
                 fsum[i] += cf[4 * c + j][i];
             }
             for (int i = 0; i < 3; ++i) fl[i] = (double)R[3 * i] * cf[4 * c + j][0] + (double)R[3 * i + 1] * cf[4 * c + j][1] + (double)R[3 * i + 2] * cf[4 * c + j][2];
@@ -774,30 +775,64 @@ __global__ __launch_bounds__(256) void cmpc_tick_pre_kernel(int B, int N, int M,
         for (int k = 255 - tid; k <= N; k += 256)
             cmpc_resample_reference_knot(plan_com + (size_t)b * plan_knots * 3, plan_h + (size_t)b * plan_knots * 3, plan_knots, plan_dt, plan_t_offset, dt, k,
                                          robot_mass, com_height, p + L.pComref() + 3 * k, p + L.pHref() + 3 * k);
-    if (tid < 2) {
+    // the merge scans its lists entry by entry: from LDS (the workgroup fetches both feet's lists of the planner and of the previous tick in one round trip) when they
+    // fit, else from global memory as the single kernel does -- the same function on the same values either way
+    constexpr int MS = 16;
+    __shared__ double st_[2][2 * 2 * MS];      // [planner | previous][foot][M][2]
+    __shared__ float sp_[2][2 * 7 * MS];
+    const bool staged = merge && M <= MS;
+    if (staged) {
+        const size_t o2 = (size_t)(2 * b) * M;
+        for (int e = tid; e < 4 * M; e += 256) { st_[0][e] = plan_t[2 * o2 + e]; st_[1][e] = prev_t[2 * o2 + e]; }
+        for (int e = tid; e < 14 * M; e += 256) { sp_[0][e] = plan_pose[7 * o2 + e]; sp_[1][e] = prev_pose[7 * o2 + e]; }
+        __syncthreads();
+    }
+    // this tick's lists live in LDS too (so_*): the merge writes them there, the sampling threads scan them there, and the workgroup copies them out
+    __shared__ double so_t[2 * 2 * MS];
+    __shared__ float so_p[2 * 7 * MS];
+    __shared__ int so_n[2];
+    const bool lstaged = M <= MS;
+    const size_t ob = (size_t)(2 * b) * M;
+    if (lstaged && !merge) {   // (first tick: the caller filled the lists)
+        for (int e = tid; e < 4 * M; e += 256) so_t[e] = list_t[2 * ob + e];
+        for (int e = tid; e < 14 * M; e += 256) so_p[e] = list_pose[7 * ob + e];
+        if (tid < 2) so_n[tid] = list_n[2 * b + tid];
+    }
+    if (tid < 2 && merge) {
         const int e = 2 * b + tid;
         const size_t o = (size_t)e * M;
-        if (merge) {
-            const bool sane = plan_n[e] >= 0 && plan_n[e] <= M && prev_n[e] >= 0 && prev_n[e] <= M;
-            if (!sane) list_n[e] = 0;
-            const bool good = sane && cmpc_merge_foot(now, plan_t + 2 * o, plan_pose + 7 * o, plan_n[e], prev_t + 2 * o, prev_pose + 7 * o, prev_n[e], M,
-                                                      list_t + 2 * o, list_pose + 7 * o, list_n + e);
-            if (!good) atomicAnd(&okw, 0);
-        }
+        const int pn = plan_n[e], mn = prev_n[e];
+        const bool sane = pn >= 0 && pn <= M && mn >= 0 && mn <= M;
+        int* on = lstaged ? &so_n[tid] : list_n + e;
+        if (!sane) *on = 0;
+        const double* pt = staged ? st_[0] + 2 * M * tid : plan_t + 2 * o;
+        const double* mt = staged ? st_[1] + 2 * M * tid : prev_t + 2 * o;
+        const float* pq = staged ? sp_[0] + 7 * M * tid : plan_pose + 7 * o;
+        const float* mq = staged ? sp_[1] + 7 * M * tid : prev_pose + 7 * o;
+        const bool good = sane && cmpc_merge_foot(now, pt, pq, pn, mt, mq, mn, M, lstaged ? so_t + 2 * M * tid : list_t + 2 * o,
+                                                  lstaged ? so_p + 7 * M * tid : list_pose + 7 * o, on);
+        if (!good) atomicAnd(&okw, 0);
     }
-    __syncthreads();   // (the merged lists of the two feet are in global memory, visible to the workgroup)
+    __syncthreads();   // (the merged lists of the two feet are visible to the workgroup: in LDS, or in global memory when they do not fit)
+    if (lstaged && merge) {   // out to global memory, the entries in use (what the single merge kernel writes)
+        for (int e = tid; e < 4 * M; e += 256) { const int c = e / (2 * M); if (e - c * 2 * M < 2 * so_n[c]) list_t[2 * ob + e] = so_t[e]; }
+        for (int e = tid; e < 14 * M; e += 256) { const int c = e / (7 * M); if (e - c * 7 * M < 7 * so_n[c]) list_pose[7 * ob + e] = so_p[e]; }
+        if (tid < 2) list_n[2 * b + tid] = so_n[tid];
+    }
     // sampling: one thread per (foot, stage) -- a single thread walking the N stages of a foot one global-memory round trip at a time was 33 of this kernel's
     // 39 us (rocprofv3, profiles/r04_rollout_tick_overhead.txt); the landing knot then comes from the stages' contact flags in LDS
     __shared__ unsigned char acts[2][CMPC_NMAX];
     for (int e2 = tid; e2 < 2 * N; e2 += 256) {
         const int cft = e2 / N, k = e2 - cft * N, e = 2 * b + cft;
         const size_t o = (size_t)e * M;
-        const int n = list_n[e];
-        if (n >= 1 && n <= M) acts[cft][k] = cmpc_sample_stage(N, dt, now, cft, k, list_t + 2 * o, list_pose + 7 * o, n, box, box + 6, p) ? 1 : 0;
+        const int n = lstaged ? so_n[cft] : list_n[e];
+        if (n >= 1 && n <= M)
+            acts[cft][k] = cmpc_sample_stage(N, dt, now, cft, k, lstaged ? so_t + 2 * M * cft : list_t + 2 * o, lstaged ? so_p + 7 * M * cft : list_pose + 7 * o, n, box,
+                                             box + 6, p) ? 1 : 0;
     }
     __syncthreads();
     if (tid < 2) {
-        const int e = 2 * b + tid, n = list_n[e];
+        const int e = 2 * b + tid, n = lstaged ? so_n[tid] : list_n[e];
         land[e] = (n < 1 || n > M) ? -2 : cmpc_landing_knot(N, [&](int k) { return acts[tid][k] != 0; });
     }
     if (merge && ok && tid == 0) ok[b] = okw;
